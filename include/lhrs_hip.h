@@ -1,0 +1,120 @@
+/* lhrs_hip.h - C ABI of the MI355X (gfx950) engine for the LHRS-Bot hot path
+ *
+ *   CLIP ViT-L/14  ->  AttnPooler projector  ->  LLaMA2-7B (+LoRA)   forward / backward / optimizer step
+ *
+ * The reference (NJU-LHRS/LHRS-Bot) is 100 % Python and has no FFI of its own; every entry point below replaces
+ * the torch / transformers / deepspeed / timm operator that the cited reference line reaches.  The shared
+ * library built from lhrs_bot_amd/csrc (liblhrs_hip.so) exports exactly these symbols.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated; the caller owns all buffers including workspaces,
+ *     the library never allocates device memory;
+ *   - lhrs_bf16_t is raw bfloat16 bits; matrices are row-major with an explicit leading dimension in ELEMENTS;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued, never synchronised;
+ *   - return value 0 = enqueued, -1 = rejected (message via lhrs_last_error(), thread-local); no exceptions;
+ *   - one host thread per GPU/rank (the reference runs one process per GPU: Script/train_stage1.sh:6-17).
+ */
+#ifndef LHRS_HIP_H
+#define LHRS_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t lhrs_bf16_t;
+
+/* ---- library ---------------------------------------------------------------------------------------- */
+const char* lhrs_last_error(void);
+int lhrs_abi_version(void);
+const char* lhrs_target_arch(void); /* "gfx950" */
+
+/* ---- GEMM (bf16 MFMA) ------------------------------------------------------------------------------- *
+ * C[M,N] = act(alpha * A[M,K] . B[N,K]^T + bias[N]) + residual[M,N]
+ * Replaces every nn.Linear on the path: HF CLIPAttention/CLIPMLP and LlamaAttention/LlamaMLP/lm_head reached
+ * from lhrs/models/rgb_vision_modal.py:166-172 and lhrs/models/text_modal.py:281-292; nn.MultiheadAttention
+ * in/out projections and the c_fc/c_proj MLP of lhrs/models/common_arch.py:276-295,302-333; AttnPooler.out_proj
+ * (common_arch.py:132,171); and their backward products (dX = dY.W, dW = dY^T.X, both expressed as NT).
+ * act: 0 none, 1 quick_gelu (CLIP), 2 gelu-erf (pooler), 3 silu.  out_f32: C is float (for weight gradients);
+ * accumulate (f32 only): C += result.  K % 64 == 0, N % 4 == 0, lda/ldb % 8 == 0. */
+int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                      const void* bias, const void* residual, int ldr, int act, int out_f32, int accumulate,
+                      float alpha, void* stream);
+
+/* ---- normalisation ---------------------------------------------------------------------------------- *
+ * LayerNorm: lhrs/models/common_arch.py:253-259 (+ HF CLIP pre_layrnorm / layer_norm1/2); eps 1e-5.
+ * RMSNorm : HF LlamaRMSNorm inside CustomLlamaForCausalLM (lhrs/models/text_modal.py:30-60).            */
+int lhrs_layernorm_fwd(const void* x, long ldx, const void* gamma, const void* beta, void* y, long ldy, float* mean,
+                       float* rstd, int rows, int cols, float eps, void* stream);
+int lhrs_layernorm_bwd_nblk(int rows); /* host helper: workspace rows */
+int lhrs_layernorm_bwd(const void* dy, long ld_dy, const void* x, long ldx, const void* gamma, const float* mean,
+                       const float* rstd, void* dx, long ld_dx, float* dgamma, float* dbeta, float* partial,
+                       int accumulate, int rows, int cols, void* stream);
+int lhrs_rmsnorm_fwd(const void* x, long ldx, const void* w, void* y, long ldy, float* rstd, int rows, int cols,
+                     float eps, void* stream);
+int lhrs_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* add, void* dx,
+                     int rows, int cols, float eps, void* stream);
+
+/* ---- attention -------------------------------------------------------------------------------------- *
+ * desc: int32 [nseq][8] = {q_off, q_len, kv_off, kv_len, kv_rows, causal_off, 0, 0} (token offsets/lengths).
+ * Replaces HF CLIPAttention, nn.MultiheadAttention (common_arch.py:302-313) and HF LlamaAttention
+ * (causal + key-padding from `attention_mask`, text_modal.py:281-292).  D = 64 or 128.
+ * *_T operands are [nseq][H*D][LT] zero-padded token-transposed copies made by lhrs_seq_transpose.       */
+int lhrs_seq_transpose(const void* in, long ld_in, void* out, int cols, int LT, const int* desc, int nseq, int use_kv,
+                       void* stream);
+int lhrs_attn_fwd(const void* q, long ldq, const void* k, long ldk, const void* vT, void* o, long ldo, float* lse,
+                  const int* desc, int nseq, int H, int D, int max_q, int LTq, int LTkv, int causal, float scale,
+                  void* stream);
+int lhrs_attn_delta(const void* o, long ldo, const void* dout, long ld_do, float* delta, const int* desc, int nseq, int H,
+                    int D, int max_q, int LTq, void* stream);
+int lhrs_attn_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout,
+                  long ld_do, const void* qT, const void* kT, const void* doT, const float* lse, const float* delta,
+                  void* dq, long ld_dq, void* dk, long ld_dk, void* dv, long ld_dv, const int* desc, int nseq, int H,
+                  int D, int max_q, int max_kv, int LTq, int LTkv, int causal, float scale, void* stream);
+
+/* ---- element-wise / layout -------------------------------------------------------------------------- *
+ * patchify/assemble: HF CLIPVisionEmbeddings (rgb_vision_modal.py:166-172); rope: HF apply_rotary_pos_emb;
+ * swiglu: HF LlamaMLP; map: nn.GELU of common_arch.py:286-292 (+ its derivative), residual add.          */
+int lhrs_patchify(const float* rgb, void* out, int B, int img, int P, int KP, void* stream);
+int lhrs_vit_assemble(const void* patch, const void* cls, const void* pos, void* out, int B, int NP, int dim,
+                      void* stream);
+int lhrs_rope(void* x, long ld, int rows, int nheads, int D, const float* cos_t, const float* sin_t, const int* pos_ids,
+              int pos_mod, int pos0, int inverse, void* stream);
+int lhrs_swiglu_fwd(const void* gate_up, void* act, long rows, int F, void* stream);
+int lhrs_swiglu_bwd(const void* dact, const void* gate_up, void* dgate_up, long rows, int F, void* stream);
+int lhrs_map(int op, const void* a, const void* b, void* out, long n, void* stream);
+int lhrs_colsum_nsplit(int rows); /* host helper */
+int lhrs_colsum(const void* x, long ld, float* out, float* partial, int rows, int cols, int accumulate, void* stream);
+int lhrs_cast_f32_to_bf16(const float* in, void* out, long n, void* stream);
+int lhrs_cast_bf16_to_f32(const void* in, float* out, long n, void* stream);
+int lhrs_transpose(const void* in, long ld_in, void* out, long ld_out, int rows, int cols, int rows_pad, void* stream);
+
+/* ---- token side ------------------------------------------------------------------------------------- *
+ * splice: TextModal.prepare_inputs_for_multimodal (lhrs/models/text_modal.py:296-526); bit-exact.
+ * cross_entropy: shifted CE (ignore -100) of HF LlamaForCausalLM.forward, mean over valid targets.       */
+int lhrs_splice_fwd(const long* ids, const long* labels, const uint8_t* mask, const void* image, const void* embed,
+                    void* out_embeds, long* out_labels, uint8_t* out_mask, int* img_pos, int B, int T, int NI, int dim,
+                    int S, int vocab, void* stream);
+int lhrs_splice_bwd(const void* d_embeds, const int* img_pos, void* d_image, int B, int NI, int dim, int S, void* stream);
+int lhrs_gather_rows(const void* src, long ld_src, const int* idx, void* dst, long ld_dst, int n, int dim, void* stream);
+int lhrs_scatter_rows(const void* src, long ld_src, const int* idx, void* dst, long ld_dst, int n, int dim, void* stream);
+int lhrs_cross_entropy(const void* logits, long ld, const int* target, float* row_loss, float* loss_out, void* dlogits,
+                       long ld_d, int n, int V, void* stream);
+
+/* ---- optimizer -------------------------------------------------------------------------------------- *
+ * Adan(no_prox) = timm "adanp" built at lhrs/optimizer/build_optimizer.py:76-86; AdamW + global-norm clip =
+ * DeepSpeed engine.step() configured at main_pretrain_stage1.py:28-85 and driven by
+ * lhrs/CustomTrainer/hook/deepspeed_hook.py:4-19.                                                         */
+int lhrs_sqnorm_nblk(long n); /* host helper */
+int lhrs_sqnorm(const float* g, long n, float* partial, float* out, int accumulate, void* stream);
+int lhrs_adan_step(float* param, const float* grad, float* exp_avg, float* exp_avg_diff, float* exp_avg_sq,
+                   float* pre_grad, void* shadow_bf16, long n, int step, float lr, float beta1, float beta2, float beta3,
+                   float eps, float weight_decay, int no_prox, const float* gnorm_sq, float max_norm, float grad_scale,
+                   void* stream);
+int lhrs_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, long n,
+                    int step, float lr, float beta1, float beta2, float eps, float weight_decay, const float* gnorm_sq,
+                    float max_norm, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LHRS_HIP_H */

@@ -1,0 +1,79 @@
+"""ctypes binding of liblhrs_hip.so (the C ABI declared in include/lhrs_hip.h).
+
+The prototypes are parsed from the header itself, so the header is the single source of truth and the
+`-m "not gpu"` test-suite can check that the library exports every declared symbol.  There is NO fallback:
+if the library is missing or a call is rejected, a RuntimeError is raised (the product path must fail loudly
+when the HIP extension is absent - it never routes through oracle/ or a CPU path).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_HERE)
+HEADER = os.path.join(REPO_ROOT, "include", "lhrs_hip.h")
+LIB_PATH = os.path.join(_HERE, "csrc", "liblhrs_hip.so")
+
+_PROTO = re.compile(r"^\s*(const\s+char\s*\*|int|void)\s+(lhrs_\w+)\s*\(([^;{]*)\)\s*;", re.M | re.S)
+
+
+def _strip_comments(text: str) -> str:
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    return re.sub(r"//[^\n]*", " ", text)
+
+
+def _ctype_of(param: str):
+    p = param.strip()
+    if "*" in p:
+        return ctypes.c_void_p
+    base = p.rsplit(" ", 1)[0] if " " in p else p
+    if "float" in base:
+        return ctypes.c_float
+    if "long" in base:
+        return ctypes.c_long
+    if "int" in base or "uint8_t" in base:
+        return ctypes.c_int
+    raise ValueError(f"unparsed C parameter: {param!r}")
+
+
+def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:
+    """-> {symbol: (restype, [argtypes])} for every prototype in the header."""
+    text = _strip_comments(open(path).read())
+    out: Dict[str, Tuple[object, List[object]]] = {}
+    for ret, name, params in _PROTO.findall(text):
+        params = " ".join(params.split())
+        args = [] if params in ("", "void") else [_ctype_of(p) for p in params.split(",")]
+        restype = ctypes.c_char_p if "char" in ret else (None if ret.strip() == "void" else ctypes.c_int)
+        out[name] = (restype, args)
+    return out
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library; raise (never fall back) if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the LHRS hot path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in parse_header().items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().lhrs_last_error()
+        raise RuntimeError(f"{what} rejected by liblhrs_hip: {msg.decode() if msg else 'unknown error'}")

@@ -1,0 +1,486 @@
+// Flash-style attention forward / backward on bf16 MFMA for gfx950 (64-lane wavefronts, LDS-staged K/V tiles,
+// online softmax in fp32 by wavefront reduction).  One kernel family serves the three attentions on the
+// LHRS-Bot hot path:
+//   * CLIP ViT self-attention      (16 heads x 64, N = 257, no mask)           - HF CLIPAttention
+//   * AttnPooler cross-attention   (16 heads x 64, (Lq,Lkv) = (64,320),(48,304),(32,288); forward + backward)
+//                                  - nn.MultiheadAttention in lhrs/models/common_arch.py:276,302-313
+//   * LLaMA causal self-attention  (32 heads x 128, causal + key-padding length; forward + backward)
+//                                  - HF LlamaAttention called from lhrs/models/text_modal.py:281-292
+//
+// Sequences are described by 8-int records {q_off, q_len, kv_off, kv_len, kv_rows, causal_off, -, -}: token
+// offsets into the row-major activations, so ragged batches (the pooler's three query groups) run in one launch.
+//
+// MFMA data flow.  Every product is v_mfma_f32_16x16x32_bf16, whose A and B operands both hold, per lane,
+// 8 k-contiguous values of row/col (lane&15), and whose result holds 4 consecutive rows of column (lane&15).
+// Products are therefore arranged so that (a) the softmax row index is always (lane&15) - row statistics are
+// per-lane scalars plus two xor-shuffles - and (b) a result fragment is reused directly as the next MFMA's B
+// operand: the MFMA k-slot <-> key (or query) assignment is a fixed permutation, applied identically to the
+// register operand and to the LDS operand, which is legal because k is summed over.
+//   forward :  S^T = K . Q^T  (A = K tile, B = Q regs)   ->  P  ->  O^T  = V^T . P^T (A = V^T tile, B = P regs)
+//   dQ      :  S^T, dP^T = V . dO^T -> dS ->  dQ^T = K^T . dS^T (A = K^T tile, B = dS regs)
+//   dK, dV  :  S = Q . K^T (A = Q tile, B = K regs), dP = dO . V^T -> P, dS ->
+//              dV^T = dO^T . P (A = dO^T tile, B = P regs),  dK^T = Q^T . dS (A = Q^T tile, B = dS regs)
+// The operands that must be contiguous along the token axis (V^T, K^T, Q^T, dO^T) are read from transposed,
+// zero-padded copies [seq][H*D][LT] produced by lhrs_seq_transpose (HBM-bound, ~1-2 % of a layer).
+#include "common.h"
+
+namespace {
+
+struct AttnArgs {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* dout;  // row-major [tokens, ld]
+  long ldq, ldk, ldv, ldo, ld_do, ld_dq, ld_dk, ld_dv;
+  bf16_t* o; bf16_t* dq; bf16_t* dk; bf16_t* dv;
+  const bf16_t* qT; const bf16_t* kT; const bf16_t* vT; const bf16_t* doT;  // [seq][H*D][LT*]
+  int LTq, LTkv;      // padded lengths of the transposed copies / lse rows (multiples of 64)
+  float* lse;         // [seq][H][LTq]
+  const float* delta; // [seq][H][LTq]
+  const int* desc;    // [nseq][8]
+  int H;
+  float scale;
+};
+
+constexpr float NEG_INF = -__builtin_huge_valf();
+
+// ---- LDS tile images ----------------------------------------------------------------------------
+// row-major tile [64][D]: 16-B chunk index XOR (row & (chunks-1))  -> ds_read_b128 fragments
+template <int D>
+__device__ __forceinline__ int rm_off(int row, int c) {
+  constexpr int CH = D / 8;
+  return row * (D * 2) + ((c ^ (row & (CH - 1))) << 4);
+}
+// transposed tile [D][64 tokens]: 8-B unit index XOR (((d>>1)&7)<<1) -> ds_read_b64 fragment halves
+__device__ __forceinline__ int t_off8(int d, int u) { return d * 128 + ((u ^ (((d >> 1) & 7) << 1)) << 3); }
+__device__ __forceinline__ int t_off16(int d, int c) { return d * 128 + ((c ^ ((d >> 1) & 7)) << 4); }
+
+template <int D>
+__device__ __forceinline__ void load_rm_tile(char* lds, const bf16_t* base, long ld, int row0, int len, int tid) {
+  constexpr int CH = D / 8;
+#pragma unroll
+  for (int i = tid; i < 64 * CH; i += 256) {
+    const int r = i / CH, c = i % CH;
+    const int gr = min(row0 + r, len - 1);
+    const uint4 v = *reinterpret_cast<const uint4*>(base + (long)gr * ld + c * 8);
+    *reinterpret_cast<uint4*>(lds + rm_off<D>(r, c)) = v;
+  }
+}
+template <int D>
+__device__ __forceinline__ void load_t_tile(char* lds, const bf16_t* baseT, int LT, int t0, int tid) {
+#pragma unroll
+  for (int i = tid; i < D * 8; i += 256) {
+    const int d = i >> 3, c = i & 7;
+    const uint4 v = *reinterpret_cast<const uint4*>(baseT + (long)d * LT + t0 + c * 8);
+    *reinterpret_cast<uint4*>(lds + t_off16(d, c)) = v;
+  }
+}
+template <int D>
+__device__ __forceinline__ bf16x8 frag_rm(const char* lds, int row, int ks, int fg) {
+  return *reinterpret_cast<const bf16x8*>(lds + rm_off<D>(row, ks * 4 + fg));
+}
+// k-step t of a [.][64]-token tile: k-slot (fg, j<4) <-> token 32t + fg*4 + j ; (fg, j>=4) <-> token 32t + 16 + fg*4 + j-4
+__device__ __forceinline__ bf16x8 frag_t(const char* lds, int d, int t, int fg) {
+  const bf16x4 lo = *reinterpret_cast<const bf16x4*>(lds + t_off8(d, (2 * t) * 4 + fg));
+  const bf16x4 hi = *reinterpret_cast<const bf16x4*>(lds + t_off8(d, (2 * t + 1) * 4 + fg));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
+  bf16x8 r;
+  r[0] = (short)f2bf(a[0]); r[1] = (short)f2bf(a[1]); r[2] = (short)f2bf(a[2]); r[3] = (short)f2bf(a[3]);
+  r[4] = (short)f2bf(b[0]); r[5] = (short)f2bf(b[1]); r[6] = (short)f2bf(b[2]); r[7] = (short)f2bf(b[3]);
+  return r;
+}
+__device__ __forceinline__ float group_max(float v) {  // across the 4 lanes sharing (lane & 15)
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+__device__ __forceinline__ void store4bf(bf16_t* p, const f32x4& v, float s) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v[0] * s, v[1] * s), pack2bf(v[2] * s, v[3] * s));
+}
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
+// ---------------------------------------------------------------- forward
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  constexpr int KS = D / 32, DB = D / 16;
+  __shared__ __attribute__((aligned(16))) char lds_k[64 * D * 2];
+  __shared__ __attribute__((aligned(16))) char lds_vt[D * 128];
+  const int seq = blockIdx.z, h = blockIdx.y;
+  const int* ds = a.desc + seq * 8;
+  const int q_off = ds[0], q_len = ds[1], kv_off = ds[2], kv_len = ds[3], coff = ds[5];
+  const int q0 = blockIdx.x * 64;
+  if (q0 >= q_len) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  const int qrow = q0 + wave * 16 + fr;
+  const bf16_t* qp = a.q + (long)(q_off + min(qrow, q_len - 1)) * a.ldq + h * D;
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32 + fg * 8);
+
+  float m = NEG_INF, l = 0.f;
+  f32x4 o[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int kv_end = kv_len;
+  if (CAUSAL) kv_end = max(0, min(kv_len, q0 + 64 + coff));
+  const int ntiles = (kv_end + 63) >> 6;
+  const bf16_t* kbase = a.k + (long)kv_off * a.ldk + h * D;
+  const bf16_t* vtbase = a.vT + ((long)(seq * a.H + h) * D) * a.LTkv;
+
+  for (int j = 0; j < ntiles; ++j) {
+    __syncthreads();
+    load_rm_tile<D>(lds_k, kbase, a.ldk, j * 64, kv_len, tid);
+    load_t_tile<D>(lds_vt, vtbase, a.LTkv, j * 64, tid);
+    __syncthreads();
+    f32x4 s[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      s[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s[nb] = MFMA(frag_rm<D>(lds_k, nb * 16 + fr, ks, fg), qf[ks], s[nb]);
+    }
+    float mx = NEG_INF;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j * 64 + nb * 16 + fg * 4 + r;
+        const bool ok = key < kv_len && (!CAUSAL || key <= qrow + coff);
+        s[nb][r] = ok ? s[nb][r] * a.scale : NEG_INF;
+        mx = fmaxf(mx, s[nb][r]);
+      }
+    mx = group_max(mx);
+    const float m_new = fmaxf(m, mx);
+    const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+    const float alpha = __expf(m - m_use);
+    float rs = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[nb][r] = __expf(s[nb][r] - m_use);
+        rs += s[nb][r];
+      }
+    rs = group_sum(rs);
+    l = l * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < DB; ++i) o[i] *= alpha;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const bf16x8 pb = pack_frag(s[2 * t], s[2 * t + 1]);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) o[db] = MFMA(frag_t(lds_vt, db * 16 + fr, t, fg), pb, o[db]);
+    }
+  }
+  if (qrow < q_len) {
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    bf16_t* op = a.o + (long)(q_off + qrow) * a.ldo + h * D + fg * 4;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) store4bf(op + db * 16, o[db], inv);
+    if (a.lse && fg == 0) a.lse[(long)(seq * a.H + h) * a.LTq + qrow] = (l > 0.f) ? m + __logf(l) : NEG_INF;
+  }
+}
+
+// ---------------------------------------------------------------- backward: dQ
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+  constexpr int KS = D / 32, DB = D / 16;
+  __shared__ __attribute__((aligned(16))) char lds_k[64 * D * 2];
+  __shared__ __attribute__((aligned(16))) char lds_v[64 * D * 2];
+  __shared__ __attribute__((aligned(16))) char lds_kt[D * 128];
+  const int seq = blockIdx.z, h = blockIdx.y;
+  const int* ds = a.desc + seq * 8;
+  const int q_off = ds[0], q_len = ds[1], kv_off = ds[2], kv_len = ds[3], coff = ds[5];
+  const int q0 = blockIdx.x * 64;
+  if (q0 >= q_len) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  const int qrow = q0 + wave * 16 + fr;
+  const int qrow_c = min(qrow, q_len - 1);
+  const bf16_t* qp = a.q + (long)(q_off + qrow_c) * a.ldq + h * D;
+  const bf16_t* dop = a.dout + (long)(q_off + qrow_c) * a.ld_do + h * D;
+  bf16x8 qf[KS], dof[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32 + fg * 8);
+    dof[ks] = *reinterpret_cast<const bf16x8*>(dop + ks * 32 + fg * 8);
+  }
+  const long stat = (long)(seq * a.H + h) * a.LTq + qrow_c;
+  const float lse_q = a.lse[stat], delta_q = a.delta[stat];
+  f32x4 dq[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int kv_end = kv_len;
+  if (CAUSAL) kv_end = max(0, min(kv_len, q0 + 64 + coff));
+  const int ntiles = (kv_end + 63) >> 6;
+  const bf16_t* kbase = a.k + (long)kv_off * a.ldk + h * D;
+  const bf16_t* vbase = a.v + (long)kv_off * a.ldv + h * D;
+  const bf16_t* ktbase = a.kT + ((long)(seq * a.H + h) * D) * a.LTkv;
+
+  for (int j = 0; j < ntiles; ++j) {
+    __syncthreads();
+    load_rm_tile<D>(lds_k, kbase, a.ldk, j * 64, kv_len, tid);
+    load_rm_tile<D>(lds_v, vbase, a.ldv, j * 64, kv_len, tid);
+    load_t_tile<D>(lds_kt, ktbase, a.LTkv, j * 64, tid);
+    __syncthreads();
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      s[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dp[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        s[nb] = MFMA(frag_rm<D>(lds_k, nb * 16 + fr, ks, fg), qf[ks], s[nb]);
+        dp[nb] = MFMA(frag_rm<D>(lds_v, nb * 16 + fr, ks, fg), dof[ks], dp[nb]);
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j * 64 + nb * 16 + fg * 4 + r;
+        const bool ok = key < kv_len && (!CAUSAL || key <= qrow + coff) && qrow < q_len;
+        const float p = ok ? __expf(s[nb][r] * a.scale - lse_q) : 0.f;
+        s[nb][r] = ok ? p * (dp[nb][r] - delta_q) * a.scale : 0.f;  // dS
+      }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const bf16x8 dsb = pack_frag(s[2 * t], s[2 * t + 1]);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) dq[db] = MFMA(frag_t(lds_kt, db * 16 + fr, t, fg), dsb, dq[db]);
+    }
+  }
+  if (qrow < q_len) {
+    bf16_t* p = a.dq + (long)(q_off + qrow) * a.ld_dq + h * D + fg * 4;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) store4bf(p + db * 16, dq[db], 1.f);
+  }
+}
+
+// ---------------------------------------------------------------- backward: dK, dV
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+  constexpr int KS = D / 32, DB = D / 16;
+  __shared__ __attribute__((aligned(16))) char lds_q[64 * D * 2];
+  __shared__ __attribute__((aligned(16))) char lds_do[64 * D * 2];
+  __shared__ __attribute__((aligned(16))) char lds_qt[D * 128];
+  __shared__ __attribute__((aligned(16))) char lds_dot[D * 128];
+  __shared__ __attribute__((aligned(16))) float lds_lse[64];
+  __shared__ __attribute__((aligned(16))) float lds_delta[64];
+  const int seq = blockIdx.z, h = blockIdx.y;
+  const int* ds = a.desc + seq * 8;
+  const int q_off = ds[0], q_len = ds[1], kv_off = ds[2], kv_len = ds[3], kv_rows = ds[4], coff = ds[5];
+  const int k0 = blockIdx.x * 64;
+  if (k0 >= kv_rows) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  const int key = k0 + wave * 16 + fr;
+  const int key_c = min(key, kv_rows - 1);
+  const bf16_t* kp = a.k + (long)(kv_off + key_c) * a.ldk + h * D;
+  const bf16_t* vp = a.v + (long)(kv_off + key_c) * a.ldv + h * D;
+  bf16x8 kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    kf[ks] = *reinterpret_cast<const bf16x8*>(kp + ks * 32 + fg * 8);
+    vf[ks] = *reinterpret_cast<const bf16x8*>(vp + ks * 32 + fg * 8);
+  }
+  f32x4 dk[DB], dv[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i) { dk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int nq_tiles = (q_len + 63) >> 6;
+  int i0 = 0;
+  if (CAUSAL) i0 = max(0, (k0 - coff) >> 6);  // first q tile that can see key k0 (q >= key - coff)
+  const bf16_t* qbase = a.q + (long)q_off * a.ldq + h * D;
+  const bf16_t* dobase = a.dout + (long)q_off * a.ld_do + h * D;
+  const bf16_t* qtbase = a.qT + ((long)(seq * a.H + h) * D) * a.LTq;
+  const bf16_t* dotbase = a.doT + ((long)(seq * a.H + h) * D) * a.LTq;
+  const float* lsebase = a.lse + (long)(seq * a.H + h) * a.LTq;
+  const float* deltabase = a.delta + (long)(seq * a.H + h) * a.LTq;
+
+  for (int i = i0; i < nq_tiles; ++i) {
+    __syncthreads();
+    load_rm_tile<D>(lds_q, qbase, a.ldq, i * 64, q_len, tid);
+    load_rm_tile<D>(lds_do, dobase, a.ld_do, i * 64, q_len, tid);
+    load_t_tile<D>(lds_qt, qtbase, a.LTq, i * 64, tid);
+    load_t_tile<D>(lds_dot, dotbase, a.LTq, i * 64, tid);
+    if (tid < 64) lds_lse[tid] = lsebase[i * 64 + tid];
+    else if (tid < 128) lds_delta[tid - 64] = deltabase[i * 64 + tid - 64];
+    __syncthreads();
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      s[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dp[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        s[qb] = MFMA(frag_rm<D>(lds_q, qb * 16 + fr, ks, fg), kf[ks], s[qb]);
+        dp[qb] = MFMA(frag_rm<D>(lds_do, qb * 16 + fr, ks, fg), vf[ks], dp[qb]);
+      }
+    }
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      const f32x4 lq = *reinterpret_cast<const f32x4*>(&lds_lse[qb * 16 + fg * 4]);
+      const f32x4 dl = *reinterpret_cast<const f32x4*>(&lds_delta[qb * 16 + fg * 4]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = i * 64 + qb * 16 + fg * 4 + r;
+        const bool ok = q < q_len && key < kv_len && (!CAUSAL || key <= q + coff);
+        const float p = ok ? __expf(s[qb][r] * a.scale - lq[r]) : 0.f;
+        dp[qb][r] = ok ? p * (dp[qb][r] - dl[r]) * a.scale : 0.f;  // dS
+        s[qb][r] = p;                                               // P
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const bf16x8 pb = pack_frag(s[2 * t], s[2 * t + 1]);
+      const bf16x8 dsb = pack_frag(dp[2 * t], dp[2 * t + 1]);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        dv[db] = MFMA(frag_t(lds_dot, db * 16 + fr, t, fg), pb, dv[db]);
+        dk[db] = MFMA(frag_t(lds_qt, db * 16 + fr, t, fg), dsb, dk[db]);
+      }
+    }
+  }
+  if (key < kv_rows) {
+    bf16_t* pk = a.dk + (long)(kv_off + key) * a.ld_dk + h * D + fg * 4;
+    bf16_t* pv = a.dv + (long)(kv_off + key) * a.ld_dv + h * D + fg * 4;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) { store4bf(pk + db * 16, dk[db], 1.f); store4bf(pv + db * 16, dv[db], 1.f); }
+  }
+}
+
+// ---------------------------------------------------------------- delta = rowsum(dO * O)
+template <int D>
+__global__ void attn_delta_kernel(const bf16_t* __restrict__ o, long ldo, const bf16_t* __restrict__ dout, long ld_do,
+                                  float* __restrict__ delta, const int* __restrict__ desc, int H, int LTq) {
+  constexpr int TPR = D / 8;  // threads per (token, head)
+  const int seq = blockIdx.z, h = blockIdx.y;
+  const int q_off = desc[seq * 8 + 0], q_len = desc[seq * 8 + 1];
+  const int t = blockIdx.x * (256 / TPR) + threadIdx.x / TPR;
+  const int c = threadIdx.x % TPR;
+  float s = 0.f;
+  if (t < q_len) {
+    const uint4 a = *reinterpret_cast<const uint4*>(o + (long)(q_off + t) * ldo + h * D + c * 8);
+    const uint4 b = *reinterpret_cast<const uint4*>(dout + (long)(q_off + t) * ld_do + h * D + c * 8);
+    s = bflo(a.x) * bflo(b.x) + bfhi(a.x) * bfhi(b.x) + bflo(a.y) * bflo(b.y) + bfhi(a.y) * bfhi(b.y) +
+        bflo(a.z) * bflo(b.z) + bfhi(a.z) * bfhi(b.z) + bflo(a.w) * bflo(b.w) + bfhi(a.w) * bfhi(b.w);
+  }
+#pragma unroll
+  for (int off = TPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (t < q_len && c == 0) delta[(long)(seq * H + h) * LTq + t] = s;
+}
+
+// ---------------------------------------------------------------- per-sequence transpose with zero padding
+// out[seq][c][t] = in[off[seq] + t][c]  (t < len[seq]) else 0,  t in [0, LT)
+__global__ __launch_bounds__(256) void seq_transpose_kernel(const bf16_t* __restrict__ in, long ld_in, bf16_t* __restrict__ out,
+                                                            int cols, int LT, const int* __restrict__ desc, int off_idx,
+                                                            int len_idx) {
+  __shared__ bf16_t tile[64][66];
+  const int seq = blockIdx.z;
+  const int off = desc[seq * 8 + off_idx], len = desc[seq * 8 + len_idx];
+  const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int t = t0 + r, c = c0 + tx;
+    tile[r][tx] = (t < len && c < cols) ? in[(long)(off + t) * ld_in + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int c = c0 + r, t = t0 + tx;
+    if (c < cols && t < LT) out[((long)seq * cols + c) * LT + t] = tile[tx][r];
+  }
+}
+
+int check_common(const AttnArgs& a, int D, int nseq, const char* who) {
+  LHRS_REQUIRE(D == 64 || D == 128, "%s: head_dim %d unsupported (64 or 128)", who, D);
+  LHRS_REQUIRE(nseq > 0 && a.H > 0, "%s: nseq=%d H=%d", who, nseq, a.H);
+  LHRS_REQUIRE(a.LTq % 64 == 0 && a.LTkv % 64 == 0, "%s: padded lengths must be multiples of 64", who);
+  return 0;
+}
+
+}  // namespace
+
+// C ABI ------------------------------------------------------------------------------------------
+extern "C" int lhrs_seq_transpose(const void* in, long ld_in, void* out, int cols, int LT, const int* desc, int nseq,
+                                  int use_kv, void* stream) {
+  LHRS_REQUIRE(LT % 64 == 0 && cols > 0 && nseq > 0, "seq_transpose: LT=%d cols=%d nseq=%d", LT, cols, nseq);
+  hipLaunchKernelGGL(seq_transpose_kernel, dim3(LT / 64, cdiv(cols, 64), nseq), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)in, ld_in, (bf16_t*)out, cols, LT, desc, use_kv ? 2 : 0, use_kv ? (use_kv == 2 ? 4 : 3) : 1);
+  LHRS_CHECK_LAUNCH("seq_transpose");
+  return 0;
+}
+
+extern "C" int lhrs_attn_fwd(const void* q, long ldq, const void* k, long ldk, const void* vT, void* o, long ldo,
+                             float* lse, const int* desc, int nseq, int H, int D, int max_q, int LTq, int LTkv,
+                             int causal, float scale, void* stream) {
+  AttnArgs a; memset(&a, 0, sizeof(a));
+  a.q = (const bf16_t*)q; a.ldq = ldq; a.k = (const bf16_t*)k; a.ldk = ldk; a.vT = (const bf16_t*)vT;
+  a.o = (bf16_t*)o; a.ldo = ldo; a.lse = lse; a.desc = desc; a.H = H; a.LTq = LTq; a.LTkv = LTkv; a.scale = scale;
+  if (check_common(a, D, nseq, "attn_fwd")) return -1;
+  const dim3 grid(cdiv(max_q, 64), H, nseq), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (D == 128) {
+    if (causal) hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, blk, 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, blk, 0, s, a);
+  } else {
+    if (causal) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, blk, 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, blk, 0, s, a);
+  }
+  LHRS_CHECK_LAUNCH("attn_fwd");
+  return 0;
+}
+
+extern "C" int lhrs_attn_delta(const void* o, long ldo, const void* dout, long ld_do, float* delta, const int* desc,
+                               int nseq, int H, int D, int max_q, int LTq, void* stream) {
+  LHRS_REQUIRE(D == 64 || D == 128, "attn_delta: head_dim %d", D);
+  const int rows_per_blk = 256 / (D / 8);
+  const dim3 grid(cdiv(max_q, rows_per_blk), H, nseq);
+  if (D == 128)
+    hipLaunchKernelGGL((attn_delta_kernel<128>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)o, ldo,
+                       (const bf16_t*)dout, ld_do, delta, desc, H, LTq);
+  else
+    hipLaunchKernelGGL((attn_delta_kernel<64>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)o, ldo,
+                       (const bf16_t*)dout, ld_do, delta, desc, H, LTq);
+  LHRS_CHECK_LAUNCH("attn_delta");
+  return 0;
+}
+
+extern "C" int lhrs_attn_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                             const void* dout, long ld_do, const void* qT, const void* kT, const void* doT,
+                             const float* lse, const float* delta, void* dq, long ld_dq, void* dk, long ld_dk,
+                             void* dv, long ld_dv, const int* desc, int nseq, int H, int D, int max_q, int max_kv,
+                             int LTq, int LTkv, int causal, float scale, void* stream) {
+  AttnArgs a; memset(&a, 0, sizeof(a));
+  a.q = (const bf16_t*)q; a.ldq = ldq; a.k = (const bf16_t*)k; a.ldk = ldk; a.v = (const bf16_t*)v; a.ldv = ldv;
+  a.dout = (const bf16_t*)dout; a.ld_do = ld_do; a.qT = (const bf16_t*)qT; a.kT = (const bf16_t*)kT;
+  a.doT = (const bf16_t*)doT; a.lse = (float*)lse; a.delta = delta;
+  a.dq = (bf16_t*)dq; a.ld_dq = ld_dq; a.dk = (bf16_t*)dk; a.ld_dk = ld_dk; a.dv = (bf16_t*)dv; a.ld_dv = ld_dv;
+  a.desc = desc; a.H = H; a.LTq = LTq; a.LTkv = LTkv; a.scale = scale;
+  if (check_common(a, D, nseq, "attn_bwd")) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 gq(cdiv(max_q, 64), H, nseq), gk(cdiv(max_kv, 64), H, nseq), blk(256);
+  if (D == 128) {
+    if (causal) {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<128, true>), gq, blk, 0, s, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, true>), gk, blk, 0, s, a);
+    } else {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<128, false>), gq, blk, 0, s, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, false>), gk, blk, 0, s, a);
+    }
+  } else {
+    if (causal) {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<64, true>), gq, blk, 0, s, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, true>), gk, blk, 0, s, a);
+    } else {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<64, false>), gq, blk, 0, s, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, false>), gk, blk, 0, s, a);
+    }
+  }
+  LHRS_CHECK_LAUNCH("attn_bwd");
+  return 0;
+}

@@ -1,0 +1,293 @@
+"""Thin host wrappers: torch tensors (device memory + streams only) -> raw pointers -> the C ABI.
+
+No arithmetic happens here and nothing falls back to torch: every function enqueues one or two HIP kernels
+of liblhrs_hip.so on the current HIP stream.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_QUICK_GELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3
+MAP_GELU, MAP_GELU_BWD, MAP_ADD, MAP_QUICK_GELU = 0, 1, 2, 3
+
+
+def _L():
+    return _lib.load()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype or not t.is_cuda:
+        raise TypeError(f"{name}: expected cuda {dtype}, got {t.device} {t.dtype}")
+
+
+# --------------------------------------------------------------------------------------------- GEMM
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, bias=None, residual=None,
+            act: int = ACT_NONE, out_f32: bool = False, accumulate: bool = False, alpha: float = 1.0,
+            M: Optional[int] = None, N: Optional[int] = None, K: Optional[int] = None) -> torch.Tensor:
+    """out[M,N] = act(alpha * a[M,K] @ b[N,K]^T + bias) + residual.  a/b/out may be strided row views."""
+    _req(a, torch.bfloat16, "a"); _req(b, torch.bfloat16, "b")
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    M = a.shape[0] if M is None else M
+    N = b.shape[0] if N is None else N
+    K = a.shape[1] if K is None else K
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    assert out.stride(1) == 1 and out.dtype == (torch.float32 if out_f32 else torch.bfloat16)
+    ldr = residual.stride(0) if residual is not None else 0
+    st = _L().lhrs_gemm_bf16_nt(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N, K,
+                                _p(bias), _p(residual), ldr, act, int(out_f32), int(accumulate), float(alpha), _stream())
+    _lib.check(st, "gemm_bf16_nt")
+    return out
+
+
+# --------------------------------------------------------------------------------------------- norms
+def layernorm_fwd(x, gamma, beta, eps=1e-5, save_stats=False, out=None):
+    rows, cols = x.shape
+    y = torch.empty_like(x) if out is None else out
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    st = _L().lhrs_layernorm_fwd(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), y.stride(0),
+                                 _p(mean), _p(rstd), rows, cols, eps, _stream())
+    _lib.check(st, "layernorm_fwd")
+    return (y, mean, rstd) if save_stats else y
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma=None, dbeta=None, accumulate=False, need_dx=True):
+    rows, cols = x.shape
+    dx = torch.empty_like(x) if need_dx else None
+    part = None
+    if dgamma is not None:
+        nblk = _L().lhrs_layernorm_bwd_nblk(rows)
+        part = torch.empty(nblk * 2 * cols, device=x.device, dtype=torch.float32)
+    st = _L().lhrs_layernorm_bwd(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gamma.data_ptr(), mean.data_ptr(),
+                                 rstd.data_ptr(), _p(dx), dx.stride(0) if dx is not None else 0, _p(dgamma), _p(dbeta),
+                                 _p(part), int(accumulate), rows, cols, _stream())
+    _lib.check(st, "layernorm_bwd")
+    return dx
+
+
+def rmsnorm_fwd(x, w, eps=1e-5, save_rstd=False, out=None):
+    rows, cols = x.shape
+    y = torch.empty_like(x) if out is None else out
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if save_rstd else None
+    st = _L().lhrs_rmsnorm_fwd(x.data_ptr(), x.stride(0), w.data_ptr(), y.data_ptr(), y.stride(0), _p(rstd), rows, cols, eps,
+                               _stream())
+    _lib.check(st, "rmsnorm_fwd")
+    return (y, rstd) if save_rstd else y
+
+
+def rmsnorm_bwd(dy, x, w, rstd=None, add=None, eps=1e-5, out=None):
+    rows, cols = x.shape
+    assert dy.is_contiguous() and x.is_contiguous()
+    dx = torch.empty_like(x) if out is None else out
+    st = _L().lhrs_rmsnorm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), _p(rstd), _p(add), dx.data_ptr(), rows, cols, eps,
+                               _stream())
+    _lib.check(st, "rmsnorm_bwd")
+    return dx
+
+
+# --------------------------------------------------------------------------------------------- attention
+def make_desc(entries, device) -> torch.Tensor:
+    """entries: list of (q_off, q_len, kv_off, kv_len[, kv_rows[, causal_off]]) -> int32 [n, 8] on device."""
+    rows = []
+    for e in entries:
+        e = list(e)
+        if len(e) == 4:
+            e.append(e[3])
+        if len(e) == 5:
+            e.append(0)
+        rows.append(e + [0, 0])
+    return torch.tensor(rows, dtype=torch.int32).to(device)
+
+
+def pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+def seq_transpose(x, cols, LT, desc, nseq, which: str):
+    """x: [tokens, ld] view (first `cols` columns used) -> [nseq, cols, LT] zero padded.  which: 'q' | 'kv' | 'kv_rows'."""
+    out = torch.empty((nseq, cols, LT), device=x.device, dtype=torch.bfloat16)
+    use = {"q": 0, "kv": 1, "kv_rows": 2}[which]
+    st = _L().lhrs_seq_transpose(x.data_ptr(), x.stride(0), out.data_ptr(), cols, LT, desc.data_ptr(), nseq, use, _stream())
+    _lib.check(st, "seq_transpose")
+    return out
+
+
+def attn_fwd(q, k, vT, o, lse, desc, nseq, H, D, max_q, LTq, LTkv, causal, scale):
+    st = _L().lhrs_attn_fwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), vT.data_ptr(), o.data_ptr(), o.stride(0),
+                            _p(lse), desc.data_ptr(), nseq, H, D, max_q, LTq, LTkv, int(causal), float(scale), _stream())
+    _lib.check(st, "attn_fwd")
+
+
+def attn_delta(o, dout, delta, desc, nseq, H, D, max_q, LTq):
+    st = _L().lhrs_attn_delta(o.data_ptr(), o.stride(0), dout.data_ptr(), dout.stride(0), delta.data_ptr(), desc.data_ptr(),
+                              nseq, H, D, max_q, LTq, _stream())
+    _lib.check(st, "attn_delta")
+
+
+def attn_bwd(q, k, v, dout, qT, kT, doT, lse, delta, dq, dk, dv, desc, nseq, H, D, max_q, max_kv, LTq, LTkv, causal, scale):
+    st = _L().lhrs_attn_bwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), dout.data_ptr(),
+                            dout.stride(0), qT.data_ptr(), kT.data_ptr(), doT.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                            dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(), dv.stride(0),
+                            desc.data_ptr(), nseq, H, D, max_q, max_kv, LTq, LTkv, int(causal), float(scale), _stream())
+    _lib.check(st, "attn_bwd")
+
+
+# --------------------------------------------------------------------------------------------- element-wise
+def patchify(rgb, P=14, KP=640):
+    B, C, H, W = rgb.shape
+    assert C == 3 and H == W
+    _req(rgb, torch.float32, "rgb")
+    rgb = rgb.contiguous()
+    out = torch.empty((B * (H // P) ** 2, KP), device=rgb.device, dtype=torch.bfloat16)
+    _lib.check(_L().lhrs_patchify(rgb.data_ptr(), out.data_ptr(), B, H, P, KP, _stream()), "patchify")
+    return out
+
+
+def vit_assemble(patch, cls, pos, B, NP, dim):
+    out = torch.empty((B * (NP + 1), dim), device=patch.device, dtype=torch.bfloat16)
+    _lib.check(_L().lhrs_vit_assemble(patch.data_ptr(), cls.data_ptr(), pos.data_ptr(), out.data_ptr(), B, NP, dim, _stream()),
+               "vit_assemble")
+    return out
+
+
+def rope_(x, rows, nheads, D, cos_t, sin_t, pos_mod, pos0=0, inverse=False, pos_ids=None):
+    st = _L().lhrs_rope(x.data_ptr(), x.stride(0), rows, nheads, D, cos_t.data_ptr(), sin_t.data_ptr(), _p(pos_ids), pos_mod,
+                        pos0, int(inverse), _stream())
+    _lib.check(st, "rope")
+
+
+def swiglu_fwd(gate_up, F, out=None):
+    rows = gate_up.shape[0]
+    act = torch.empty((rows, F), device=gate_up.device, dtype=torch.bfloat16) if out is None else out
+    _lib.check(_L().lhrs_swiglu_fwd(gate_up.data_ptr(), act.data_ptr(), rows, F, _stream()), "swiglu_fwd")
+    return act
+
+
+def swiglu_bwd(dact, gate_up, F, out=None):
+    rows = gate_up.shape[0]
+    dgu = torch.empty_like(gate_up) if out is None else out
+    _lib.check(_L().lhrs_swiglu_bwd(dact.data_ptr(), gate_up.data_ptr(), dgu.data_ptr(), rows, F, _stream()), "swiglu_bwd")
+    return dgu
+
+
+def map_(op, a, b=None, out=None):
+    out = torch.empty_like(a) if out is None else out
+    assert a.is_contiguous() and out.is_contiguous()
+    _lib.check(_L().lhrs_map(op, a.data_ptr(), _p(b), out.data_ptr(), a.numel(), _stream()), "map")
+    return out
+
+
+def colsum(x, out, accumulate=False):
+    rows, cols = x.shape
+    ns = _L().lhrs_colsum_nsplit(rows)
+    part = torch.empty(ns * cols, device=x.device, dtype=torch.float32)
+    _lib.check(_L().lhrs_colsum(x.data_ptr(), x.stride(0), out.data_ptr(), part.data_ptr(), rows, cols, int(accumulate),
+                                _stream()), "colsum")
+    return out
+
+
+def cast_f32_to_bf16(x, out=None):
+    out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if out is None else out
+    _lib.check(_L().lhrs_cast_f32_to_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "cast")
+    return out
+
+
+def transpose(x, rows_pad=None, out=None):
+    """x [rows, cols] (strided rows ok) -> [cols, rows_pad] with zero padding."""
+    rows, cols = x.shape
+    rows_pad = rows if rows_pad is None else rows_pad
+    out = torch.empty((cols, rows_pad), device=x.device, dtype=torch.bfloat16) if out is None else out
+    _lib.check(_L().lhrs_transpose(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), rows, cols, rows_pad, _stream()),
+               "transpose")
+    return out
+
+
+# --------------------------------------------------------------------------------------------- token side
+def splice_fwd(ids, labels, mask, image, embed, S):
+    B, T = ids.shape
+    NI, dim = image.shape[1], image.shape[2]
+    _req(ids, torch.int64, "input_ids")
+    dev = ids.device
+    out = torch.empty((B, S, dim), device=dev, dtype=torch.bfloat16)
+    out_labels = torch.empty((B, S), device=dev, dtype=torch.int64)
+    out_mask = torch.empty((B, S), device=dev, dtype=torch.uint8)
+    img_pos = torch.empty(B, device=dev, dtype=torch.int32)
+    m8 = None if mask is None else mask.to(torch.uint8).contiguous()
+    st = _L().lhrs_splice_fwd(ids.contiguous().data_ptr(), _p(None if labels is None else labels.contiguous()), _p(m8),
+                              image.data_ptr(), embed.data_ptr(), out.data_ptr(), out_labels.data_ptr(), out_mask.data_ptr(),
+                              img_pos.data_ptr(), B, T, NI, dim, S, embed.shape[0], _stream())
+    _lib.check(st, "splice_fwd")
+    return out, out_labels, out_mask, img_pos
+
+
+def splice_bwd(d_embeds, img_pos, NI):
+    B, S, dim = d_embeds.shape
+    d_image = torch.empty((B, NI, dim), device=d_embeds.device, dtype=torch.bfloat16)
+    _lib.check(_L().lhrs_splice_bwd(d_embeds.data_ptr(), img_pos.data_ptr(), d_image.data_ptr(), B, NI, dim, S, _stream()),
+               "splice_bwd")
+    return d_image
+
+
+def gather_rows(src, idx, out=None):
+    n, dim = idx.numel(), src.shape[1]
+    out = torch.empty((n, dim), device=src.device, dtype=torch.bfloat16) if out is None else out
+    _lib.check(_L().lhrs_gather_rows(src.data_ptr(), src.stride(0), idx.data_ptr(), out.data_ptr(), out.stride(0), n, dim,
+                                     _stream()), "gather_rows")
+    return out
+
+
+def scatter_rows(src, idx, dst):
+    n, dim = idx.numel(), src.shape[1]
+    _lib.check(_L().lhrs_scatter_rows(src.data_ptr(), src.stride(0), idx.data_ptr(), dst.data_ptr(), dst.stride(0), n, dim,
+                                      _stream()), "scatter_rows")
+    return dst
+
+
+def cross_entropy(logits, target, want_grad=True, inplace=True):
+    n, V = logits.shape
+    row_loss = torch.empty(n, device=logits.device, dtype=torch.float32)
+    loss = torch.empty((), device=logits.device, dtype=torch.float32)
+    dl = None
+    if want_grad:
+        dl = logits if inplace else torch.empty_like(logits)
+    st = _L().lhrs_cross_entropy(logits.data_ptr(), logits.stride(0), target.data_ptr(), row_loss.data_ptr(), loss.data_ptr(),
+                                 _p(dl), dl.stride(0) if dl is not None else 0, n, V, _stream())
+    _lib.check(st, "cross_entropy")
+    return loss, dl
+
+
+# --------------------------------------------------------------------------------------------- optimizer
+def sqnorm(g, out, accumulate=False):
+    nb = _L().lhrs_sqnorm_nblk(g.numel())
+    part = torch.empty(nb, device=g.device, dtype=torch.float32)
+    _lib.check(_L().lhrs_sqnorm(g.data_ptr(), g.numel(), part.data_ptr(), out.data_ptr(), int(accumulate), _stream()), "sqnorm")
+    return out
+
+
+def adan_step(p, g, m, v, n, pre, shadow, step, lr, betas=(0.98, 0.92, 0.99), eps=1e-8, wd=0.0, no_prox=True,
+              gnorm_sq=None, max_norm=0.0, grad_scale=1.0):
+    st = _L().lhrs_adan_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n.data_ptr(), pre.data_ptr(), _p(shadow),
+                             p.numel(), step, lr, betas[0], betas[1], betas[2], eps, wd, int(no_prox), _p(gnorm_sq), max_norm,
+                             grad_scale, _stream())
+    _lib.check(st, "adan_step")
+
+
+def adamw_step(p, g, m, v, shadow, step, lr, betas=(0.9, 0.95), eps=1e-8, wd=0.0, gnorm_sq=None, max_norm=0.0, grad_scale=1.0):
+    st = _L().lhrs_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(shadow), p.numel(), step, lr, betas[0],
+                              betas[1], eps, wd, _p(gnorm_sq), max_norm, grad_scale, _stream())
+    _lib.check(st, "adamw_step")

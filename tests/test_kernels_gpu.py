@@ -1,0 +1,327 @@
+"""Per-kernel numerics on a real MI355X: each HIP kernel of liblhrs_hip.so against a plain fp32 PyTorch
+statement of the same op (tolerances are bf16-level and written next to each check)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from lhrs_bot_amd import kernels as K  # noqa: E402
+
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 1024, 1024), (2184, 4096, 4096), (1000, 12288, 4096),
+                                   (273, 4096, 11008), (64, 64, 64), (33, 132, 128), (1152, 1024, 4096)])
+def test_gemm_plain(M, N, K):
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
+    a = bf(torch.randn(M, K, generator=g)).to(DEV)
+    b = bf(torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    out = K.gemm_nt(a, b)
+    ref = a.float() @ b.float().t()
+    assert rel_err(out, ref) < 4e-3  # bf16 output rounding: 2^-9 relative per element
+
+
+def test_gemm_transpose_detecting():
+    # A = "identity-like", asymmetric B: catches swapped operands / transposed C writes
+    M = N = K = 128
+    a = torch.zeros(M, K)
+    a[torch.arange(M), torch.arange(K)] = 1.0
+    b = torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 - 125.0
+    out = K.gemm_nt(bf(a).to(DEV), bf(b).to(DEV), out_f32=True)
+    assert torch.equal(out.cpu(), bf(b).float().t().contiguous())
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_gemm_epilogue(act):
+    M, N, Kd = 300, 1024, 512
+    g = torch.Generator().manual_seed(act)
+    a = bf(torch.randn(M, Kd, generator=g)).to(DEV)
+    b = bf(torch.randn(N, Kd, generator=g) * 0.05).to(DEV)
+    bias = bf(torch.randn(N, generator=g)).to(DEV)
+    res = bf(torch.randn(M, N, generator=g)).to(DEV)
+    out = K.gemm_nt(a, b, bias=bias, residual=res, act=act, alpha=0.5)
+    z = 0.5 * (a.float() @ b.float().t()) + bias.float()
+    if act == 1:
+        z = z * torch.sigmoid(1.702 * z)
+    elif act == 2:
+        z = F.gelu(z)
+    elif act == 3:
+        z = F.silu(z)
+    ref = z + res.float()
+    assert rel_err(out, ref) < 4e-3
+
+
+def test_gemm_f32_accumulate_and_strided():
+    M, N, Kd = 192, 256, 128
+    g = torch.Generator().manual_seed(5)
+    abig = bf(torch.randn(M, Kd * 2, generator=g)).to(DEV)
+    a = abig[:, Kd:]  # strided view
+    b = bf(torch.randn(N, Kd, generator=g)).to(DEV)
+    c = torch.ones(M, N, device=DEV, dtype=torch.float32)
+    K.gemm_nt(a, b, out=c, out_f32=True, accumulate=True)
+    ref = 1.0 + a.float() @ b.float().t()
+    assert rel_err(c, ref) < 1e-5
+
+
+def test_gemm_rejects_bad_k():
+    a = torch.zeros(8, 48, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        K.gemm_nt(a, a)
+
+
+# ------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("rows,cols", [(7, 1024), (2057, 1024), (100, 512)])
+def test_layernorm_fwd_bwd(rows, cols):
+    g = torch.Generator().manual_seed(rows)
+    x = bf(torch.randn(rows, cols, generator=g) * 2 + 0.5).to(DEV)
+    gamma = bf(torch.randn(cols, generator=g)).to(DEV)
+    beta = bf(torch.randn(cols, generator=g)).to(DEV)
+    dy = bf(torch.randn(rows, cols, generator=g)).to(DEV)
+    y, mean, rstd = K.layernorm_fwd(x, gamma, beta, save_stats=True)
+    xr = x.float().requires_grad_(True)
+    gr = gamma.float().requires_grad_(True)
+    br = beta.float().requires_grad_(True)
+    yr = F.layer_norm(xr, (cols,), gr, br, 1e-5)
+    assert rel_err(y, yr) < 4e-3
+    yr.backward(dy.float())
+    dgamma = torch.empty(cols, device=DEV)
+    dbeta = torch.empty(cols, device=DEV)
+    dx = K.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta)
+    assert rel_err(dx, xr.grad) < 4e-3
+    assert rel_err(dgamma, gr.grad) < 1e-4
+    assert rel_err(dbeta, br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("rows", [5, 2184])
+def test_rmsnorm_fwd_bwd(rows):
+    cols = 4096
+    g = torch.Generator().manual_seed(rows)
+    x = bf(torch.randn(rows, cols, generator=g)).to(DEV)
+    w = bf(1 + 0.1 * torch.randn(cols, generator=g)).to(DEV)
+    dy = bf(torch.randn(rows, cols, generator=g)).to(DEV)
+    add = bf(torch.randn(rows, cols, generator=g)).to(DEV)
+    y, rstd = K.rmsnorm_fwd(x, w, save_rstd=True)
+    xr = x.float().requires_grad_(True)
+    yr = w.float() * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5))
+    assert rel_err(y, yr) < 6e-3
+    yr.backward(dy.float())
+    dx = K.rmsnorm_bwd(dy, x, w, rstd, add=add)
+    assert rel_err(dx, xr.grad + add.float()) < 4e-3
+    dx2 = K.rmsnorm_bwd(dy, x, w, None)
+    assert rel_err(dx2, xr.grad) < 4e-3
+
+
+# ------------------------------------------------------------------------------------------- attention
+def ref_attention(q, k, v, causal, kv_len, scale):
+    # q [Lq, H, D] ... fp32 reference
+    s = torch.einsum("qhd,khd->hqk", q, k) * scale
+    Lq, Lk = q.shape[0], k.shape[0]
+    mask = torch.zeros(Lq, Lk, dtype=torch.bool, device=q.device)
+    mask[:, kv_len:] = True
+    if causal:
+        mask |= torch.triu(torch.ones(Lq, Lk, dtype=torch.bool, device=q.device), 1)
+    s = s.masked_fill(mask, float("-inf"))
+    p = torch.softmax(s, -1)
+    return torch.einsum("hqk,khd->qhd", p, v)
+
+
+def run_attention_case(D, H, seqs, causal, same_qkv_buffer):
+    """seqs: list of (Lq, Lkv, kv_len_valid)."""
+    g = torch.Generator().manual_seed(D + H + len(seqs))
+    tq = sum(s[0] for s in seqs)
+    tk = sum(s[1] for s in seqs)
+    scale = 1.0 / math.sqrt(D)
+    q = bf(torch.randn(tq, H * D, generator=g)).to(DEV)
+    k = bf(torch.randn(tk, H * D, generator=g)).to(DEV)
+    v = bf(torch.randn(tk, H * D, generator=g)).to(DEV)
+    do = bf(torch.randn(tq, H * D, generator=g)).to(DEV)
+    entries, qo, ko = [], 0, 0
+    for (lq, lk, kvl) in seqs:
+        entries.append((qo, lq, ko, kvl, lk, 0))
+        qo += lq
+        ko += lk
+    nseq = len(seqs)
+    desc = K.make_desc(entries, DEV)
+    max_q = max(s[0] for s in seqs)
+    max_kv = max(s[1] for s in seqs)
+    LTq, LTkv = K.pad64(max_q), K.pad64(max_kv)
+    vT = K.seq_transpose(v, H * D, LTkv, desc, nseq, "kv")
+    o = torch.zeros(tq, H * D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(nseq, H, LTq, device=DEV, dtype=torch.float32)
+    K.attn_fwd(q, k, vT, o, lse, desc, nseq, H, D, max_q, LTq, LTkv, causal, scale)
+    # backward
+    qT = K.seq_transpose(q, H * D, LTq, desc, nseq, "q")
+    kT = K.seq_transpose(k, H * D, LTkv, desc, nseq, "kv")
+    doT = K.seq_transpose(do, H * D, LTq, desc, nseq, "q")
+    delta = torch.zeros(nseq, H, LTq, device=DEV, dtype=torch.float32)
+    K.attn_delta(o, do, delta, desc, nseq, H, D, max_q, LTq)
+    dq = torch.full_like(q, float("nan"))
+    dk = torch.full_like(k, float("nan"))
+    dv = torch.full_like(v, float("nan"))
+    K.attn_bwd(q, k, v, do, qT, kT, doT, lse, delta, dq, dk, dv, desc, nseq, H, D, max_q, max_kv, LTq, LTkv, causal, scale)
+    torch.cuda.synchronize()
+    qo = ko = 0
+    for (lq, lk, kvl) in seqs:
+        qr = q[qo:qo + lq].float().view(lq, H, D).requires_grad_(True)
+        kr = k[ko:ko + lk].float().view(lk, H, D).requires_grad_(True)
+        vr = v[ko:ko + lk].float().view(lk, H, D).requires_grad_(True)
+        ref = ref_attention(qr, kr, vr, causal, kvl, scale)
+        got = o[qo:qo + lq].float().view(lq, H, D)
+        assert rel_err(got, ref) < 8e-3, "forward"
+        ref.backward(do[qo:qo + lq].float().view(lq, H, D))
+        assert rel_err(dq[qo:qo + lq].view(lq, H, D), qr.grad) < 1.5e-2, "dq"
+        assert rel_err(dk[ko:ko + lk].view(lk, H, D), kr.grad) < 1.5e-2, "dk"
+        assert rel_err(dv[ko:ko + lk].view(lk, H, D), vr.grad) < 1.5e-2, "dv"
+        # padded keys get exactly zero gradient
+        assert torch.all(dk[ko + kvl:ko + lk] == 0) and torch.all(dv[ko + kvl:ko + lk] == 0)
+        qo += lq
+        ko += lk
+
+
+def test_attention_vit_shape():
+    run_attention_case(64, 16, [(257, 257, 257)] * 2, causal=False, same_qkv_buffer=False)
+
+
+def test_attention_pooler_groups():
+    run_attention_case(64, 16, [(64, 320, 320), (48, 304, 304), (32, 288, 288)] * 2, causal=False, same_qkv_buffer=False)
+
+
+def test_attention_llama_causal():
+    run_attention_case(128, 32, [(273, 273, 273), (273, 273, 250)], causal=True, same_qkv_buffer=False)
+
+
+def test_attention_small_ragged():
+    run_attention_case(128, 2, [(1, 1, 1), (17, 17, 17), (64, 64, 64), (65, 65, 3)], causal=True, same_qkv_buffer=False)
+
+
+# ------------------------------------------------------------------------------------------- element-wise
+def test_rope_roundtrip_and_reference():
+    rows, H, D, S = 546, 64, 128, 273
+    g = torch.Generator().manual_seed(3)
+    x = bf(torch.randn(rows, H * D + 64, generator=g)).to(DEV)  # extra columns must stay untouched
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
+    fr = torch.outer(torch.arange(S).float(), inv)
+    cos_t = fr.cos().to(torch.bfloat16).float().to(DEV)
+    sin_t = fr.sin().to(torch.bfloat16).float().to(DEV)
+    x0 = x.clone()
+    K.rope_(x, rows, H, D, cos_t, sin_t, pos_mod=S)
+    xr = x0[:, :H * D].float().view(rows, H, D)
+    pos = torch.arange(rows, device=DEV) % S
+    c = torch.cat([cos_t, cos_t], -1)[pos][:, None, :]
+    s = torch.cat([sin_t, sin_t], -1)[pos][:, None, :]
+    rot = torch.cat([-xr[..., D // 2:], xr[..., :D // 2]], -1)
+    ref = xr * c + rot * s
+    assert rel_err(x[:, :H * D].view(rows, H, D), ref) < 4e-3
+    assert torch.equal(x[:, H * D:], x0[:, H * D:])
+    K.rope_(x, rows, H, D, cos_t, sin_t, pos_mod=S, inverse=True)
+    # forward then inverse is the identity up to bf16 rounding and cos^2+sin^2 of bf16-rounded tables
+    assert rel_err(x[:, :H * D], x0[:, :H * D]) < 1e-2
+
+
+def test_swiglu_fwd_bwd():
+    rows, Fd = 301, 11008
+    g = torch.Generator().manual_seed(4)
+    gu = bf(torch.randn(rows, 2 * Fd, generator=g)).to(DEV)
+    da = bf(torch.randn(rows, Fd, generator=g)).to(DEV)
+    act = K.swiglu_fwd(gu, Fd)
+    gr = gu.float().requires_grad_(True)
+    ref = F.silu(gr[:, :Fd]) * gr[:, Fd:]
+    assert rel_err(act, ref) < 4e-3
+    ref.backward(da.float())
+    dgu = K.swiglu_bwd(da, gu, Fd)
+    assert rel_err(dgu, gr.grad) < 4e-3
+
+
+def test_map_colsum_transpose_cast():
+    g = torch.Generator().manual_seed(6)
+    a = bf(torch.randn(333, 4096, generator=g)).to(DEV)
+    b = bf(torch.randn(333, 4096, generator=g)).to(DEV)
+    assert rel_err(K.map_(K.MAP_GELU, a), F.gelu(a.float())) < 4e-3
+    assert rel_err(K.map_(K.MAP_ADD, a, b), a.float() + b.float()) < 4e-3
+    xr = b.float().requires_grad_(True)
+    F.gelu(xr).backward(a.float())
+    assert rel_err(K.map_(K.MAP_GELU_BWD, a, b), xr.grad) < 4e-3
+    out = torch.empty(4096, device=DEV)
+    K.colsum(a, out)
+    assert rel_err(out, a.float().sum(0)) < 1e-5
+    t = K.transpose(a[:, :1000], rows_pad=384)
+    assert torch.equal(t[:, :333], a[:, :1000].t()) and torch.all(t[:, 333:] == 0)
+    f = torch.randn(1000, device=DEV)
+    assert torch.equal(K.cast_f32_to_bf16(f), f.to(torch.bfloat16))
+
+
+def test_patchify_assemble():
+    B = 3
+    g = torch.Generator().manual_seed(8)
+    rgb = torch.randn(B, 3, 224, 224, generator=g).to(DEV)
+    w = torch.randn(1024, 3, 14, 14, generator=g).to(DEV) * 0.02
+    patches = K.patchify(rgb)
+    wp = torch.zeros(1024, 640, device=DEV)
+    wp[:, :588] = w.reshape(1024, 588)
+    emb = K.gemm_nt(patches, bf(wp))
+    ref = F.conv2d(bf(rgb).float(), bf(w).float(), stride=14).flatten(2).transpose(1, 2).reshape(B * 256, 1024)
+    assert rel_err(emb, ref) < 4e-3
+    cls = bf(torch.randn(1024, generator=g)).to(DEV)
+    pos = bf(torch.randn(257, 1024, generator=g)).to(DEV)
+    full = K.vit_assemble(emb, cls, pos, B, 256, 1024).view(B, 257, 1024)
+    ref_full = torch.cat([cls.float().expand(B, 1, 1024), emb.float().view(B, 256, 1024)], 1) + pos.float()
+    assert rel_err(full, ref_full) < 4e-3
+
+
+# ------------------------------------------------------------------------------------------- token side
+def test_cross_entropy():
+    n, V = 77, 32000
+    g = torch.Generator().manual_seed(9)
+    logits = bf(torch.randn(n, V, generator=g) * 3).to(DEV)
+    tgt = torch.randint(0, V, (n,), generator=g).to(DEV)
+    lr = logits.float().requires_grad_(True)
+    ref = F.cross_entropy(lr, tgt)
+    ref.backward()
+    loss, dl = K.cross_entropy(logits.clone(), tgt.to(torch.int32), inplace=True)
+    assert abs(loss.item() - ref.item()) < 2e-4 * abs(ref.item())
+    assert rel_err(dl, lr.grad) < 5e-3
+
+
+def test_gather_scatter_rows():
+    src = bf(torch.randn(50, 4096)).to(DEV)
+    idx = torch.tensor([3, 49, 0, 7], dtype=torch.int32, device=DEV)
+    got = K.gather_rows(src, idx)
+    assert torch.equal(got, src[idx.long()])
+    dst = torch.zeros_like(src)
+    K.scatter_rows(got, idx, dst)
+    assert torch.equal(dst[idx.long()], got) and dst.float().abs().sum() == got.float().abs().sum()
+
+
+# ------------------------------------------------------------------------------------------- optimizer
+def test_adan_and_clip_match_restatement():
+    from oracle.optim_oracle import adan_step_ref
+
+    n = 10007
+    g = torch.Generator().manual_seed(11)
+    p = torch.randn(n, generator=g)
+    state = dict(p=p.clone().double(), m=torch.zeros(n).double(), v=torch.zeros(n).double(), n=torch.zeros(n).double(), pre=None)
+    dp = p.clone().to(DEV)
+    dm, dv, dn, dpre = (torch.zeros(n, device=DEV) for _ in range(4))
+    shadow = torch.zeros(n, device=DEV, dtype=torch.bfloat16)
+    gn = torch.zeros((), device=DEV)
+    for step in range(1, 5):
+        grad = torch.randn(n, generator=g) * (10.0 if step == 2 else 0.1)
+        adan_step_ref(state, grad.double(), step, lr=2e-4, wd=0.02, max_norm=0.3)
+        dg = grad.to(DEV)
+        K.sqnorm(dg, gn)
+        K.adan_step(dp, dg, dm, dv, dn, dpre, shadow, step, 2e-4, wd=0.02, gnorm_sq=gn, max_norm=0.3)
+        assert (dp.cpu().double() - state["p"]).abs().max() < 1e-6
+    assert torch.equal(shadow, dp.to(torch.bfloat16))
