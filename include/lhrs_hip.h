@@ -47,8 +47,8 @@ int lhrs_layernorm_fwd(const void* x, long ldx, const void* gamma, const void* b
                        float* rstd, int rows, int cols, float eps, void* stream);
 int lhrs_layernorm_bwd_nblk(int rows); /* host helper: workspace rows */
 int lhrs_layernorm_bwd(const void* dy, long ld_dy, const void* x, long ldx, const void* gamma, const float* mean,
-                       const float* rstd, void* dx, long ld_dx, float* dgamma, float* dbeta, float* partial,
-                       int accumulate, int rows, int cols, void* stream);
+                       const float* rstd, const void* add, void* dx, long ld_dx, float* dgamma, float* dbeta,
+                       float* partial, int accumulate, int rows, int cols, void* stream);
 int lhrs_rmsnorm_fwd(const void* x, long ldx, const void* w, void* y, long ldy, float* rstd, int rows, int cols,
                      float eps, void* stream);
 int lhrs_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* add, void* dx,
@@ -87,6 +87,14 @@ int lhrs_colsum(const void* x, long ld, float* out, float* partial, int rows, in
 int lhrs_cast_f32_to_bf16(const float* in, void* out, long n, void* stream);
 int lhrs_cast_bf16_to_f32(const void* in, float* out, long n, void* stream);
 int lhrs_transpose(const void* in, long ld_in, void* out, long ld_out, int rows, int cols, int rows_pad, void* stream);
+
+/* ---- AttnPooler layout (lhrs/models/common_arch.py:134-173: query expand, split, cat(sub_token, sub_image)) ---- */
+int lhrs_pooler_build(const void* query, const void* img, void* t, void* kv, int B, int nq0, int nq1, int nq2, int ni0,
+                      int ni1, int ni2, int dim, void* stream);
+int lhrs_pooler_query_grad(const void* dt0, const void* dkv, float* dquery, int B, int nq0, int nq1, int nq2, int ni0,
+                           int ni1, int ni2, int dim, int accumulate, void* stream);
+int lhrs_copy_2d(void* dst, long dst_pitch_bytes, const void* src, long src_pitch_bytes, long width_bytes, long height,
+                 void* stream);
 
 /* ---- token side ------------------------------------------------------------------------------------- *
  * splice: TextModal.prepare_inputs_for_multimodal (lhrs/models/text_modal.py:296-526); bit-exact.

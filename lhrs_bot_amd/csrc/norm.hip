@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
 template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                             const bf16_t* __restrict__ gamma, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, bf16_t* __restrict__ dx,
+                                                            const float* __restrict__ rstd, const bf16_t* add, bf16_t* dx,
                                                             float* __restrict__ partial, int rows, long ld_dy, long ldx,
                                                             long ld_dx) {
   constexpr int cols = NCH * 512;
@@ -109,6 +109,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
       for (int c = 0; c < NCH; ++c)
 #pragma unroll
         for (int i = 0; i < 8; ++i) dv[c][i] = rs * (g[c][i] * dv[c][i] - s1 - xv[c][i] * s2);
+      if (add) {
+        float av[NCH][8];
+        load_row<NCH>(add + row * ld_dx, lane, av);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) dv[c][i] += av[c][i];
+      }
       store_row<NCH>(dx + row * ld_dx, lane, dv);
     }
   }
@@ -240,9 +248,11 @@ extern "C" int lhrs_layernorm_bwd_nblk(int rows) {
 }
 
 // partial: fp32 workspace of lhrs_layernorm_bwd_nblk(rows) * 2 * cols floats (may be null when dgamma is null)
+// add (optional, same layout as dx, may alias dx): dx = dx_layernorm + add
 extern "C" int lhrs_layernorm_bwd(const void* dy, long ld_dy, const void* x, long ldx, const void* gamma,
-                                  const float* mean, const float* rstd, void* dx, long ld_dx, float* dgamma,
-                                  float* dbeta, float* partial, int accumulate, int rows, int cols, void* stream) {
+                                  const float* mean, const float* rstd, const void* add, void* dx, long ld_dx,
+                                  float* dgamma, float* dbeta, float* partial, int accumulate, int rows, int cols,
+                                  void* stream) {
   LHRS_REQUIRE(rows > 0 && cols % 512 == 0 && cols <= 1024, "layernorm_bwd: rows=%d cols=%d (cols<=1024)", rows, cols);
   LHRS_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta both or neither");
   LHRS_REQUIRE(dgamma == nullptr || partial != nullptr, "layernorm_bwd: workspace missing");
@@ -252,11 +262,11 @@ extern "C" int lhrs_layernorm_bwd(const void* dy, long ld_dy, const void* x, lon
   switch (cols / 512) {
     case 1:
       hipLaunchKernelGGL((layernorm_bwd_kernel<1>), dim3(nblk), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
-                         (const bf16_t*)gamma, mean, rstd, (bf16_t*)dx, part, rows, ld_dy, ldx, ld_dx);
+                         (const bf16_t*)gamma, mean, rstd, (const bf16_t*)add, (bf16_t*)dx, part, rows, ld_dy, ldx, ld_dx);
       break;
     default:
       hipLaunchKernelGGL((layernorm_bwd_kernel<2>), dim3(nblk), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
-                         (const bf16_t*)gamma, mean, rstd, (bf16_t*)dx, part, rows, ld_dy, ldx, ld_dx);
+                         (const bf16_t*)gamma, mean, rstd, (const bf16_t*)add, (bf16_t*)dx, part, rows, ld_dy, ldx, ld_dx);
       break;
   }
   LHRS_CHECK_LAUNCH("layernorm_bwd");

@@ -1,0 +1,79 @@
+// Layout kernels specific to AttnPooler (/root/reference lhrs/models/common_arch.py:134-173).
+//   build : t[b] = query (all 144 learned queries);  kv[b] = [q_g0 | img_g0 | q_g1 | img_g1 | q_g2 | img_g2]
+//           i.e. cat(sub_token, sub_image) of common_arch.py:160-161 for the three groups, packed per sample so
+//           that all groups run in ONE varlen attention launch and ONE GEMM per projection.
+//   query_grad : d query = sum_b ( d t0[b] + d kv[b, query rows] )   (fp32)
+#include "common.h"
+
+namespace {
+
+struct Groups { int nq[3]; int nimg[3]; };
+
+__global__ __launch_bounds__(256) void pooler_build_kernel(const bf16_t* __restrict__ query, const bf16_t* __restrict__ img,
+                                                           bf16_t* __restrict__ t, bf16_t* __restrict__ kv, Groups g, int NQ,
+                                                           int NIMG, int KV, int dim) {
+  // grid: (NQ + KV, B)
+  const int r = blockIdx.x, b = blockIdx.y;
+  const bf16_t* src;
+  bf16_t* dst;
+  if (r < NQ) { src = query + (long)r * dim; dst = t + ((long)b * NQ + r) * dim; }
+  else {
+    int j = r - NQ, qo = 0, io = 0, grp = 0;
+    while (grp < 2 && j >= g.nq[grp] + g.nimg[grp]) { j -= g.nq[grp] + g.nimg[grp]; qo += g.nq[grp]; io += g.nimg[grp]; ++grp; }
+    src = (j < g.nq[grp]) ? query + (long)(qo + j) * dim : img + ((long)b * NIMG + io + j - g.nq[grp]) * dim;
+    dst = kv + ((long)b * KV + (r - NQ)) * dim;
+  }
+  for (int c = threadIdx.x; c < dim / 8; c += 256) *reinterpret_cast<uint4*>(dst + c * 8) = *reinterpret_cast<const uint4*>(src + c * 8);
+}
+
+__global__ __launch_bounds__(256) void pooler_query_grad_kernel(const bf16_t* __restrict__ dt0, const bf16_t* __restrict__ dkv,
+                                                                float* __restrict__ dquery, Groups g, int B, int NQ, int KV,
+                                                                int dim, int accumulate) {
+  // grid: NQ blocks; thread per column
+  const int r = blockIdx.x;
+  int grp = 0, j = r, kvo = 0;
+  while (grp < 2 && j >= g.nq[grp]) { j -= g.nq[grp]; kvo += g.nq[grp] + g.nimg[grp]; ++grp; }
+  const int kvrow = kvo + j;
+  for (int c = threadIdx.x; c < dim; c += 256) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+      s += bf2f(dt0[((long)b * NQ + r) * dim + c]);
+      if (dkv) s += bf2f(dkv[((long)b * KV + kvrow) * dim + c]);
+    }
+    dquery[(long)r * dim + c] = accumulate ? dquery[(long)r * dim + c] + s : s;
+  }
+}
+
+}  // namespace
+
+extern "C" int lhrs_pooler_build(const void* query, const void* img, void* t, void* kv, int B, int nq0, int nq1, int nq2,
+                                 int ni0, int ni1, int ni2, int dim, void* stream) {
+  LHRS_REQUIRE(B > 0 && dim % 8 == 0, "pooler_build: B=%d dim=%d", B, dim);
+  Groups g{{nq0, nq1, nq2}, {ni0, ni1, ni2}};
+  const int NQ = nq0 + nq1 + nq2, NIMG = ni0 + ni1 + ni2, KV = NQ + NIMG;
+  hipLaunchKernelGGL(pooler_build_kernel, dim3(NQ + KV, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)query,
+                     (const bf16_t*)img, (bf16_t*)t, (bf16_t*)kv, g, NQ, NIMG, KV, dim);
+  LHRS_CHECK_LAUNCH("pooler_build");
+  return 0;
+}
+
+extern "C" int lhrs_pooler_query_grad(const void* dt0, const void* dkv, float* dquery, int B, int nq0, int nq1, int nq2,
+                                      int ni0, int ni1, int ni2, int dim, int accumulate, void* stream) {
+  LHRS_REQUIRE(B > 0 && dim > 0, "pooler_query_grad: B=%d dim=%d", B, dim);
+  Groups g{{nq0, nq1, nq2}, {ni0, ni1, ni2}};
+  const int NQ = nq0 + nq1 + nq2, KV = NQ + ni0 + ni1 + ni2;
+  hipLaunchKernelGGL(pooler_query_grad_kernel, dim3(NQ), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dt0,
+                     (const bf16_t*)dkv, dquery, g, B, NQ, KV, dim, accumulate);
+  LHRS_CHECK_LAUNCH("pooler_query_grad");
+  return 0;
+}
+
+// strided block copy (device to device) on the stream: `height` rows of `width_bytes`
+extern "C" int lhrs_copy_2d(void* dst, long dst_pitch_bytes, const void* src, long src_pitch_bytes, long width_bytes,
+                            long height, void* stream) {
+  LHRS_REQUIRE(width_bytes > 0 && height > 0, "copy_2d: width=%ld height=%ld", width_bytes, height);
+  hipError_t e = hipMemcpy2DAsync(dst, (size_t)dst_pitch_bytes, src, (size_t)src_pitch_bytes, (size_t)width_bytes,
+                                  (size_t)height, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) LHRS_FAIL("copy_2d: %s", hipGetErrorString(e));
+  return 0;
+}

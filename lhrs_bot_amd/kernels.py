@@ -66,15 +66,15 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, save_stats=False, out=None):
     return (y, mean, rstd) if save_stats else y
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma=None, dbeta=None, accumulate=False, need_dx=True):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma=None, dbeta=None, accumulate=False, need_dx=True, add=None, out=None):
     rows, cols = x.shape
-    dx = torch.empty_like(x) if need_dx else None
+    dx = (torch.empty_like(x) if out is None else out) if need_dx else None
     part = None
     if dgamma is not None:
         nblk = _L().lhrs_layernorm_bwd_nblk(rows)
         part = torch.empty(nblk * 2 * cols, device=x.device, dtype=torch.float32)
     st = _L().lhrs_layernorm_bwd(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gamma.data_ptr(), mean.data_ptr(),
-                                 rstd.data_ptr(), _p(dx), dx.stride(0) if dx is not None else 0, _p(dgamma), _p(dbeta),
+                                 rstd.data_ptr(), _p(add), _p(dx), dx.stride(0) if dx is not None else 0, _p(dgamma), _p(dbeta),
                                  _p(part), int(accumulate), rows, cols, _stream())
     _lib.check(st, "layernorm_bwd")
     return dx
@@ -215,6 +215,28 @@ def transpose(x, rows_pad=None, out=None):
     _lib.check(_L().lhrs_transpose(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), rows, cols, rows_pad, _stream()),
                "transpose")
     return out
+
+
+# --------------------------------------------------------------------------------------------- pooler layout
+def pooler_build(query, img, B, nq=(64, 48, 32), ni=(256, 256, 256)):
+    dim = query.shape[1]
+    NQ, KV = sum(nq), sum(nq) + sum(ni)
+    t = torch.empty((B * NQ, dim), device=query.device, dtype=torch.bfloat16)
+    kv = torch.empty((B * KV, dim), device=query.device, dtype=torch.bfloat16)
+    _lib.check(_L().lhrs_pooler_build(query.data_ptr(), img.data_ptr(), t.data_ptr(), kv.data_ptr(), B, *nq, *ni, dim, _stream()),
+               "pooler_build")
+    return t, kv
+
+
+def pooler_query_grad(dt0, dkv, dquery, B, nq=(64, 48, 32), ni=(256, 256, 256), accumulate=False):
+    dim = dquery.shape[1]
+    _lib.check(_L().lhrs_pooler_query_grad(dt0.data_ptr(), _p(dkv), dquery.data_ptr(), B, *nq, *ni, dim, int(accumulate),
+                                           _stream()), "pooler_query_grad")
+    return dquery
+
+
+def copy_2d(dst_ptr, dst_pitch, src_ptr, src_pitch, width_bytes, height):
+    _lib.check(_L().lhrs_copy_2d(dst_ptr, dst_pitch, src_ptr, src_pitch, width_bytes, height, _stream()), "copy_2d")
 
 
 # --------------------------------------------------------------------------------------------- token side

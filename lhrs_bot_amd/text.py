@@ -1,0 +1,200 @@
+"""TextModal: image-token splice + LLaMA-2 forward / activation-gradient backward + causal-LM loss on gfx950.
+
+Mirrors /root/reference lhrs/models/text_modal.py: `TextModal.decode` (:258-294), `prepare_inputs_for_multimodal`
+(:296-526), `CustomLlamaForCausalLM` (:30-60) over HF LlamaForCausalLM.  Stage 1 trains the projector only, so the
+backward pass propagates dX through the frozen decoder (no dW): every linear's backward is one NT GEMM against a
+pre-transposed copy of its weight that stays resident in HBM (2 x 13.5 GB of 288 GB).
+
+Activation memory per layer and token: x_in, x_mid, o (3 x 4096), qkv (12288), gate|up (22016) in bf16 = 93 KB;
+32 layers x 2184 tokens (B=8, S=273) = 6.5 GB - no gradient checkpointing (the reference needs it on 80 GB parts).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import kernels as hk
+
+IGNORE_INDEX = -100
+IMAGE_TOKEN_INDEX = -200
+DEFAULT_IMAGE_TOKEN = "<image>"
+DEFAULT_IMAGE_PATCH_TOKEN = "<im_patch>"
+DEFAULT_IM_START_TOKEN = "<im_start>"
+DEFAULT_IM_END_TOKEN = "<im_end>"
+
+
+class SyntheticTokenizer:
+    """Stands in for LlamaTokenizerFast when no tokenizer files exist offline (pad = unk = 0, bos = 1)."""
+    unk_token_id = pad_token_id = 0
+    bos_token_id = 1
+    eos_token_id = 2
+    model_max_length = 2048
+
+    def __len__(self):
+        return 32000
+
+
+class TextModal:
+    def __init__(self, config=None, device="cuda", layers=32, dim=4096, ff=11008, heads=32, vocab=32000, eps=1e-5,
+                 rope_theta=10000.0, max_pos=2048):
+        self.device = torch.device(device)
+        self.nl, self.d, self.ff, self.heads, self.vocab, self.eps = layers, dim, ff, heads, vocab, float(eps)
+        self.hd = dim // heads
+        self.tokenizer = SyntheticTokenizer()
+        self.p: Dict = {}
+        inv = 1.0 / (rope_theta ** (torch.arange(0, self.hd, 2).float() / self.hd))
+        fr = torch.outer(torch.arange(max_pos).float(), inv)
+        # HF casts cos/sin to the activation dtype before use; keep bf16-representable values in an fp32 table
+        self.cos = fr.cos().to(torch.bfloat16).float().to(self.device).contiguous()
+        self.sin = fr.sin().to(torch.bfloat16).float().to(self.device).contiguous()
+        self._ctx = None
+        self.text_encoder = self  # attribute path used by the entry scripts (.text.text_encoder)
+
+    def get_text_encoder(self):
+        return self
+
+    # ------------------------------------------------------------------ parameters
+    def _finish(self):
+        """Build the transposed copies used by the dX GEMMs (weights are frozen: done once)."""
+        for L in self.p["layers"]:
+            for k in ("qkv_w", "o_w", "gu_w", "down_w"):
+                L[k + "T"] = hk.transpose(L[k])
+        self.p["lm_headT"] = hk.transpose(self.p["lm_head"])
+
+    def load_params(self, p: Dict) -> None:
+        dev, bf = self.device, torch.bfloat16
+        self.p = {"embed": p["embed"].to(dev, bf), "norm_w": p["norm_w"].to(dev, bf), "lm_head": p["lm_head"].to(dev, bf),
+                  "layers": [{k: v.to(dev, bf).contiguous() for k, v in L.items()} for L in p["layers"]]}
+        self.nl = len(self.p["layers"])
+        self._finish()
+
+    def init_random(self, seed: int = 0) -> None:
+        """Random-init LLaMA-2-7B shapes, N(0, 0.02) (HF initializer_range) - no weights exist offline."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        dev, bf, d, ff = self.device, torch.bfloat16, self.d, self.ff
+
+        def rn(*shape, std=0.02, mean=0.0):
+            out = torch.empty(*shape, device=dev, dtype=bf)
+            rows = shape[0]
+            step = max(1, (1 << 26) // max(1, out[0].numel())) if len(shape) > 1 else rows
+            for r0 in range(0, rows, step):  # chunked so the fp32 temporary stays small
+                r1 = min(rows, r0 + step)
+                out[r0:r1] = (torch.randn((r1 - r0,) + tuple(shape[1:]), device=dev, generator=g) * std + mean).to(bf)
+            return out
+
+        self.p = {"embed": rn(self.vocab, d), "norm_w": rn(d, std=0.0, mean=1.0), "lm_head": rn(self.vocab, d), "layers": []}
+        for _ in range(self.nl):
+            self.p["layers"].append({"ln1_w": rn(d, std=0.0, mean=1.0), "qkv_w": rn(3 * d, d), "o_w": rn(d, d),
+                                     "ln2_w": rn(d, std=0.0, mean=1.0), "gu_w": rn(2 * ff, d), "down_w": rn(d, ff)})
+        self._finish()
+
+    # ------------------------------------------------------------------ splice
+    def prepare_inputs_for_multimodal(self, input_ids, attention_mask, labels, image_embedding):
+        """Device-side restatement of text_modal.py:296-526 (one <image> per sample, tune_im_start off)."""
+        ids = input_ids.to(self.device)
+        B, T = ids.shape
+        NI = image_embedding.shape[1]
+        has_img = (ids == IMAGE_TOKEN_INDEX).any(dim=1)
+        n_img = (ids == IMAGE_TOKEN_INDEX).sum(dim=1)
+        if int(n_img.max()) > 1:
+            raise NotImplementedError("more than one <image> token per sample is not supported by the device splice")
+        S = T - 1 + NI if bool(has_img.any()) else T
+        lab = None if labels is None else labels.to(self.device)
+        msk = None if attention_mask is None else attention_mask.to(self.device)
+        return hk.splice_fwd(ids, lab, msk, image_embedding.contiguous(), self.p["embed"], S)
+
+    # ------------------------------------------------------------------ forward
+    def _layer_fwd(self, L, x, B, S, desc, LT, save):
+        d, H, hd, ff = self.d, self.heads, self.hd, self.ff
+        M = x.shape[0]
+        h = hk.rmsnorm_fwd(x, L["ln1_w"], self.eps)
+        qkv = hk.gemm_nt(h, L["qkv_w"])
+        hk.rope_(qkv, M, 2 * H, hd, self.cos, self.sin, pos_mod=S)
+        vT = hk.seq_transpose(qkv[:, 2 * d:], d, LT, desc, B, "kv")
+        o = torch.empty((M, d), device=self.device, dtype=torch.bfloat16)
+        lse = torch.empty((B, H, LT), device=self.device, dtype=torch.float32)
+        hk.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], vT, o, lse, desc, B, H, hd, S, LT, LT, True, 1.0 / math.sqrt(hd))
+        x_mid = hk.gemm_nt(o, L["o_w"], residual=x)
+        h = hk.rmsnorm_fwd(x_mid, L["ln2_w"], self.eps, out=h)
+        gu = hk.gemm_nt(h, L["gu_w"])
+        act = hk.swiglu_fwd(gu, ff)
+        x_out = hk.gemm_nt(act, L["down_w"], residual=x_mid)
+        if save is not None:
+            save.append(dict(x_in=x, qkv=qkv, o=o, lse=lse, x_mid=x_mid, gu=gu))
+        return x_out
+
+    def forward_hidden(self, embeds, mask_u8, save_ctx=True):
+        """embeds [B,S,d] bf16, mask [B,S] uint8 (right padding) -> final-norm hidden [B*S, d]."""
+        B, S, d = embeds.shape
+        kv_len = mask_u8.to(torch.int32).sum(dim=1).tolist() if mask_u8 is not None else [S] * B
+        desc = hk.make_desc([(b * S, S, b * S, int(kv_len[b]), S, 0) for b in range(B)], self.device)
+        LT = hk.pad64(S)
+        saved: Optional[List] = [] if save_ctx else None
+        x = embeds.reshape(B * S, d)
+        for L in self.p["layers"]:
+            x = self._layer_fwd(L, x, B, S, desc, LT, saved)
+        hidden = hk.rmsnorm_fwd(x, self.p["norm_w"], self.eps)
+        if save_ctx:
+            self._ctx = dict(B=B, S=S, desc=desc, LT=LT, layers=saved, x_last=x)
+        return hidden
+
+    def decode(self, input_ids, image_embedding=None, attention_mask=None, labels=None, save_ctx=True):
+        """TextModal.decode: returns the scalar text loss (0-dim fp32 device tensor)."""
+        embeds, new_labels, new_mask, img_pos = self.prepare_inputs_for_multimodal(input_ids, attention_mask, labels, image_embedding)
+        B, S, d = embeds.shape
+        hidden = self.forward_hidden(embeds, new_mask, save_ctx)
+        # shifted targets: position j predicts label j+1 (HF LlamaForCausalLM.forward); ignore_index rows are skipped
+        tgt = torch.full_like(new_labels, IGNORE_INDEX)
+        tgt[:, :-1] = new_labels[:, 1:]
+        rows = torch.nonzero(tgt.reshape(-1) != IGNORE_INDEX).squeeze(1)
+        n = rows.numel()
+        if n == 0:
+            raise ValueError("no valid target token in the micro-batch (loss would be NaN in the reference)")
+        rows32 = rows.to(torch.int32)
+        targets = tgt.reshape(-1)[rows].to(torch.int32)
+        hv = hk.gather_rows(hidden, rows32)
+        logits = hk.gemm_nt(hv, self.p["lm_head"])
+        loss, dlogits = hk.cross_entropy(logits, targets, want_grad=save_ctx, inplace=True)
+        if save_ctx:
+            self._ctx.update(rows=rows32, dlogits=dlogits, img_pos=img_pos, NI=image_embedding.shape[1])
+        return loss
+
+    __call__ = decode
+
+    # ------------------------------------------------------------------ backward (activation gradients only)
+    def backward(self, loss_scale: float = 1.0) -> torch.Tensor:
+        """d loss / d image_embedding  [B, NI, d] bf16."""
+        c = self._ctx
+        assert c is not None, "decode(save_ctx=True) must precede backward"
+        B, S, desc, LT = c["B"], c["S"], c["desc"], c["LT"]
+        d, H, hd, ff, p = self.d, self.heads, self.hd, self.ff, self.p
+        M = B * S
+        dhv = hk.gemm_nt(c["dlogits"], p["lm_headT"], alpha=loss_scale)
+        dhid = torch.zeros((M, d), device=self.device, dtype=torch.bfloat16)
+        hk.scatter_rows(dhv, c["rows"], dhid)
+        dx = hk.rmsnorm_bwd(dhid, c["x_last"], p["norm_w"], None, eps=self.eps)
+        scale = 1.0 / math.sqrt(hd)
+        delta = torch.empty((B, H, LT), device=self.device, dtype=torch.float32)
+        dqkv = torch.empty((M, 3 * d), device=self.device, dtype=torch.bfloat16)
+        for L, s in zip(reversed(p["layers"]), reversed(c["layers"])):
+            gu, qkv = s["gu"], s["qkv"]
+            dact = hk.gemm_nt(dx, L["down_wT"])
+            dgu = hk.swiglu_bwd(dact, gu, ff, out=gu)
+            dh = hk.gemm_nt(dgu, L["gu_wT"])
+            dx_mid = hk.rmsnorm_bwd(dh, s["x_mid"], L["ln2_w"], None, add=dx, eps=self.eps, out=dh)
+            do = hk.gemm_nt(dx_mid, L["o_wT"])
+            hk.attn_delta(s["o"], do, delta, desc, B, H, hd, S, LT)
+            qT = hk.seq_transpose(qkv[:, :d], d, LT, desc, B, "q")
+            kT = hk.seq_transpose(qkv[:, d:2 * d], d, LT, desc, B, "kv")
+            doT = hk.seq_transpose(do, d, LT, desc, B, "q")
+            hk.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], do, qT, kT, doT, s["lse"], delta, dqkv[:, :d], dqkv[:, d:2 * d],
+                        dqkv[:, 2 * d:], desc, B, H, hd, S, S, LT, LT, True, scale)
+            hk.rope_(dqkv, M, 2 * H, hd, self.cos, self.sin, pos_mod=S, inverse=True)
+            dh1 = hk.gemm_nt(dqkv, L["qkv_wT"])
+            dx = hk.rmsnorm_bwd(dh1, s["x_in"], L["ln1_w"], None, add=dx_mid, eps=self.eps, out=dh1)
+            s.clear()
+        d_image = hk.splice_bwd(dx.view(B, S, d), c["img_pos"], c["NI"])
+        self._ctx = None
+        return d_image

@@ -1,0 +1,123 @@
+"""UniBind: the multimodal module the entry scripts drive, re-built on the gfx950 engine.
+
+Mirrors /root/reference lhrs/models/UniBind.py (`UniBind.__init__` :25-57, `prepare_for_training` :119-176,
+`forward` :178-199, `encode_image` :201-212) and lhrs/models/build.py:16-22 (`build_model`).  There is no autograd:
+`forward` records what the hand-written backward needs and `backward()` runs LLaMA dX -> splice slice -> AttnPooler
+(dW + dX), leaving fp32 gradients in `rgb_pooler.grad`.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .pooler import AttnPooler
+from .text import TextModal
+from .vision import VisionModal
+
+
+def _get(cfg, path: str, default):
+    cur = cfg
+    for k in path.split("."):
+        if cur is None:
+            return default
+        cur = cur.get(k) if isinstance(cur, dict) else getattr(cur, k, None)
+    return default if cur is None else cur
+
+
+class UniBind:
+    def __init__(self, activate_modal: Tuple[str, ...] = ("rgb", "text"), config=None, device="cuda",
+                 llama_layers: Optional[int] = None, vit_layers: int = 24):
+        _lib.load()  # fail loudly, before anything else, if the HIP library is missing
+        assert len(activate_modal) > 0, "activate_modal should not be empty"
+        self.modal = tuple(activate_modal)
+        self.stage = _get(config, "stage", 1)
+        self.device = torch.device(device)
+        if "rgb" in self.modal:
+            self.rgb = VisionModal(config, device, layers=vit_layers)
+            self.rgb_pooler = AttnPooler(
+                num_query=_get(config, "rgb_vision.attn_pooler.num_query", 144),
+                num_layers=_get(config, "rgb_vision.attn_pooler.num_layers", 6),
+                num_attention_heads=_get(config, "rgb_vision.attn_pooler.num_attn_heads", 16),
+                encoder_hidden_size=VisionModal.EMBEDDING_DIM[_get(config, "rgb_vision.arch", "vit_large")],
+                hidden_size=VisionModal.EMBEDDING_DIM[_get(config, "rgb_vision.arch", "vit_large")],
+                output_size=_get(config, "text.hidden_size", 4096), device=device)
+        if "text" in self.modal:
+            eps = float(_get(config, "text.rms_norm_eps", 1e-5))  # yaml.safe_load yields the STRING "1e-5" 
+            self.text = TextModal(config, device, layers=llama_layers or _get(config, "text.num_hidden_layers", 32),
+                                  dim=_get(config, "text.hidden_size", 4096), eps=eps)
+        self.training = True
+        self._image_embedding = None
+
+    # ------------------------------------------------------------------ reference surface
+    def prepare_for_training(self, freeze_vision=True, freeze_text=True, tune_rgb_pooler=True, model_path=None,
+                             tune_im_start=False, compute_dtype=torch.bfloat16):
+        if not freeze_vision or not freeze_text or tune_im_start:
+            raise NotImplementedError("stage-1 scope: frozen ViT / LLaMA, projector-only training (BASELINE configs 1-3)")
+        self.rgb_pooler.requires_grad = bool(tune_rgb_pooler)
+        self.train()
+        if model_path is not None:
+            self.custom_load_state_dict(model_path)
+
+    def train(self):
+        self.training = True
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def init_random(self, seed: int = 0):
+        if hasattr(self, "rgb"):
+            self.rgb.init_random(seed)
+            self.rgb_pooler.init_random(seed + 1)
+        if hasattr(self, "text"):
+            self.text.init_random(seed + 2)
+        return self
+
+    def load_params(self, P: Dict):
+        """P = {'vit':..., 'pooler':..., 'llama':...} in the engine layout (oracle/params.py)."""
+        self.rgb.load_params(P["vit"])
+        self.rgb_pooler.load_params(P["pooler"])
+        self.text.load_params(P["llama"])
+        return self
+
+    def encode_image(self, image, pool: bool = False):
+        emb = self.rgb_pooler.forward(self.rgb.encode(image), save_ctx=False)
+        return emb.float().mean(dim=1).to(emb.dtype) if pool else emb
+
+    def forward(self, data: Dict) -> Dict[str, torch.Tensor]:
+        """UniBind.forward: {"text_loss", "total_loss"} as 0-dim device tensors."""
+        grad = self.training and self.rgb_pooler.requires_grad
+        image_embedding = self.rgb_pooler.forward(self.rgb.encode(data["rgb"]), save_ctx=grad)
+        loss = self.text.decode(data["input_ids"], image_embedding=image_embedding, attention_mask=data.get("attention_mask"),
+                                labels=data["labels"], save_ctx=grad)
+        return {"text_loss": loss, "total_loss": loss}
+
+    __call__ = forward
+
+    def backward(self, loss_scale: float = 1.0) -> None:
+        d_image = self.text.backward(loss_scale)
+        self.rgb_pooler.backward(d_image)
+
+    def custom_save_checkpoint(self, file_name: str):
+        import os
+        os.makedirs(file_name, exist_ok=True)
+        ckpt = {"rgb_ckpt": {}, "other_ckpt": {"rgb_pooler": self.rgb_pooler.state_dict()}}
+        torch.save(ckpt, os.path.join(file_name, "FINAL.pt"))
+        return ckpt
+
+    def custom_load_state_dict(self, path: str, strict: bool = False):
+        ckpt = torch.load(path, map_location="cpu")
+        if "other_ckpt" in ckpt and "rgb_pooler" in ckpt["other_ckpt"]:
+            self.rgb_pooler.load_state_dict(ckpt["other_ckpt"]["rgb_pooler"], strict=strict)
+        return None
+
+
+def build_model(config=None, activate_modal=("rgb", "text"), **kw) -> UniBind:
+    """lhrs.models.build_model (lhrs/models/build.py:16-22)."""
+    return UniBind(activate_modal, config, **kw)

@@ -1,0 +1,109 @@
+"""Parity of the HIP hot path against (a) the golden vectors produced by the reference's own modules and (b) the CPU
+oracle on the same seeded parameters.  The engine computes in bf16 (fp32 accumulation / statistics); the reference
+vectors are fp32.  Tolerances (relative L2 unless stated): activations 2e-2, loss 3e-3 relative, gradients 4e-2.
+Token / label / mask indexing is bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from lhrs_bot_amd import kernels as hk  # noqa: E402
+from lhrs_bot_amd.pooler import AttnPooler  # noqa: E402
+from lhrs_bot_amd.text import TextModal  # noqa: E402
+from lhrs_bot_amd.unibind import UniBind  # noqa: E402
+from oracle import lhrs_oracle as O  # noqa: E402
+from oracle import params as OP  # noqa: E402
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def test_pooler_forward_backward_vs_reference_golden():
+    z = np.load(os.path.join(G, "pooler.npz"))
+    g = torch.Generator().manual_seed(int(z["input_seed"]))
+    x = torch.randn(2, 768, 1024, generator=g)
+    dout = torch.randn(2, 144, 4096, generator=g) * 0.01
+    pool = AttnPooler(device=DEV)
+    pool.load_params(OP.make_pooler_params(seed=1))
+    out = pool.forward(x.to(DEV, torch.bfloat16))
+    assert rel(out, torch.from_numpy(z["out"]).float()) < 2e-2
+    pool.backward(dout.to(DEV, torch.bfloat16))
+    torch.cuda.synchronize()
+    norms = dict(zip(z["grad_names"].tolist(), z["grad_norms"].tolist()))
+    bad = []
+    for name, want in norms.items():
+        got = pool.g[name].double().norm().item()
+        if abs(got - want) > 4e-2 * want:
+            bad.append((name, got, want))
+    assert not bad, bad
+    assert rel(pool.g["query"], torch.from_numpy(z["g_query"]).float()) < 4e-2
+    assert rel(pool.g["out_proj.bias"], torch.from_numpy(z["g_out_proj_b"]).float()) < 4e-2
+    assert rel(pool.g["layers.0.attn.in_proj_weight"][::64, ::64], torch.from_numpy(z["g_l0_in_w_slice"]).float()) < 4e-2
+    assert rel(pool.g["layers.5.mlp.c_fc.weight"][::64, ::64], torch.from_numpy(z["g_l5_fc_w_slice"]).float()) < 4e-2
+    assert rel(pool.g["layers.3.ln_1_kv.weight"], torch.from_numpy(z["g_l3_ln1kv_w"]).float()) < 4e-2
+
+
+def test_splice_bit_exact_vs_reference_golden():
+    z = np.load(os.path.join(G, "splice.npz"))
+    NI = int(z["n_img_tokens"])
+    tm = TextModal(device=DEV, layers=0)
+    g = torch.Generator().manual_seed(0)
+    embed = torch.randn(32000, 4096, generator=g).to(DEV, torch.bfloat16)
+    tm.p = {"embed": embed}
+    for name in ("uniform", "ragged_pad", "mixed_noimg", "img_last", "single"):
+        ids = torch.from_numpy(z[name + "_ids"]); labels = torch.from_numpy(z[name + "_labels"])
+        mask = torch.from_numpy(z[name + "_mask"])
+        B = ids.shape[0]
+        img = torch.randn(B, NI, 4096, generator=g).to(DEV, torch.bfloat16)
+        emb, nl, nm, pos = tm.prepare_inputs_for_multimodal(ids, mask, labels, img)
+        assert torch.equal(nl.cpu(), torch.from_numpy(z[name + "_new_labels"])), name
+        assert torch.equal(nm.cpu().bool(), torch.from_numpy(z[name + "_new_mask"])), name
+        src = torch.from_numpy(z[name + "_src"])
+        src_o, _, _ = O.splice(ids, labels, mask, NI)
+        want = torch.zeros_like(emb.cpu())
+        for b in range(B):
+            for j in range(src_o.shape[1]):
+                s = int(src_o[b, j])
+                if s >= 0:
+                    want[b, j] = embed[int(ids[b, s])].cpu()
+                elif s > -10 ** 8:
+                    want[b, j] = img[b, -s - 1].cpu()
+        assert torch.equal(emb.cpu(), want), name  # pure copies: bit-exact
+        amb = src == -5
+        assert torch.equal(src_o[~amb], src[~amb]), name
+
+
+@pytest.mark.timeout(1200)
+def test_unibind_end_to_end_vs_reference_golden_and_oracle():
+    z = np.load(os.path.join(G, "unibind_e2e.npz"))
+    nl = int(z["n_llama_layers"])
+    P = {"vit": OP.make_vit_params(seed=2), "pooler": OP.make_pooler_params(seed=1), "llama": OP.make_llama_params(seed=3, layers=nl)}
+    model = UniBind(("rgb", "text"), None, device=DEV, llama_layers=nl).load_params(P)
+    model.prepare_for_training()
+    batch = dict(rgb=torch.from_numpy(z["rgb"]).float(), input_ids=torch.from_numpy(z["input_ids"]),
+                 labels=torch.from_numpy(z["labels"]), attention_mask=torch.from_numpy(z["attention_mask"]))
+    taps = model.rgb.encode(batch["rgb"])
+    assert rel(taps[:1, ::2], torch.from_numpy(z["vit_taps"]).float()) < 2e-2
+    image = model.rgb_pooler.forward(taps, save_ctx=False)
+    assert rel(image[:, ::2], torch.from_numpy(z["image"]).float()) < 2e-2
+    out = model(batch)
+    loss = out["total_loss"].item()
+    assert abs(loss - float(z["loss"])) < 3e-3 * float(z["loss"]), (loss, float(z["loss"]))
+    d_image = model.text.backward()
+    assert rel(d_image[:, ::4], torch.from_numpy(z["d_image"])) < 4e-2
+    model.rgb_pooler.backward(d_image)
+    torch.cuda.synchronize()
+    norms = dict(zip(z["grad_names"].tolist(), z["grad_norms"].tolist()))
+    bad = [(n, model.rgb_pooler.g[n].double().norm().item(), w) for n, w in norms.items()
+           if abs(model.rgb_pooler.g[n].double().norm().item() - w) > 5e-2 * w]
+    assert not bad, bad
+    assert rel(model.rgb_pooler.g["out_proj.bias"], torch.from_numpy(z["g_out_proj_b"])) < 4e-2
+    assert rel(model.rgb_pooler.g["query"][::4], torch.from_numpy(z["g_query"])) < 5e-2
