@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""Stage-1 pretrain throughput of the gfx950 engine (BASELINE.json metric).
+
+One "step" = one full stage-1 optimizer step over one micro-batch of synthetic samples per GPU:
+  CLIP ViT-L/14 forward (22 useful layers) -> AttnPooler forward -> splice -> LLaMA2-7B (32 layers) forward -> loss
+  -> LLaMA activation-gradient backward -> AttnPooler backward (dW + dX) -> [RCCL gradient all-reduce] -> Adan step.
+Workload = BASELINE.json configs[1]: 224x224 images, input_ids = [BOS, <image>, 128 caption tokens] => S = 273,
+random-init LLaMA-2-7B / ViT-L/14 shapes (no weights exist offline), bf16 compute, inputs resident in HBM.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` (dominant kernel = the bf16 MFMA
+GEMM, timed live with HIP events on its launch stream inside the timed region) and, at N=1, `cpu_baseline` (the CPU
+oracle timed on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md: ~2.5 PF dense, 2495 TF measured)
+
+
+def f_alg(S: int) -> float:
+    """Algorithmic FLOPs per sample (SURVEY.md §8d / BASELINE.md §2), projector-only, no recompute."""
+    return 278.8e9 + 2 * S * 13.214e9 + 1572864.0 * S * S
+
+
+def make_batch(B, T, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(3, 32000, (B, T), generator=g)
+    ids[:, 0] = 1
+    ids[:, 1] = -200
+    labels = ids.clone()
+    labels[:, :2] = -100
+    rgb = torch.randn(B, 3, 224, 224, generator=g)
+    return dict(rgb=rgb.to(device), input_ids=ids.to(device), labels=labels.to(device), attention_mask=ids.ne(0).to(device))
+
+
+def cpu_baseline(S: int, budget_s: float = 25.0):
+    """Oracle (CPU restatement of the reference, fp32 torch) on a bounded sample: one sample through ViT + pooler
+    (fwd+bwd) + ONE LLaMA-7B-width decoder layer (fwd + activation-gradient bwd) + final norm/lm_head/CE, then
+    extrapolated to 32 layers.  Reported, not optimised-for."""
+    from oracle import lhrs_oracle as O
+    from oracle import params as OP
+
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    P = {"vit": OP.make_vit_params(seed=2), "pooler": OP.make_pooler_params(seed=1), "llama": OP.make_llama_params(seed=3, layers=1)}
+    for L in [P["pooler"]] + P["pooler"]["layers"]:
+        for v in L.values():
+            if torch.is_tensor(v):
+                v.requires_grad_(True)
+    g = torch.Generator().manual_seed(0)
+    rgb = torch.randn(1, 3, 224, 224, generator=g)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        taps = O.vit_forward(P["vit"], rgb)
+    t_vit = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    img = O.pooler_forward(P["pooler"], taps)
+    img.backward(torch.randn(img.shape, generator=g) * 0.01)
+    t_pool = time.perf_counter() - t0
+    x = torch.randn(1, S, 4096, generator=g).requires_grad_(True)
+    labels = torch.randint(3, 32000, (1, S), generator=g)
+    labels[:, :146] = -100
+    t0 = time.perf_counter()
+    h = O.llama_hidden(P["llama"], x, None)
+    loss = O.causal_lm_loss(P["llama"], h, labels)
+    loss.backward()
+    t_l1 = time.perf_counter() - t0
+    # the same without the decoder layer = norm + lm_head + CE
+    x2 = torch.randn(1, S, 4096, generator=g).requires_grad_(True)
+    t0 = time.perf_counter()
+    h2 = O._rms(x2, P["llama"]["norm_w"], 1e-5)
+    O.causal_lm_loss(P["llama"], h2, labels).backward()
+    t_head = time.perf_counter() - t0
+    t_layer = max(t_l1 - t_head, 1e-6)
+    t_full = t_vit + t_pool + t_head + 32 * t_layer
+    return {"value": 1.0 / t_full, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": (f"1 sample, S={S}: ViT-L/14 fwd {t_vit:.2f}s + AttnPooler fwd+bwd {t_pool:.2f}s + lm_head/CE fwd+bwd {t_head:.2f}s "
+                       f"+ 1 of 32 LLaMA-7B layers fwd+dX-bwd {t_layer:.2f}s, extrapolated x32 (oracle/lhrs_oracle.py, fp32 torch CPU)")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--micro-batch", type=int, default=8, help="samples per GPU per step (reference: --batch-size 8, Script/train_stage1.sh:11)")
+    ap.add_argument("--caption-tokens", type=int, default=128)
+    ap.add_argument("--llama-layers", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comm-dtype", default="float32", choices=["float32", "bfloat16"])
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the LHRS hot path has no CPU fallback (cpu_baseline is only the checker)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    from lhrs_bot_amd import _lib
+    from lhrs_bot_amd.engine import LHRSEngine
+    from lhrs_bot_amd.unibind import UniBind
+
+    lib = _lib.load()
+    B, T = a.micro_batch, a.caption_tokens + 2
+    S = T - 1 + 144
+    model = UniBind(("rgb", "text"), None, device=dev, llama_layers=a.llama_layers).init_random(seed=0)  # same weights on every rank
+    model.prepare_for_training()
+    engine = LHRSEngine(model, optimizer="adanp", lr=2e-4, weight_decay=0.0, max_grad_norm=0.3,
+                        comm_dtype=getattr(torch, a.comm_dtype))
+    batch = make_batch(B, T, dev, seed=322 + rank)  # reference seed convention (main_pretrain_stage1.py:281-287)
+
+    def step():
+        out = engine(batch)
+        engine.backward(out["total_loss"])
+        engine.step()
+        return out["total_loss"]
+
+    for _ in range(a.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    import ctypes
+    _lib.check(lib.lhrs_gemm_profile_enable(6000), "gemm_profile_enable")
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = (ctypes.c_double * 5)()
+    _lib.check(lib.lhrs_gemm_profile_read(ctypes.addressof(prof)), "gemm_profile_read")
+    lib.lhrs_gemm_profile_enable(0)
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        sps = world * B * a.steps / dt
+        n_samp, ms, fl = prof[0], prof[1], prof[2]
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        scale_layers = a.llama_layers / 32.0
+        res = {
+            "metric": "stage-1 pretrain samples/sec (224^2 image + 128-tok caption)", "value": round(sps, 3), "unit": "samples/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: stage-1 projector-only, CLIP ViT-L/14@224 + AttnPooler + LLaMA2-7B "
+                                   f"({a.llama_layers} layers), S={S}, random-init weights",
+                       "micro_batch_per_gpu": B, "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
+                       "optimizer": "adanp", "grad_allreduce": a.comm_dtype if world > 1 else "none"},
+            "loss": round(final_loss, 4),
+            "step_mfma_frac": round(sps / world * f_alg(S) / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 else None,
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<4,4,*> (128x128x64 bf16 MFMA GEMM)", "achieved": round(ach, 1),
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "launches_timed": int(n_samp), "avg_launch_us": round(1e3 * ms / max(n_samp, 1), 2),
+                         "gemm_flops_share_of_step": round(prof[4] / a.steps / (B * f_alg(S)), 3) if scale_layers == 1.0 else None},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(S)
+            except Exception as e:  # the checker must never take the product number down with it
+                res["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

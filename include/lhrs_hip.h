@@ -40,6 +40,10 @@ int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, i
                       const void* bias, const void* residual, int ldr, int act, int out_f32, int accumulate,
                       float alpha, void* stream);
 
+/* live HIP-event timing of the dominant (128x128-tile) GEMM launches for bench.py's roofline leg; see gemm.hip */
+int lhrs_gemm_profile_enable(int max_samples);
+int lhrs_gemm_profile_read(double* out5_host);
+
 /* ---- normalisation ---------------------------------------------------------------------------------- *
  * LayerNorm: lhrs/models/common_arch.py:253-259 (+ HF CLIP pre_layrnorm / layer_norm1/2); eps 1e-5.
  * RMSNorm : HF LlamaRMSNorm inside CustomLlamaForCausalLM (lhrs/models/text_modal.py:30-60).            */

@@ -195,6 +195,51 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 
 }  // namespace
 
+// ---- optional live timing of the GEMM launches (bench.py roofline leg) -----------------------------------
+// When enabled, every launch of the 128x128 kernel is bracketed by HIP events ON THE LAUNCH STREAM until the
+// event pool is used up; lhrs_gemm_profile_read synchronises those events and returns summed time and flops.
+namespace {
+struct GemmProf {
+  bool on = false;
+  int cap = 0, used = 0;
+  hipEvent_t* ev = nullptr;   // 2 * cap
+  double* flops = nullptr;    // cap
+  double total_flops_all = 0; // every GEMM launch while enabled (sampled or not)
+  long launches_all = 0;
+} g_prof;
+}  // namespace
+
+extern "C" int lhrs_gemm_profile_enable(int max_samples) {
+  if (g_prof.ev) {
+    for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+    delete[] g_prof.ev; delete[] g_prof.flops;
+    g_prof.ev = nullptr; g_prof.flops = nullptr;
+  }
+  g_prof.on = max_samples > 0; g_prof.cap = max_samples > 0 ? max_samples : 0; g_prof.used = 0;
+  g_prof.total_flops_all = 0; g_prof.launches_all = 0;
+  if (g_prof.on) {
+    g_prof.ev = new hipEvent_t[2 * g_prof.cap];
+    g_prof.flops = new double[g_prof.cap];
+    for (int i = 0; i < 2 * g_prof.cap; ++i)
+      if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) LHRS_FAIL("gemm_profile_enable: hipEventCreate failed");
+  }
+  return 0;
+}
+
+// out[0] = sampled launches, out[1] = their summed duration (ms), out[2] = their summed flops,
+// out[3] = all GEMM launches while enabled, out[4] = flops of all of them
+extern "C" int lhrs_gemm_profile_read(double* out) {
+  double ms = 0, fl = 0;
+  for (int i = 0; i < g_prof.used; ++i) {
+    float t = 0;
+    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) LHRS_FAIL("gemm_profile_read: event sync failed");
+    if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) LHRS_FAIL("gemm_profile_read: elapsed failed");
+    ms += t; fl += g_prof.flops[i];
+  }
+  out[0] = g_prof.used; out[1] = ms; out[2] = fl; out[3] = (double)g_prof.launches_all; out[4] = g_prof.total_flops_all;
+  return 0;
+}
+
 // C ABI ------------------------------------------------------------------------------------------
 extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N,
                                  int K, const void* bias, const void* residual, int ldr, int act, int out_f32,
@@ -227,10 +272,21 @@ extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
       default: hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, 3>), grid, blk, 0, s, g); break;             \
     }                                                                                                  \
   } while (0)
-  if (t128 >= 384) LAUNCH_TILE(4, 4);
+  const bool big = t128 >= 384;
+  int slot = -1;
+  if (g_prof.on) {
+    g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * K;
+    if (big && g_prof.used < g_prof.cap) {
+      slot = g_prof.used++;
+      g_prof.flops[slot] = 2.0 * M * N * K;
+      (void)hipEventRecord(g_prof.ev[2 * slot], s);
+    }
+  }
+  if (big) LAUNCH_TILE(4, 4);
   else if (t64x128 >= 256) LAUNCH_TILE(2, 4);
   else LAUNCH_TILE(2, 2);
 #undef LAUNCH_TILE
+  if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], s);
   LHRS_CHECK_LAUNCH("gemm_bf16_nt");
   return 0;
 }

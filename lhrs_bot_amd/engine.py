@@ -1,0 +1,207 @@
+"""Training engine: the small surface the entry scripts use from the DeepSpeed engine, on HIP streams + RCCL.
+
+Replaces, for the stage-1 hot path, what /root/reference reaches through `deepspeed.initialize(...)`
+(main_pretrain_stage1.py:215-220) and `DeepSpeedHook.after_iter` (lhrs/CustomTrainer/hook/deepspeed_hook.py:4-19):
+    loss_dict = engine(batch); engine.backward(loss); engine.step()
+plus `optimizer.param_groups` / `optimizer._global_grad_norm` used by the LR hook and the logger.
+
+Data parallelism: every rank holds the frozen ViT + LLaMA and the 80 M trainable projector
+parameters.  The projector's fp32 gradients live in ONE flat buffer ordered [query | layer0..5 | out_proj];
+backward finishes them in the order out_proj, layer5..0, query, and each finished range is all-reduced (RCCL over
+xGMI, via torch.distributed backend "nccl") from a dedicated HIP stream while the remaining pooler backward runs.
+ZeRO sharding is dropped on purpose: 80 M fp32 x 6 states = 1.9 GB per GPU of 288 GB.
+Averaging is folded into the optimizer kernel (grad_scale = 1/world); the global-norm clip (DeepSpeed
+`gradient_clipping`, main_pretrain_stage1.py:28-85) uses a device-resident squared norm: no host sync per step.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import kernels as hk
+
+
+def cosine_warmup_lr(it: int, base_lr: float, max_iters: int, min_lr: float = 0.0, warmup_iters: int = 0,
+                     warmup_ratio: float = 0.1, warmup: Optional[str] = "linear") -> float:
+    """CosineAnnealingLrUpdaterHook(by_epoch=False) + linear warm-up of the reference
+    (lhrs/CustomTrainer/hook/lr_scheduler_hook.py:80-145, 243-271, 690-705): pure host math."""
+    regular = min_lr + 0.5 * (base_lr - min_lr) * (math.cos(math.pi * it / max_iters) + 1)
+    if warmup is None or it >= warmup_iters:
+        return regular
+    if warmup == "constant":
+        return regular * warmup_ratio
+    if warmup == "linear":
+        k = (1 - it / warmup_iters) * (1 - warmup_ratio)
+        return regular * (1 - k)
+    if warmup == "exp":
+        return regular * warmup_ratio ** (1 - it / warmup_iters)
+    raise ValueError(warmup)
+
+
+class _Optimizer:
+    """`optimizer.param_groups[*]["lr"]` / `_global_grad_norm` surface of the reference's optimizer object."""
+
+    def __init__(self, lr, wd, decay_numel, nodecay_numel):
+        # build_optimizer.py:18-38 - decay group and no-decay group (1-D tensors and biases)
+        self.param_groups: List[Dict] = [dict(lr=lr, initial_lr=lr, weight_decay=wd, numel=decay_numel),
+                                         dict(lr=lr, initial_lr=lr, weight_decay=0.0, numel=nodecay_numel)]
+        self._global_grad_norm = None
+
+
+def bucket_ranges(pool):
+    """Flat [key, start, end) ranges in the order AttnPooler.backward completes them: out_proj, layers nl-1..0, query."""
+    first = {}
+    for name, _ in pool.spec:
+        key = name.split(".")[1] if name.startswith("layers.") else name.split(".")[0]
+        first.setdefault(key, pool.offsets[name][0])
+    keys = list(first.keys())  # query, 0..nl-1, out_proj (spec order)
+    ends = {k: (first[keys[i + 1]] if i + 1 < len(keys) else pool.numel) for i, k in enumerate(keys)}
+    order = ["out_proj"] + [str(l) for l in reversed(range(pool.nl))] + ["query"]
+    return [(k, first[k], ends[k]) for k in order]
+
+
+class GradReducer:
+    """Bucketed sum all-reduce of ranges of ONE flat gradient buffer, launched as ranges become final.
+
+    Device-agnostic on purpose: on MI355X the collectives are RCCL over xGMI (torch.distributed backend "nccl")
+    issued from a dedicated HIP stream that waits on an event recorded by the compute stream; on CPU tensors
+    (gloo, used by the world_size-2 tests) the same code runs without streams."""
+
+    def __init__(self, flat_grad: torch.Tensor, buckets, process_group=None, comm_dtype=torch.float32):
+        self.flat, self.pg, self.comm_dtype = flat_grad, process_group, comm_dtype
+        self.buckets = {k: (s, e) for k, s, e in buckets}
+        self.cuda = flat_grad.is_cuda
+        self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
+        self.pending = []
+
+    def ready(self, key: str) -> None:
+        s, e = self.buckets[key]
+        buf = self.flat[s:e]
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                self._issue(buf)
+        else:
+            self._issue(buf)
+
+    def _issue(self, buf):
+        if self.comm_dtype == buf.dtype:
+            self.pending.append((torch.distributed.all_reduce(buf, group=self.pg, async_op=True), None, buf))
+        else:
+            low = buf.to(self.comm_dtype)
+            self.pending.append((torch.distributed.all_reduce(low, group=self.pg, async_op=True), low, buf))
+
+    def finish(self) -> None:
+        """Make the compute stream (or the host, on CPU) wait for every outstanding bucket."""
+        for w, low, buf in self.pending:
+            w.wait()
+            if low is not None:
+                if self.cuda:
+                    with torch.cuda.stream(self.comm_stream):
+                        buf.copy_(low)
+                else:
+                    buf.copy_(low)
+        self.pending.clear()
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+
+class LHRSEngine:
+    def __init__(self, model, optimizer: str = "adanp", lr: float = 2e-4, weight_decay: float = 0.0,
+                 max_grad_norm: float = 0.3, betas=None, eps: float = 1e-8, process_group=None, comm_dtype=torch.float32):
+        self.module = self.model = model
+        self.pool = model.rgb_pooler
+        self.opt_name = optimizer.lower()
+        if self.opt_name not in ("adanp", "adan", "adamw"):
+            raise ValueError(f"optimizer {optimizer!r}: the reference builds adanp (stage 1) or adamw (stage 2/3)")
+        self.betas = betas or ((0.98, 0.92, 0.99) if self.opt_name.startswith("adan") else (0.9, 0.95))
+        self.eps, self.max_grad_norm = eps, float(max_grad_norm or 0.0)
+        dev, n = self.pool.device, self.pool.numel
+        self.exp_avg = torch.zeros(n, device=dev)
+        self.exp_avg_sq = torch.zeros(n, device=dev)
+        if self.opt_name.startswith("adan"):
+            self.exp_avg_diff = torch.zeros(n, device=dev)
+            self.pre_grad = torch.zeros(n, device=dev)
+        self.gnorm_sq = torch.zeros((), device=dev)
+        self.global_steps = 0
+        # no-decay = 1-D params and biases (build_optimizer.py:41-73); wd is applied per element range
+        nodecay = sum(v.numel() for nme, v in self.pool.named_parameters() if v.dim() == 1 or nme.endswith(".bias"))
+        self.optimizer = _Optimizer(lr, weight_decay, self.pool.num_parameters() - nodecay, nodecay)
+        self._ranges = self._build_wd_ranges()
+        # ---- data parallel
+        self.pg = process_group
+        self.world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size(self.pg)
+        self.buckets = bucket_ranges(self.pool)
+        self.reducer = GradReducer(self.pool.grad, self.buckets, self.pg, comm_dtype) if self.world > 1 else None
+
+    # ------------------------------------------------------------------ layout helpers
+    def _build_wd_ranges(self):
+        """Contiguous [start, end, decays] element ranges of the flat buffer, in order."""
+        out = []
+        for name, shape in self.pool.spec:
+            off, _ = self.pool.offsets[name]
+            n = 1
+            for s in shape:
+                n *= s
+            padded = (n + 63) // 64 * 64
+            dec = not (len(shape) == 1 or name.endswith(".bias"))
+            if out and out[-1][2] == dec and out[-1][1] == off:
+                out[-1][1] = off + padded
+            else:
+                out.append([off, off + padded, dec])
+        return out
+
+    # ------------------------------------------------------------------ engine surface
+    def __call__(self, batch):
+        return self.model(batch)
+
+    def train(self):
+        self.model.train()
+        return self
+
+    def backward(self, loss=None):
+        """Hand-written backward; gradient ranges are all-reduced on the comm stream as they become final."""
+        d_image = self.model.text.backward()
+        self.pool.backward(d_image, on_ready=self.reducer.ready if self.reducer else None)
+
+    def step(self, lr_kwargs: Optional[Dict] = None):
+        pool, dev = self.pool, self.pool.device
+        if self.reducer:
+            self.reducer.finish()
+        self.global_steps += 1
+        step = self.global_steps
+        gscale = 1.0 / self.world
+        if self.max_grad_norm > 0:
+            hk.sqnorm(pool.grad, self.gnorm_sq)
+        gn = self.gnorm_sq if self.max_grad_norm > 0 else None
+        g_dec, g_nodec = self.optimizer.param_groups
+        ranges = self._ranges
+        if g_dec["lr"] == g_nodec["lr"] and g_dec["weight_decay"] == g_nodec["weight_decay"]:
+            ranges = [[0, pool.numel, True]]  # one launch over the whole flat buffer (stage-1 YAML: wd = 0)
+        for start, end, dec in ranges:
+            grp = g_dec if dec else g_nodec
+            sl = slice(start, end)
+            if self.opt_name.startswith("adan"):
+                hk.adan_step(pool.master[sl], pool.grad[sl], self.exp_avg[sl], self.exp_avg_diff[sl], self.exp_avg_sq[sl],
+                             self.pre_grad[sl], pool.shadow[sl], step, grp["lr"], self.betas, self.eps, grp["weight_decay"],
+                             no_prox=self.opt_name == "adanp", gnorm_sq=gn, max_norm=self.max_grad_norm, grad_scale=gscale)
+            else:
+                hk.adamw_step(pool.master[sl], pool.grad[sl], self.exp_avg[sl], self.exp_avg_sq[sl], pool.shadow[sl], step,
+                              grp["lr"], self.betas, self.eps, grp["weight_decay"], gnorm_sq=gn, max_norm=self.max_grad_norm,
+                              grad_scale=gscale)
+        pool.refresh_transposed()
+        self.optimizer._global_grad_norm = self.gnorm_sq  # device scalar (squared, un-averaged); see grad_norm()
+
+    def grad_norm(self) -> float:
+        """Host read of the global gradient norm of the last step (synchronises; for logging only)."""
+        return float(self.gnorm_sq.sqrt().item()) / self.world
+
+    def set_lr(self, lr: float):
+        for g in self.optimizer.param_groups:
+            g["lr"] = lr

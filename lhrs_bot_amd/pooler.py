@@ -193,8 +193,10 @@ class AttnPooler:
         g = self.g[name] if rows is None else self.g[name][rows[0]: rows[1]]
         hk.gemm_nt(dyT, xT, out=g, out_f32=True)
 
-    def backward(self, d_out: torch.Tensor) -> None:
-        """d_out [B,144,4096] bf16 -> fills self.grad (fp32).  The ViT is frozen: no image gradient is produced."""
+    def backward(self, d_out: torch.Tensor, on_ready=None) -> None:
+        """d_out [B,144,4096] bf16 -> fills self.grad (fp32).  The ViT is frozen: no image gradient is produced.
+        on_ready(key) is called as soon as a gradient range is final ('out_proj', '5'..'0', 'query'): the engine
+        launches that range's all-reduce on its comm stream while the rest of the backward runs."""
         c = self._ctx
         assert c is not None, "forward(save_ctx=True) must precede backward"
         B, d, H, g, w, wT = c["B"], self.d, self.heads, self.g, self.w, self.wT
@@ -204,6 +206,8 @@ class AttnPooler:
         hk.colsum(d_out, g["out_proj.bias"])
         self._dw("out_proj.weight", d_out, c["t_final"])
         dt = hk.gemm_nt(d_out, wT["out_proj.weight"])
+        if on_ready:
+            on_ready("out_proj")
         dkv_total = None
         for l in reversed(range(self.nl)):
             b = f"layers.{l}."
@@ -241,5 +245,9 @@ class AttnPooler:
             dkvn = hk.gemm_nt(dkvp, wT[b + "kv"])
             dkv_total = hk.layernorm_bwd(dkvn, c["kv"], w[b + "ln_1_kv.weight"], *s["kv_stats"], g[b + "ln_1_kv.weight"],
                                          g[b + "ln_1_kv.bias"], add=dkv_total)
+            if on_ready:
+                on_ready(str(l))
         hk.pooler_query_grad(dt, dkv_total, g["query"], B, STAGE_NUM, SPLIT_PART)
+        if on_ready:
+            on_ready("query")
         self._ctx = None
