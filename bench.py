@@ -51,7 +51,7 @@ def cpu_baseline(S: int, budget_s: float = 25.0):
     from oracle import lhrs_oracle as O
     from oracle import params as OP
 
-    threads = os.cpu_count() or 1
+    threads = min(32, os.cpu_count() or 1)  # 256 OpenMP threads on these shapes are slower than 32 (measured)
     torch.set_num_threads(threads)
     P = {"vit": OP.make_vit_params(seed=2), "pooler": OP.make_pooler_params(seed=1), "llama": OP.make_llama_params(seed=3, layers=1)}
     for L in [P["pooler"]] + P["pooler"]["layers"]:
@@ -94,7 +94,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--micro-batch", type=int, default=8, help="samples per GPU per step (reference: --batch-size 8, Script/train_stage1.sh:11)")
+    ap.add_argument("--micro-batch", type=int, default=32,
+                    help="samples per GPU per step (DESIGN.md §4; the reference script uses 8 on 80 GB parts: Script/train_stage1.sh:11)")
     ap.add_argument("--caption-tokens", type=int, default=128)
     ap.add_argument("--llama-layers", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -59,6 +59,7 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    import torch  # noqa: F401  torch's bundled HIP runtime must be the one in the process before the .so binds to it
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
