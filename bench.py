@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--micro-batch", type=int, default=32,
+    ap.add_argument("--micro-batch", type=int, default=30,
                     help="samples per GPU per step (DESIGN.md §4; the reference script uses 8 on 80 GB parts: Script/train_stage1.sh:11)")
     ap.add_argument("--caption-tokens", type=int, default=128)
     ap.add_argument("--llama-layers", type=int, default=32)
@@ -172,7 +172,7 @@ def main():
                        "optimizer": "adanp", "grad_allreduce": a.comm_dtype if world > 1 else "none"},
             "loss": round(final_loss, 4),
             "step_mfma_frac": round(sps / world * f_alg(S) / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 else None,
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<4,4,*> (128x128x64 bf16 MFMA GEMM)", "achieved": round(ach, 1),
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_256p_kernel (256x256 tile, 4-stage BK=32 LDS ring, v_mfma_f32_32x32x16_bf16)", "achieved": round(ach, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "launches_timed": int(n_samp), "avg_launch_us": round(1e3 * ms / max(n_samp, 1), 2),
                          "gemm_flops_share_of_step": round(prof[4] / a.steps / (B * f_alg(S)), 3) if scale_layers == 1.0 else None},

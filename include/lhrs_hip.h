@@ -41,6 +41,7 @@ int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, i
                       float alpha, void* stream);
 
 /* live HIP-event timing of the dominant (128x128-tile) GEMM launches for bench.py's roofline leg; see gemm.hip */
+int lhrs_gemm_set_policy(int allow_256);
 int lhrs_gemm_profile_enable(int max_samples);
 int lhrs_gemm_profile_read(double* out5_host);
 

@@ -193,6 +193,296 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 256x256 tile, 8 waves (2 x 4), v_mfma_f32_32x32x16_bf16, BK = 32 stages in a 4-deep LDS ring (128 KiB).
+//
+// Why this shape: a 128^2 tile moves 1/64 B of L2->LDS traffic per flop (15 TB/s at 950 TFLOP/s - the measured
+// ceiling of the kernel above); 256^2 halves it, and the 32x32x16 MFMA has the higher issue-rate ceiling.
+// Pipeline: the DMA for stage i+3 is issued right after the barrier that opens stage i, so a stage has three
+// stage-times (~3 x 1000 cycles) to land; each wave waits only for ITS OWN loads of stage i with a COUNTED
+// s_waitcnt vmcnt(8) (never 0 in the steady state), then one s_barrier publishes the stage to all waves.
+//   RAW: a wave reads stage i only after [its vmcnt -> barrier(i)], which every loading wave reaches after its own
+//        vmcnt for stage i.
+//   WAR: buffer (i+3)&3 == (i-1)&3 is refilled only after barrier(i), which every wave reaches after issuing the
+//        MFMAs that consumed its ds_reads of stage i-1.
+// LDS image of a stage: A[256][32], B[256][32] bf16 (64-B rows); 16-B chunk index XOR ((row>>2)&3) makes every
+// ds_read_b128 lane group hit 16 distinct slots of the 256-B bank row (swizzle applied on DMA source + read).
+// ------------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(512, 2) void gemm_nt_256_kernel(GemmArgs g) {
+  constexpr int BM = 256, BN = 256, BK = 32, NS = 4;
+  constexpr int A_BYTES = BM * BK * 2, STAGE = A_BYTES + BN * BK * 2;  // 16 KiB + 16 KiB
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+
+  int tm, tn;
+  tile_coords(g, tm, tn);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- DMA: per stage 32 wave-instructions of 1 KiB (16 rows x 64 B); wave w issues #4w..4w+3 (waves 0-3: A, 4-7: B)
+  const int lrow = lane >> 2;
+  const int lchunk = (lane & 3) ^ ((lane >> 4) & 3);
+  const bf16_t* src[4];
+  int dst_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = wave * 4 + j;
+    if (idx < 16) {
+      const int row = min(tm * BM + idx * 16 + lrow, g.M - 1);
+      src[j] = g.A + (long)row * g.lda + lchunk * 8;
+      dst_off[j] = idx * 1024;
+    } else {
+      const int row = min(tn * BN + (idx - 16) * 16 + lrow, g.N - 1);
+      src[j] = g.B + (long)row * g.ldb + lchunk * 8;
+      dst_off[j] = A_BYTES + (idx - 16) * 1024;
+    }
+  }
+  auto issue = [&](int kt) {
+    char* base = smem + (kt & (NS - 1)) * STAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + (long)kt * BK), (lptr_t)(base + dst_off[j]), 16, 0, 0);
+  };
+
+  // ---- fragments: wave (wm, wn) owns rows [wm*128,+128) x cols [wn*64,+64)
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int sw = (lane >> 2) & 3;
+  const int a_base = (wm * 128 + fr) * 64;            // + mi*32*64
+  const int b_base = A_BYTES + (wn * 64 + fr) * 64;   // + ni*32*64
+  int koff[2];
+  koff[0] = ((0 * 2 + fh) ^ sw) * 16;
+  koff[1] = ((1 * 2 + fh) ^ sw) * 16;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto compute = [&](int kt) {
+    const char* st = smem + (kt & (NS - 1)) * STAGE;
+    // all 12 fragment reads of the stage are issued before the first MFMA (48 VGPRs): the MFMAs then run
+    // back to back behind counted lgkmcnt waits instead of read->wait->4 MFMA->read->wait...
+    bf16x8 af[2][4], bfr[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) bfr[kk][ni] = *reinterpret_cast<const bf16x8*>(st + b_base + ni * 2048 + koff[kk]);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) af[kk][mi] = *reinterpret_cast<const bf16x8*>(st + a_base + mi * 2048 + koff[kk]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[kk][ni], af[kk][mi], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  const int nk = g.K / BK;  // >= 3 (host guarantees)
+  issue(0); issue(1); issue(2);
+  for (int kt = 0; kt < nk - 2; ++kt) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 3 < nk) issue(kt + 3);
+    compute(kt);
+  }
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  compute(nk - 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  compute(nk - 1);
+
+  // ---- epilogue: lane holds C[m = .. + fr][n = .. + 8*q + 4*fh + 0..3], q = 0..3
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = tm * BM + wm * 128 + mi * 32 + fr;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4;
+        if (n >= g.N) continue;
+        store4<ACT>(g, m, n, f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]});
+      }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// 256x256 "pipelined" variant: same tile / ring as gemm_nt_256_kernel, but the ds_read of the NEXT k-step is in
+// flight while the MFMAs of the current k-step issue, so LDS latency never sits in front of the matrix pipe.
+// Fragment reads are inline asm (hipcc would otherwise place an lgkmcnt(0) right before every consumer, i.e.
+// behind the reads just issued); every wait is an explicit lgkmcnt(0) placed BEFORE the next batch of reads, so
+// it only ever covers reads issued one 8-MFMA block (>= 256 cycles) earlier.
+//   per iteration i (stage i+1 is published by the barrier):
+//     vmcnt(4) ; barrier ; DMA(stage i+3) ; wait ; read k0(i+1)->set0 ; 8 MFMA set1=k1(i) ; wait ; read k1(i+1)->set1 ;
+//     8 MFMA set0
+//   WAR on LDS: buffer (i+3)&3 held stage i-1, whose last reads (k1) completed before MFMA k1(i-1) issued, which every
+//   wave did before reaching this iteration's barrier.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_read6(bf16x8 (&a)[4], bf16x8 (&b)[2], unsigned a_addr, unsigned b_addr) {
+  asm volatile(
+      "ds_read_b128 %0, %6\n\t"
+      "ds_read_b128 %1, %6 offset:2048\n\t"
+      "ds_read_b128 %2, %7\n\t"
+      "ds_read_b128 %3, %7 offset:2048\n\t"
+      "ds_read_b128 %4, %7 offset:4096\n\t"
+      "ds_read_b128 %5, %7 offset:6144"
+      : "=&v"(b[0]), "=&v"(b[1]), "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3])
+      : "v"(b_addr), "v"(a_addr));
+}
+__device__ __forceinline__ void lds_wait6(bf16x8 (&a)[4], bf16x8 (&b)[2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+#define LDS_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+
+template <int ACT, bool ILV>
+__global__ __launch_bounds__(512, 2) void gemm_nt_256p_kernel(GemmArgs g) {
+  constexpr int BM = 256, BN = 256, BK = 32, NS = 4;
+  constexpr int A_BYTES = BM * BK * 2, STAGE = A_BYTES + BN * BK * 2;
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+
+  int tm, tn;
+  tile_coords(g, tm, tn);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int lrow = lane >> 2;
+  const int lchunk = (lane & 3) ^ ((lane >> 4) & 3);
+  const bf16_t* src[4];
+  int dst_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = wave * 4 + j;
+    if (idx < 16) {
+      const int row = min(tm * BM + idx * 16 + lrow, g.M - 1);
+      src[j] = g.A + (long)row * g.lda + lchunk * 8;
+      dst_off[j] = idx * 1024;
+    } else {
+      const int row = min(tn * BN + (idx - 16) * 16 + lrow, g.N - 1);
+      src[j] = g.B + (long)row * g.ldb + lchunk * 8;
+      dst_off[j] = A_BYTES + (idx - 16) * 1024;
+    }
+  }
+  auto issue = [&](int kt) {
+    char* base = smem + (kt & (NS - 1)) * STAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + (long)kt * BK), (lptr_t)(base + dst_off[j]), 16, 0, 0);
+  };
+
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int sw = (lane >> 2) & 3;
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+  const unsigned a_base = lds0 + (wm * 128 + fr) * 64;
+  const unsigned b_base = lds0 + A_BYTES + (wn * 64 + fr) * 64;
+  const unsigned koff0 = ((0 * 2 + fh) ^ sw) * 16, koff1 = ((1 * 2 + fh) ^ sw) * 16;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  bf16x8 a0[4], b0[2], a1[4], b1[2];  // set0 = k-step 0 fragments, set1 = k-step 1 fragments
+#define MFMA8(A_, B_)                                                                                   \
+  _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)     \
+      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B_[ni], A_[mi], acc[mi][ni], 0, 0, 0);      \
+  __builtin_amdgcn_sched_barrier(0);
+
+  const int nk = g.K / BK;  // >= 2 (host guarantees)
+  issue(0);
+  issue(1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (2 < nk) issue(2);
+  lds_read6(a0, b0, a_base + koff0, b_base + koff0);
+  lds_read6(a1, b1, a_base + koff1, b_base + koff1);
+  asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(b0[0]), "+v"(b0[1]), "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]));
+  __builtin_amdgcn_sched_barrier(0);
+  MFMA8(a0, b0)
+  auto issue1 = [&](int kt, int j) {
+    __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + (long)kt * BK), (lptr_t)(smem + (kt & (NS - 1)) * STAGE + dst_off[j]), 16, 0, 0);
+  };
+#define MF(A_, B_, mi, ni) \
+  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B_[ni], A_[mi], acc[mi][ni], 0, 0, 0); __builtin_amdgcn_sched_barrier(0);
+  for (int kt = 0; kt < nk - 1; ++kt) {
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned so = ((kt + 1) & (NS - 1)) * STAGE;
+    if (!ILV) {
+      if (kt + 3 < nk) issue(kt + 3);
+      lds_wait6(a1, b1);                                          // k1(kt) landed (issued one MFMA block ago)
+      lds_read6(a0, b0, a_base + so + koff0, b_base + so + koff0);  // k0(kt+1)
+      __builtin_amdgcn_sched_barrier(0);
+      MFMA8(a1, b1)
+      lds_wait6(a0, b0);
+      lds_read6(a1, b1, a_base + so + koff1, b_base + so + koff1);  // k1(kt+1)
+      __builtin_amdgcn_sched_barrier(0);
+      MFMA8(a0, b0)
+    } else {
+      // one filler (ds_read of the next k-step, or one DMA piece of stage kt+3) behind every MFMA
+      const bool dma = kt + 3 < nk;
+      const unsigned aa0 = a_base + so + koff0, ba0 = b_base + so + koff0;
+      const unsigned aa1 = a_base + so + koff1, ba1 = b_base + so + koff1;
+      lds_wait6(a1, b1);
+      MF(a1, b1, 0, 0) LDS_RD(b0[0], ba0, 0);    __builtin_amdgcn_sched_barrier(0);
+      MF(a1, b1, 0, 1) LDS_RD(b0[1], ba0, 2048); __builtin_amdgcn_sched_barrier(0);
+      MF(a1, b1, 1, 0) LDS_RD(a0[0], aa0, 0);    __builtin_amdgcn_sched_barrier(0);
+      MF(a1, b1, 1, 1) LDS_RD(a0[1], aa0, 2048); __builtin_amdgcn_sched_barrier(0);
+      MF(a1, b1, 2, 0) LDS_RD(a0[2], aa0, 4096); __builtin_amdgcn_sched_barrier(0);
+      MF(a1, b1, 2, 1) LDS_RD(a0[3], aa0, 6144); __builtin_amdgcn_sched_barrier(0);
+      MF(a1, b1, 3, 0) if (dma) issue1(kt + 3, 0); __builtin_amdgcn_sched_barrier(0);
+      MF(a1, b1, 3, 1) if (dma) issue1(kt + 3, 1); __builtin_amdgcn_sched_barrier(0);
+      lds_wait6(a0, b0);
+      MF(a0, b0, 0, 0) LDS_RD(b1[0], ba1, 0);    __builtin_amdgcn_sched_barrier(0);
+      MF(a0, b0, 0, 1) LDS_RD(b1[1], ba1, 2048); __builtin_amdgcn_sched_barrier(0);
+      MF(a0, b0, 1, 0) LDS_RD(a1[0], aa1, 0);    __builtin_amdgcn_sched_barrier(0);
+      MF(a0, b0, 1, 1) LDS_RD(a1[1], aa1, 2048); __builtin_amdgcn_sched_barrier(0);
+      MF(a0, b0, 2, 0) LDS_RD(a1[2], aa1, 4096); __builtin_amdgcn_sched_barrier(0);
+      MF(a0, b0, 2, 1) LDS_RD(a1[3], aa1, 6144); __builtin_amdgcn_sched_barrier(0);
+      MF(a0, b0, 3, 0) if (dma) issue1(kt + 3, 2); __builtin_amdgcn_sched_barrier(0);
+      MF(a0, b0, 3, 1) if (dma) issue1(kt + 3, 3); __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#undef MF
+  lds_wait6(a1, b1);
+  MFMA8(a1, b1)
+#undef MFMA8
+
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = tm * BM + wm * 128 + mi * 32 + fr;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4;
+        if (n >= g.N) continue;
+        store4<ACT>(g, m, n, f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]});
+      }
+  }
+}
+
 }  // namespace
 
 // ---- optional live timing of the GEMM launches (bench.py roofline leg) -----------------------------------
@@ -240,12 +530,16 @@ extern "C" int lhrs_gemm_profile_read(double* out) {
   return 0;
 }
 
+static int g_gemm_allow_256 = 3;
+// tile policy switch for A/B measurements: 0 = never use a 256x256 kernel, 1 = simple ring kernel, 2 = pipelined
+extern "C" int lhrs_gemm_set_policy(int allow_256) { g_gemm_allow_256 = allow_256; return 0; }
+
 // C ABI ------------------------------------------------------------------------------------------
 extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N,
                                  int K, const void* bias, const void* residual, int ldr, int act, int out_f32,
                                  int accumulate, float alpha, void* stream) {
   LHRS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
-  LHRS_REQUIRE(K % 64 == 0, "gemm: K=%d must be a multiple of 64 (zero-pad the reduction dim)", K);
+  LHRS_REQUIRE(K % 32 == 0, "gemm: K=%d must be a multiple of 32 (zero-pad the reduction dim)", K);
   LHRS_REQUIRE(N % 4 == 0, "gemm: N=%d must be a multiple of 4", N);
   LHRS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "gemm: lda=%d ldb=%d must be multiples of 8 (16-B rows)", lda, ldb);
   LHRS_REQUIRE(ldc % 4 == 0 && (residual == nullptr || ldr % 4 == 0), "gemm: ldc/ldr must be multiples of 4");
@@ -272,17 +566,45 @@ extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
       default: hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, 3>), grid, blk, 0, s, g); break;             \
     }                                                                                                  \
   } while (0)
+  const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
+  const bool use256 = g_gemm_allow_256 && t256 >= 160 && K >= 96 && K % 32 == 0;  // ring prologue needs >= 3 stages
+  LHRS_REQUIRE(use256 || K % 64 == 0, "gemm: K=%d must be a multiple of 64 for this problem size (zero-pad the reduction dim)", K);
   const bool big = t128 >= 384;
   int slot = -1;
   if (g_prof.on) {
     g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * K;
-    if (big && g_prof.used < g_prof.cap) {
+    if ((big || use256) && g_prof.used < g_prof.cap) {
       slot = g_prof.used++;
       g_prof.flops[slot] = 2.0 * M * N * K;
       (void)hipEventRecord(g_prof.ev[2 * slot], s);
     }
   }
-  if (big) LAUNCH_TILE(4, 4);
+  if (use256) {
+    g.tilesM = cdiv(M, 256); g.tilesN = cdiv(N, 256);
+    const dim3 grid(g.tilesM * g.tilesN), blk(512);
+    if (g_gemm_allow_256 == 3) {
+      switch (act) {
+        case 0: hipLaunchKernelGGL((gemm_nt_256p_kernel<0, true>), grid, blk, 0, s, g); break;
+        case 1: hipLaunchKernelGGL((gemm_nt_256p_kernel<1, true>), grid, blk, 0, s, g); break;
+        case 2: hipLaunchKernelGGL((gemm_nt_256p_kernel<2, true>), grid, blk, 0, s, g); break;
+        default: hipLaunchKernelGGL((gemm_nt_256p_kernel<3, true>), grid, blk, 0, s, g); break;
+      }
+    } else if (g_gemm_allow_256 == 1) {
+      switch (act) {
+        case 0: hipLaunchKernelGGL((gemm_nt_256_kernel<0>), grid, blk, 0, s, g); break;
+        case 1: hipLaunchKernelGGL((gemm_nt_256_kernel<1>), grid, blk, 0, s, g); break;
+        case 2: hipLaunchKernelGGL((gemm_nt_256_kernel<2>), grid, blk, 0, s, g); break;
+        default: hipLaunchKernelGGL((gemm_nt_256_kernel<3>), grid, blk, 0, s, g); break;
+      }
+    } else {
+      switch (act) {
+        case 0: hipLaunchKernelGGL((gemm_nt_256p_kernel<0, false>), grid, blk, 0, s, g); break;
+        case 1: hipLaunchKernelGGL((gemm_nt_256p_kernel<1, false>), grid, blk, 0, s, g); break;
+        case 2: hipLaunchKernelGGL((gemm_nt_256p_kernel<2, false>), grid, blk, 0, s, g); break;
+        default: hipLaunchKernelGGL((gemm_nt_256p_kernel<3, false>), grid, blk, 0, s, g); break;
+      }
+    }
+  } else if (big) LAUNCH_TILE(4, 4);
   else if (t64x128 >= 256) LAUNCH_TILE(2, 4);
   else LAUNCH_TILE(2, 2);
 #undef LAUNCH_TILE

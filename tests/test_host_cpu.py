@@ -32,7 +32,7 @@ def test_rejected_call_reports_error_without_gpu():
 
     lib = _lib.load()
     st = lib.lhrs_gemm_bf16_nt(None, 8, None, 8, None, 8, 4, 4, 48, None, None, 0, 0, 0, 0, 1.0, None)  # K % 64 != 0
-    assert st == -1 and b"multiple of 64" in lib.lhrs_last_error()
+    assert st == -1 and b"must be a multiple of" in lib.lhrs_last_error()
     with pytest.raises(RuntimeError):
         _lib.check(st, "gemm")
 

@@ -24,7 +24,9 @@ def bf(x):
 
 # ------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 1024, 1024), (2184, 4096, 4096), (1000, 12288, 4096),
-                                   (273, 4096, 11008), (64, 64, 64), (33, 132, 128), (1152, 1024, 4096)])
+                                   (273, 4096, 11008), (64, 64, 64), (33, 132, 128), (1152, 1024, 4096),
+                                   (4095, 4096, 128), (3000, 4100, 96), (8190, 4096, 4096), (2184, 22016, 4096),
+                                   (4095, 4096, 22016)])
 def test_gemm_plain(M, N, K):
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
     a = bf(torch.randn(M, K, generator=g)).to(DEV)
@@ -62,6 +64,37 @@ def test_gemm_epilogue(act):
         z = F.silu(z)
     ref = z + res.float()
     assert rel_err(out, ref) < 4e-3
+
+
+@pytest.mark.parametrize("act", [0, 2])
+def test_gemm_epilogue_256_tile(act):
+    M, N, Kd = 4000, 4096, 256   # 16 x 16 tiles of 256^2 -> the 4-stage-ring kernel
+    g = torch.Generator().manual_seed(40 + act)
+    a = bf(torch.randn(M, Kd, generator=g)).to(DEV)
+    b = bf(torch.randn(N, Kd, generator=g) * 0.05).to(DEV)
+    bias = bf(torch.randn(N, generator=g)).to(DEV)
+    res = bf(torch.randn(M, N, generator=g)).to(DEV)
+    out = hk.gemm_nt(a, b, bias=bias, residual=res, act=act)
+    z = a.float() @ b.float().t() + bias.float()
+    if act == 2:
+        z = F.gelu(z)
+    assert rel_err(out, z + res.float()) < 4e-3
+    c32 = hk.gemm_nt(a, b, out_f32=True)
+    assert rel_err(c32, a.float() @ b.float().t()) < 1e-5
+
+
+def test_gemm_256_tile_transpose_detecting_and_repeatable():
+    M = N = 4096
+    Kd = 128
+    a = torch.zeros(M, Kd)
+    a[torch.arange(M), torch.arange(M) % Kd] = 1.0
+    b = (torch.arange(N * Kd, dtype=torch.float32).reshape(N, Kd) % 251) - 125.0
+    A, B = bf(a).to(DEV), bf(b).to(DEV)
+    ref = (A.float() @ B.float().t())
+    first = hk.gemm_nt(A, B, out_f32=True)
+    assert torch.equal(first, ref)
+    for _ in range(20):  # race screen: the ring pipeline must give bit-identical results every launch
+        assert torch.equal(hk.gemm_nt(A, B, out_f32=True), first)
 
 
 def test_gemm_f32_accumulate_and_strided():
