@@ -63,18 +63,18 @@ int lhrs_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* 
  * desc: int32 [nseq][8] = {q_off, q_len, kv_off, kv_len, kv_rows, causal_off, 0, 0} (token offsets/lengths).
  * Replaces HF CLIPAttention, nn.MultiheadAttention (common_arch.py:302-313) and HF LlamaAttention
  * (causal + key-padding from `attention_mask`, text_modal.py:281-292).  D = 64 or 128.
- * *_T operands are [nseq][H*D][LT] zero-padded token-transposed copies made by lhrs_seq_transpose.       */
+ * lse / delta are fp32 [nseq][H][LTq] (LTq = max_q rounded up to 64).  Token-transposed operands are formed in LDS
+ * by ds_read_b64_tr_b16; no transposed copies are needed.                                                  */
 int lhrs_seq_transpose(const void* in, long ld_in, void* out, int cols, int LT, const int* desc, int nseq, int use_kv,
-                       void* stream);
-int lhrs_attn_fwd(const void* q, long ldq, const void* k, long ldk, const void* vT, void* o, long ldo, float* lse,
-                  const int* desc, int nseq, int H, int D, int max_q, int LTq, int LTkv, int causal, float scale,
-                  void* stream);
+                       void* stream); /* utility; the attention kernels no longer need transposed copies */
+int lhrs_attn_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, float* lse,
+                  const int* desc, int nseq, int H, int D, int max_q, int LTq, int causal, float scale, void* stream);
 int lhrs_attn_delta(const void* o, long ldo, const void* dout, long ld_do, float* delta, const int* desc, int nseq, int H,
                     int D, int max_q, int LTq, void* stream);
 int lhrs_attn_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout,
-                  long ld_do, const void* qT, const void* kT, const void* doT, const float* lse, const float* delta,
-                  void* dq, long ld_dq, void* dk, long ld_dk, void* dv, long ld_dv, const int* desc, int nseq, int H,
-                  int D, int max_q, int max_kv, int LTq, int LTkv, int causal, float scale, void* stream);
+                  long ld_do, const float* lse, const float* delta, void* dq, long ld_dq, void* dk, long ld_dk, void* dv,
+                  long ld_dv, const int* desc, int nseq, int H, int D, int max_q, int max_kv, int LTq, int causal,
+                  float scale, void* stream);
 
 /* ---- element-wise / layout -------------------------------------------------------------------------- *
  * patchify/assemble: HF CLIPVisionEmbeddings (rgb_vision_modal.py:166-172); rope: HF apply_rotary_pos_emb;

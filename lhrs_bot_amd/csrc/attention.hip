@@ -20,8 +20,13 @@
 //   dQ      :  S^T, dP^T = V . dO^T -> dS ->  dQ^T = K^T . dS^T (A = K^T tile, B = dS regs)
 //   dK, dV  :  S = Q . K^T (A = Q tile, B = K regs), dP = dO . V^T -> P, dS ->
 //              dV^T = dO^T . P (A = dO^T tile, B = P regs),  dK^T = Q^T . dS (A = Q^T tile, B = dS regs)
-// The operands that must be contiguous along the token axis (V^T, K^T, Q^T, dO^T) are read from transposed,
-// zero-padded copies [seq][H*D][LT] produced by lhrs_seq_transpose (HBM-bound, ~1-2 % of a layer).
+// The operands that must be contiguous along the token axis (V^T, K^T, Q^T, dO^T) are read straight out of the SAME
+// row-major LDS tiles with gfx950's transposing LDS read (ds_read_b64_tr_b16): inside a 16-lane group, lane i receives
+// element (i&3) of the 8-byte chunk addressed by lane 4j + (i>>2), for j = 0..3 - so when lane L addresses
+// tile[token t0 + (L>>2)][d0 + 4*(L&3)], lane i ends up with tile[t0 + j][d0 + i]: a [4 tokens x 16 d] transpose per
+// group and instruction, which is exactly one half of an MFMA operand in the k-slot permutation above.
+// No transposed copies exist in HBM.  K/V (or Q/dO) tiles are prefetched global->registers while the previous tile is
+// multiplied, then written to LDS behind one barrier (latency hidden behind the MFMAs).
 #include "common.h"
 
 namespace {
@@ -30,8 +35,7 @@ struct AttnArgs {
   const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* dout;  // row-major [tokens, ld]
   long ldq, ldk, ldv, ldo, ld_do, ld_dq, ld_dk, ld_dv;
   bf16_t* o; bf16_t* dq; bf16_t* dk; bf16_t* dv;
-  const bf16_t* qT; const bf16_t* kT; const bf16_t* vT; const bf16_t* doT;  // [seq][H*D][LT*]
-  int LTq, LTkv;      // padded lengths of the transposed copies / lse rows (multiples of 64)
+  int LTq;            // padded row length of lse / delta (multiple of 64)
   float* lse;         // [seq][H][LTq]
   const float* delta; // [seq][H][LTq]
   const int* desc;    // [nseq][8]
@@ -41,45 +45,82 @@ struct AttnArgs {
 
 constexpr float NEG_INF = -__builtin_huge_valf();
 
-// ---- LDS tile images ----------------------------------------------------------------------------
-// row-major tile [64][D]: 16-B chunk index XOR (row & (chunks-1))  -> ds_read_b128 fragments
+// ---- LDS tile image ----------------------------------------------------------------------------
+// row-major tile [64 tokens][D]: 16-B chunk index XOR f(row).  D=128 (16 chunks, 256-B rows): f = ((row&7)<<1)|((row>>3)&1)
+// - a bijection on 0..15 (ds_read_b128 over 16 rows conflict-free) whose low rows land on distinct 32-B pairs (the
+// 8 tokens x 32 B of a transposing read conflict-free).  D=64 (8 chunks, 128-B rows): f = row&7.
 template <int D>
-__device__ __forceinline__ int rm_off(int row, int c) {
-  constexpr int CH = D / 8;
-  return row * (D * 2) + ((c ^ (row & (CH - 1))) << 4);
+__device__ __forceinline__ int swz(int row) {
+  return D == 128 ? (((row & 7) << 1) | ((row >> 3) & 1)) : (row & 7);
 }
-// transposed tile [D][64 tokens]: 8-B unit index XOR (((d>>1)&7)<<1) -> ds_read_b64 fragment halves
-__device__ __forceinline__ int t_off8(int d, int u) { return d * 128 + ((u ^ (((d >> 1) & 7) << 1)) << 3); }
-__device__ __forceinline__ int t_off16(int d, int c) { return d * 128 + ((c ^ ((d >> 1) & 7)) << 4); }
+template <int D>
+__device__ __forceinline__ int rm_off(int row, int c) { return row * (D * 2) + ((c ^ swz<D>(row)) << 4); }
+
+template <int D> struct TileRegs { uint4 v[64 * (D / 8) / 256]; };
 
 template <int D>
-__device__ __forceinline__ void load_rm_tile(char* lds, const bf16_t* base, long ld, int row0, int len, int tid) {
-  constexpr int CH = D / 8;
+__device__ __forceinline__ void tile_load(TileRegs<D>& r, const bf16_t* base, long ld, int row0, int len, int tid) {
+  constexpr int CH = D / 8, N = 64 * CH / 256;
 #pragma unroll
-  for (int i = tid; i < 64 * CH; i += 256) {
-    const int r = i / CH, c = i % CH;
-    const int gr = min(row0 + r, len - 1);
-    const uint4 v = *reinterpret_cast<const uint4*>(base + (long)gr * ld + c * 8);
-    *reinterpret_cast<uint4*>(lds + rm_off<D>(r, c)) = v;
+  for (int i = 0; i < N; ++i) {
+    const int idx = tid + i * 256;
+    const int gr = min(row0 + idx / CH, len - 1);
+    r.v[i] = *reinterpret_cast<const uint4*>(base + (long)gr * ld + (idx % CH) * 8);
   }
 }
 template <int D>
-__device__ __forceinline__ void load_t_tile(char* lds, const bf16_t* baseT, int LT, int t0, int tid) {
+__device__ __forceinline__ void tile_store(char* lds, const TileRegs<D>& r, int tid) {
+  constexpr int CH = D / 8, N = 64 * CH / 256;
 #pragma unroll
-  for (int i = tid; i < D * 8; i += 256) {
-    const int d = i >> 3, c = i & 7;
-    const uint4 v = *reinterpret_cast<const uint4*>(baseT + (long)d * LT + t0 + c * 8);
-    *reinterpret_cast<uint4*>(lds + t_off16(d, c)) = v;
+  for (int i = 0; i < N; ++i) {
+    const int idx = tid + i * 256;
+    *reinterpret_cast<uint4*>(lds + rm_off<D>(idx / CH, idx % CH)) = r.v[i];
   }
 }
 template <int D>
 __device__ __forceinline__ bf16x8 frag_rm(const char* lds, int row, int ks, int fg) {
   return *reinterpret_cast<const bf16x8*>(lds + rm_off<D>(row, ks * 4 + fg));
 }
-// k-step t of a [.][64]-token tile: k-slot (fg, j<4) <-> token 32t + fg*4 + j ; (fg, j>=4) <-> token 32t + 16 + fg*4 + j-4
-__device__ __forceinline__ bf16x8 frag_t(const char* lds, int d, int t, int fg) {
-  const bf16x4 lo = *reinterpret_cast<const bf16x4*>(lds + t_off8(d, (2 * t) * 4 + fg));
-  const bf16x4 hi = *reinterpret_cast<const bf16x4*>(lds + t_off8(d, (2 * t + 1) * 4 + fg));
+
+// Transposing fragment reads.  For k-step t of a 64-token tile, the fragment of d-block db holds, for lane (L = lane&15,
+// g = lane>>4): k-slot j<4 <-> token 32t + 4g + j, j>=4 <-> token 32t + 16 + 4g + (j-4), all at d = 16 db + L.
+// Lane address: token r0 = 4g + (L>>2) (+32t, +16), 16-B chunk 2 db + ((L&3)>>1), 8-B half (L&1).
+template <int D>
+struct TrAddr {
+  unsigned base[D / 16];  // per d-block byte address inside the tile for (t = 0, lower half)
+  __device__ __forceinline__ void init(const char* lds, int lane) {
+    const int L = lane & 15, g = lane >> 4;
+    const int r0 = 4 * g + (L >> 2);
+    const unsigned tile = (unsigned)(size_t)((__attribute__((address_space(3))) const char*)lds);
+#pragma unroll
+    for (int db = 0; db < D / 16; ++db)
+      base[db] = tile + r0 * (D * 2) + (((2 * db + ((L & 3) >> 1)) ^ swz<D>(r0)) << 4) + (L & 1) * 8;
+  }
+};
+#define TR_RD(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+
+// issue the 2 * D/16 transposing reads of k-step T (results are NOT valid until tr_wait)
+template <int D, int T>
+__device__ __forceinline__ void tr_issue(const TrAddr<D>& a, bf16x4 (&lo)[D / 16], bf16x4 (&hi)[D / 16]) {
+#pragma unroll
+  for (int db = 0; db < D / 16; ++db) {
+    TR_RD(lo[db], a.base[db], (32 * T) * (D * 2));
+    TR_RD(hi[db], a.base[db], (32 * T + 16) * (D * 2));
+  }
+}
+template <int N>
+__device__ __forceinline__ void tr_wait(bf16x4 (&lo)[N], bf16x4 (&hi)[N]) {
+  if constexpr (N == 8) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]),
+                   "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7]));
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ bf16x8 join(const bf16x4& lo, const bf16x4& hi) {
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
@@ -107,7 +148,7 @@ template <int D, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   constexpr int KS = D / 32, DB = D / 16;
   __shared__ __attribute__((aligned(16))) char lds_k[64 * D * 2];
-  __shared__ __attribute__((aligned(16))) char lds_vt[D * 128];
+  __shared__ __attribute__((aligned(16))) char lds_v[64 * D * 2];
   const int seq = blockIdx.z, h = blockIdx.y;
   const int* ds = a.desc + seq * 8;
   const int q_off = ds[0], q_len = ds[1], kv_off = ds[2], kv_len = ds[3], coff = ds[5];
@@ -129,13 +170,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   if (CAUSAL) kv_end = max(0, min(kv_len, q0 + 64 + coff));
   const int ntiles = (kv_end + 63) >> 6;
   const bf16_t* kbase = a.k + (long)kv_off * a.ldk + h * D;
-  const bf16_t* vtbase = a.vT + ((long)(seq * a.H + h) * D) * a.LTkv;
+  const bf16_t* vbase = a.v + (long)kv_off * a.ldv + h * D;
+  TrAddr<D> tv;
+  tv.init(lds_v, lane);
+  TileRegs<D> kr, vr;
+  if (ntiles > 0) { tile_load<D>(kr, kbase, a.ldk, 0, kv_len, tid); tile_load<D>(vr, vbase, a.ldv, 0, kv_len, tid); }
 
   for (int j = 0; j < ntiles; ++j) {
+    __syncthreads();  // every wave is done reading tile j-1
+    tile_store<D>(lds_k, kr, tid);
+    tile_store<D>(lds_v, vr, tid);
     __syncthreads();
-    load_rm_tile<D>(lds_k, kbase, a.ldk, j * 64, kv_len, tid);
-    load_t_tile<D>(lds_vt, vtbase, a.LTkv, j * 64, tid);
-    __syncthreads();
+    if (j + 1 < ntiles) {  // prefetch tile j+1 into registers; the loads fly while tile j is multiplied
+      tile_load<D>(kr, kbase, a.ldk, (j + 1) * 64, kv_len, tid);
+      tile_load<D>(vr, vbase, a.ldv, (j + 1) * 64, kv_len, tid);
+    }
     f32x4 s[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
@@ -143,6 +192,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) s[nb] = MFMA(frag_rm<D>(lds_k, nb * 16 + fr, ks, fg), qf[ks], s[nb]);
     }
+    bf16x4 v0lo[DB], v0hi[DB], v1lo[DB], v1hi[DB];
+    tr_issue<D, 0>(tv, v0lo, v0hi);  // V^T fragments of k-step 0 land while the softmax runs
     float mx = NEG_INF;
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
@@ -170,12 +221,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     m = m_new;
 #pragma unroll
     for (int i = 0; i < DB; ++i) o[i] *= alpha;
+    const bf16x8 p0 = pack_frag(s[0], s[1]), p1 = pack_frag(s[2], s[3]);
+    tr_wait<DB>(v0lo, v0hi);
+    tr_issue<D, 1>(tv, v1lo, v1hi);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const bf16x8 pb = pack_frag(s[2 * t], s[2 * t + 1]);
+    for (int db = 0; db < DB; ++db) o[db] = MFMA(join(v0lo[db], v0hi[db]), p0, o[db]);
+    tr_wait<DB>(v1lo, v1hi);
 #pragma unroll
-      for (int db = 0; db < DB; ++db) o[db] = MFMA(frag_t(lds_vt, db * 16 + fr, t, fg), pb, o[db]);
-    }
+    for (int db = 0; db < DB; ++db) o[db] = MFMA(join(v1lo[db], v1hi[db]), p1, o[db]);
   }
   if (qrow < q_len) {
     const float inv = l > 0.f ? 1.f / l : 0.f;
@@ -192,7 +246,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
   constexpr int KS = D / 32, DB = D / 16;
   __shared__ __attribute__((aligned(16))) char lds_k[64 * D * 2];
   __shared__ __attribute__((aligned(16))) char lds_v[64 * D * 2];
-  __shared__ __attribute__((aligned(16))) char lds_kt[D * 128];
   const int seq = blockIdx.z, h = blockIdx.y;
   const int* ds = a.desc + seq * 8;
   const int q_off = ds[0], q_len = ds[1], kv_off = ds[2], kv_len = ds[3], coff = ds[5];
@@ -220,14 +273,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
   const int ntiles = (kv_end + 63) >> 6;
   const bf16_t* kbase = a.k + (long)kv_off * a.ldk + h * D;
   const bf16_t* vbase = a.v + (long)kv_off * a.ldv + h * D;
-  const bf16_t* ktbase = a.kT + ((long)(seq * a.H + h) * D) * a.LTkv;
+  TrAddr<D> tk;
+  tk.init(lds_k, lane);
+  TileRegs<D> kr, vr;
+  if (ntiles > 0) { tile_load<D>(kr, kbase, a.ldk, 0, kv_len, tid); tile_load<D>(vr, vbase, a.ldv, 0, kv_len, tid); }
 
   for (int j = 0; j < ntiles; ++j) {
     __syncthreads();
-    load_rm_tile<D>(lds_k, kbase, a.ldk, j * 64, kv_len, tid);
-    load_rm_tile<D>(lds_v, vbase, a.ldv, j * 64, kv_len, tid);
-    load_t_tile<D>(lds_kt, ktbase, a.LTkv, j * 64, tid);
+    tile_store<D>(lds_k, kr, tid);
+    tile_store<D>(lds_v, vr, tid);
     __syncthreads();
+    if (j + 1 < ntiles) {
+      tile_load<D>(kr, kbase, a.ldk, (j + 1) * 64, kv_len, tid);
+      tile_load<D>(vr, vbase, a.ldv, (j + 1) * 64, kv_len, tid);
+    }
     f32x4 s[4], dp[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
@@ -239,6 +298,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         dp[nb] = MFMA(frag_rm<D>(lds_v, nb * 16 + fr, ks, fg), dof[ks], dp[nb]);
       }
     }
+    bf16x4 k0lo[DB], k0hi[DB], k1lo[DB], k1hi[DB];
+    tr_issue<D, 0>(tk, k0lo, k0hi);  // K^T fragments of k-step 0 land while dS is formed
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
@@ -248,12 +309,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         const float p = ok ? __expf(s[nb][r] * a.scale - lse_q) : 0.f;
         s[nb][r] = ok ? p * (dp[nb][r] - delta_q) * a.scale : 0.f;  // dS
       }
+    const bf16x8 d0 = pack_frag(s[0], s[1]), d1 = pack_frag(s[2], s[3]);
+    tr_wait<DB>(k0lo, k0hi);
+    tr_issue<D, 1>(tk, k1lo, k1hi);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const bf16x8 dsb = pack_frag(s[2 * t], s[2 * t + 1]);
+    for (int db = 0; db < DB; ++db) dq[db] = MFMA(join(k0lo[db], k0hi[db]), d0, dq[db]);
+    tr_wait<DB>(k1lo, k1hi);
 #pragma unroll
-      for (int db = 0; db < DB; ++db) dq[db] = MFMA(frag_t(lds_kt, db * 16 + fr, t, fg), dsb, dq[db]);
-    }
+    for (int db = 0; db < DB; ++db) dq[db] = MFMA(join(k1lo[db], k1hi[db]), d1, dq[db]);
   }
   if (qrow < q_len) {
     bf16_t* p = a.dq + (long)(q_off + qrow) * a.ld_dq + h * D + fg * 4;
@@ -268,8 +332,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   constexpr int KS = D / 32, DB = D / 16;
   __shared__ __attribute__((aligned(16))) char lds_q[64 * D * 2];
   __shared__ __attribute__((aligned(16))) char lds_do[64 * D * 2];
-  __shared__ __attribute__((aligned(16))) char lds_qt[D * 128];
-  __shared__ __attribute__((aligned(16))) char lds_dot[D * 128];
   __shared__ __attribute__((aligned(16))) float lds_lse[64];
   __shared__ __attribute__((aligned(16))) float lds_delta[64];
   const int seq = blockIdx.z, h = blockIdx.y;
@@ -297,20 +359,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   if (CAUSAL) i0 = max(0, (k0 - coff) >> 6);  // first q tile that can see key k0 (q >= key - coff)
   const bf16_t* qbase = a.q + (long)q_off * a.ldq + h * D;
   const bf16_t* dobase = a.dout + (long)q_off * a.ld_do + h * D;
-  const bf16_t* qtbase = a.qT + ((long)(seq * a.H + h) * D) * a.LTq;
-  const bf16_t* dotbase = a.doT + ((long)(seq * a.H + h) * D) * a.LTq;
   const float* lsebase = a.lse + (long)(seq * a.H + h) * a.LTq;
   const float* deltabase = a.delta + (long)(seq * a.H + h) * a.LTq;
+  TrAddr<D> tq, tdo;
+  tq.init(lds_q, lane);
+  tdo.init(lds_do, lane);
+  TileRegs<D> qr, dor;
+  float stat_r = 0.f;
+  auto prefetch = [&](int i) {
+    tile_load<D>(qr, qbase, a.ldq, i * 64, q_len, tid);
+    tile_load<D>(dor, dobase, a.ld_do, i * 64, q_len, tid);
+    if (tid < 64) stat_r = lsebase[i * 64 + tid];
+    else if (tid < 128) stat_r = deltabase[i * 64 + tid - 64];
+  };
+  if (i0 < nq_tiles) prefetch(i0);
 
   for (int i = i0; i < nq_tiles; ++i) {
     __syncthreads();
-    load_rm_tile<D>(lds_q, qbase, a.ldq, i * 64, q_len, tid);
-    load_rm_tile<D>(lds_do, dobase, a.ld_do, i * 64, q_len, tid);
-    load_t_tile<D>(lds_qt, qtbase, a.LTq, i * 64, tid);
-    load_t_tile<D>(lds_dot, dotbase, a.LTq, i * 64, tid);
-    if (tid < 64) lds_lse[tid] = lsebase[i * 64 + tid];
-    else if (tid < 128) lds_delta[tid - 64] = deltabase[i * 64 + tid - 64];
+    tile_store<D>(lds_q, qr, tid);
+    tile_store<D>(lds_do, dor, tid);
+    if (tid < 64) lds_lse[tid] = stat_r;
+    else if (tid < 128) lds_delta[tid - 64] = stat_r;
     __syncthreads();
+    if (i + 1 < nq_tiles) prefetch(i + 1);
     f32x4 s[4], dp[4];
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) {
@@ -322,6 +393,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         dp[qb] = MFMA(frag_rm<D>(lds_do, qb * 16 + fr, ks, fg), vf[ks], dp[qb]);
       }
     }
+    bf16x4 alo[DB], ahi[DB], blo[DB], bhi[DB];
+    tr_issue<D, 0>(tdo, alo, ahi);  // dO^T, k-step 0
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) {
       const f32x4 lq = *reinterpret_cast<const f32x4*>(&lds_lse[qb * 16 + fg * 4]);
@@ -335,16 +408,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         s[qb][r] = p;                                               // P
       }
     }
+    const bf16x8 p0 = pack_frag(s[0], s[1]), p1 = pack_frag(s[2], s[3]);
+    const bf16x8 d0 = pack_frag(dp[0], dp[1]), d1 = pack_frag(dp[2], dp[3]);
+    tr_wait<DB>(alo, ahi);
+    tr_issue<D, 0>(tq, blo, bhi);   // Q^T, k-step 0
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const bf16x8 pb = pack_frag(s[2 * t], s[2 * t + 1]);
-      const bf16x8 dsb = pack_frag(dp[2 * t], dp[2 * t + 1]);
+    for (int db = 0; db < DB; ++db) dv[db] = MFMA(join(alo[db], ahi[db]), p0, dv[db]);
+    tr_wait<DB>(blo, bhi);
+    tr_issue<D, 1>(tdo, alo, ahi);  // dO^T, k-step 1
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int db = 0; db < DB; ++db) {
-        dv[db] = MFMA(frag_t(lds_dot, db * 16 + fr, t, fg), pb, dv[db]);
-        dk[db] = MFMA(frag_t(lds_qt, db * 16 + fr, t, fg), dsb, dk[db]);
-      }
-    }
+    for (int db = 0; db < DB; ++db) dk[db] = MFMA(join(blo[db], bhi[db]), d0, dk[db]);
+    tr_wait<DB>(alo, ahi);
+    tr_issue<D, 1>(tq, blo, bhi);   // Q^T, k-step 1
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int db = 0; db < DB; ++db) dv[db] = MFMA(join(alo[db], ahi[db]), p1, dv[db]);
+    tr_wait<DB>(blo, bhi);
+#pragma unroll
+    for (int db = 0; db < DB; ++db) dk[db] = MFMA(join(blo[db], bhi[db]), d1, dk[db]);
   }
   if (key < kv_rows) {
     bf16_t* pk = a.dk + (long)(kv_off + key) * a.ld_dk + h * D + fg * 4;
@@ -399,7 +482,7 @@ __global__ __launch_bounds__(256) void seq_transpose_kernel(const bf16_t* __rest
 int check_common(const AttnArgs& a, int D, int nseq, const char* who) {
   LHRS_REQUIRE(D == 64 || D == 128, "%s: head_dim %d unsupported (64 or 128)", who, D);
   LHRS_REQUIRE(nseq > 0 && a.H > 0, "%s: nseq=%d H=%d", who, nseq, a.H);
-  LHRS_REQUIRE(a.LTq % 64 == 0 && a.LTkv % 64 == 0, "%s: padded lengths must be multiples of 64", who);
+  LHRS_REQUIRE(a.LTq % 64 == 0, "%s: LTq must be a multiple of 64", who);
   return 0;
 }
 
@@ -415,12 +498,12 @@ extern "C" int lhrs_seq_transpose(const void* in, long ld_in, void* out, int col
   return 0;
 }
 
-extern "C" int lhrs_attn_fwd(const void* q, long ldq, const void* k, long ldk, const void* vT, void* o, long ldo,
-                             float* lse, const int* desc, int nseq, int H, int D, int max_q, int LTq, int LTkv,
-                             int causal, float scale, void* stream) {
+extern "C" int lhrs_attn_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
+                             float* lse, const int* desc, int nseq, int H, int D, int max_q, int LTq, int causal,
+                             float scale, void* stream) {
   AttnArgs a; memset(&a, 0, sizeof(a));
-  a.q = (const bf16_t*)q; a.ldq = ldq; a.k = (const bf16_t*)k; a.ldk = ldk; a.vT = (const bf16_t*)vT;
-  a.o = (bf16_t*)o; a.ldo = ldo; a.lse = lse; a.desc = desc; a.H = H; a.LTq = LTq; a.LTkv = LTkv; a.scale = scale;
+  a.q = (const bf16_t*)q; a.ldq = ldq; a.k = (const bf16_t*)k; a.ldk = ldk; a.v = (const bf16_t*)v; a.ldv = ldv;
+  a.o = (bf16_t*)o; a.ldo = ldo; a.lse = lse; a.desc = desc; a.H = H; a.LTq = LTq; a.scale = scale;
   if (check_common(a, D, nseq, "attn_fwd")) return -1;
   const dim3 grid(cdiv(max_q, 64), H, nseq), blk(256);
   hipStream_t s = (hipStream_t)stream;
@@ -451,16 +534,14 @@ extern "C" int lhrs_attn_delta(const void* o, long ldo, const void* dout, long l
 }
 
 extern "C" int lhrs_attn_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
-                             const void* dout, long ld_do, const void* qT, const void* kT, const void* doT,
-                             const float* lse, const float* delta, void* dq, long ld_dq, void* dk, long ld_dk,
-                             void* dv, long ld_dv, const int* desc, int nseq, int H, int D, int max_q, int max_kv,
-                             int LTq, int LTkv, int causal, float scale, void* stream) {
+                             const void* dout, long ld_do, const float* lse, const float* delta, void* dq, long ld_dq,
+                             void* dk, long ld_dk, void* dv, long ld_dv, const int* desc, int nseq, int H, int D,
+                             int max_q, int max_kv, int LTq, int causal, float scale, void* stream) {
   AttnArgs a; memset(&a, 0, sizeof(a));
   a.q = (const bf16_t*)q; a.ldq = ldq; a.k = (const bf16_t*)k; a.ldk = ldk; a.v = (const bf16_t*)v; a.ldv = ldv;
-  a.dout = (const bf16_t*)dout; a.ld_do = ld_do; a.qT = (const bf16_t*)qT; a.kT = (const bf16_t*)kT;
-  a.doT = (const bf16_t*)doT; a.lse = (float*)lse; a.delta = delta;
+  a.dout = (const bf16_t*)dout; a.ld_do = ld_do; a.lse = (float*)lse; a.delta = delta;
   a.dq = (bf16_t*)dq; a.ld_dq = ld_dq; a.dk = (bf16_t*)dk; a.ld_dk = ld_dk; a.dv = (bf16_t*)dv; a.ld_dv = ld_dv;
-  a.desc = desc; a.H = H; a.LTq = LTq; a.LTkv = LTkv; a.scale = scale;
+  a.desc = desc; a.H = H; a.LTq = LTq; a.scale = scale;
   if (check_common(a, D, nseq, "attn_bwd")) return -1;
   hipStream_t s = (hipStream_t)stream;
   const dim3 gq(cdiv(max_q, 64), H, nseq), gk(cdiv(max_kv, 64), H, nseq), blk(256);

@@ -127,9 +127,9 @@ def seq_transpose(x, cols, LT, desc, nseq, which: str):
     return out
 
 
-def attn_fwd(q, k, vT, o, lse, desc, nseq, H, D, max_q, LTq, LTkv, causal, scale):
-    st = _L().lhrs_attn_fwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), vT.data_ptr(), o.data_ptr(), o.stride(0),
-                            _p(lse), desc.data_ptr(), nseq, H, D, max_q, LTq, LTkv, int(causal), float(scale), _stream())
+def attn_fwd(q, k, v, o, lse, desc, nseq, H, D, max_q, LTq, causal, scale):
+    st = _L().lhrs_attn_fwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), o.data_ptr(),
+                            o.stride(0), _p(lse), desc.data_ptr(), nseq, H, D, max_q, LTq, int(causal), float(scale), _stream())
     _lib.check(st, "attn_fwd")
 
 
@@ -139,11 +139,11 @@ def attn_delta(o, dout, delta, desc, nseq, H, D, max_q, LTq):
     _lib.check(st, "attn_delta")
 
 
-def attn_bwd(q, k, v, dout, qT, kT, doT, lse, delta, dq, dk, dv, desc, nseq, H, D, max_q, max_kv, LTq, LTkv, causal, scale):
+def attn_bwd(q, k, v, dout, lse, delta, dq, dk, dv, desc, nseq, H, D, max_q, max_kv, LTq, causal, scale):
     st = _L().lhrs_attn_bwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), dout.data_ptr(),
-                            dout.stride(0), qT.data_ptr(), kT.data_ptr(), doT.data_ptr(), lse.data_ptr(), delta.data_ptr(),
-                            dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(), dv.stride(0),
-                            desc.data_ptr(), nseq, H, D, max_q, max_kv, LTq, LTkv, int(causal), float(scale), _stream())
+                            dout.stride(0), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dq.stride(0), dk.data_ptr(),
+                            dk.stride(0), dv.data_ptr(), dv.stride(0), desc.data_ptr(), nseq, H, D, max_q, max_kv, LTq,
+                            int(causal), float(scale), _stream())
     _lib.check(st, "attn_bwd")
 
 

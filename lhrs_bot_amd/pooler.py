@@ -164,10 +164,9 @@ class AttnPooler:
             tn, t_mean, t_rstd = hk.layernorm_fwd(t, w[b + "ln_1.weight"], w[b + "ln_1.bias"], save_stats=True)
             q = hk.gemm_nt(tn, Win[:d], bias=bin_[:d])
             kvp = hk.gemm_nt(kvn, Win[d:], bias=bin_[d:])                      # [B*912, 2d] = K | V
-            vT = hk.seq_transpose(kvp[:, d:], d, LTkv, desc, nseq, "kv")
             o = torch.empty((M, d), device=self.device, dtype=torch.bfloat16)
             lse = torch.empty((nseq, H, LTq), device=self.device, dtype=torch.float32)
-            hk.attn_fwd(q, kvp[:, :d], vT, o, lse, desc, nseq, H, d // H, max(STAGE_NUM), LTq, LTkv, False, scale)
+            hk.attn_fwd(q, kvp[:, :d], kvp[:, d:], o, lse, desc, nseq, H, d // H, max(STAGE_NUM), LTq, False, scale)
             t1 = hk.gemm_nt(o, w[b + "attn.out_proj.weight"], bias=w[b + "attn.out_proj.bias"], residual=t)
             t1n, t1_mean, t1_rstd = hk.layernorm_fwd(t1, w[b + "ln_2.weight"], w[b + "ln_2.bias"], save_stats=True)
             hpre = hk.gemm_nt(t1n, w[b + "mlp.c_fc.weight"], bias=w[b + "mlp.c_fc.bias"])
@@ -228,13 +227,10 @@ class AttnPooler:
             delta = torch.empty((nseq, H, LTq), device=self.device, dtype=torch.float32)
             hk.attn_delta(s["o"], do, delta, desc, nseq, H, d // H, max(STAGE_NUM), LTq)
             kvp = s["kvp"]
-            qT = hk.seq_transpose(s["q"], d, LTq, desc, nseq, "q")
-            kT = hk.seq_transpose(kvp[:, :d], d, LTkv, desc, nseq, "kv")
-            doT = hk.seq_transpose(do, d, LTq, desc, nseq, "q")
             dq = torch.empty_like(s["q"])
             dkvp = torch.empty_like(kvp)
-            hk.attn_bwd(s["q"], kvp[:, :d], kvp[:, d:], do, qT, kT, doT, s["lse"], delta, dq, dkvp[:, :d], dkvp[:, d:], desc, nseq,
-                        H, d // H, max(STAGE_NUM), LTkv, LTq, LTkv, False, scale)
+            hk.attn_bwd(s["q"], kvp[:, :d], kvp[:, d:], do, s["lse"], delta, dq, dkvp[:, :d], dkvp[:, d:], desc, nseq, H, d // H,
+                        max(STAGE_NUM), LTkv, LTq, False, scale)
             gb = g[b + "attn.in_proj_bias"]
             hk.colsum(dq, gb[:d])
             hk.colsum(dkvp, gb[d:])

@@ -112,10 +112,9 @@ class TextModal:
         h = hk.rmsnorm_fwd(x, L["ln1_w"], self.eps)
         qkv = hk.gemm_nt(h, L["qkv_w"])
         hk.rope_(qkv, M, 2 * H, hd, self.cos, self.sin, pos_mod=S)
-        vT = hk.seq_transpose(qkv[:, 2 * d:], d, LT, desc, B, "kv")
         o = torch.empty((M, d), device=self.device, dtype=torch.bfloat16)
         lse = torch.empty((B, H, LT), device=self.device, dtype=torch.float32)
-        hk.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], vT, o, lse, desc, B, H, hd, S, LT, LT, True, 1.0 / math.sqrt(hd))
+        hk.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, desc, B, H, hd, S, LT, True, 1.0 / math.sqrt(hd))
         x_mid = hk.gemm_nt(o, L["o_w"], residual=x)
         h = hk.rmsnorm_fwd(x_mid, L["ln2_w"], self.eps, out=h)
         gu = hk.gemm_nt(h, L["gu_w"])
@@ -186,11 +185,8 @@ class TextModal:
             dx_mid = hk.rmsnorm_bwd(dh, s["x_mid"], L["ln2_w"], None, add=dx, eps=self.eps, out=dh)
             do = hk.gemm_nt(dx_mid, L["o_wT"])
             hk.attn_delta(s["o"], do, delta, desc, B, H, hd, S, LT)
-            qT = hk.seq_transpose(qkv[:, :d], d, LT, desc, B, "q")
-            kT = hk.seq_transpose(qkv[:, d:2 * d], d, LT, desc, B, "kv")
-            doT = hk.seq_transpose(do, d, LT, desc, B, "q")
-            hk.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], do, qT, kT, doT, s["lse"], delta, dqkv[:, :d], dqkv[:, d:2 * d],
-                        dqkv[:, 2 * d:], desc, B, H, hd, S, S, LT, LT, True, scale)
+            hk.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], do, s["lse"], delta, dqkv[:, :d], dqkv[:, d:2 * d],
+                        dqkv[:, 2 * d:], desc, B, H, hd, S, S, LT, True, scale)
             hk.rope_(dqkv, M, 2 * H, hd, self.cos, self.sin, pos_mod=S, inverse=True)
             dh1 = hk.gemm_nt(dqkv, L["qkv_wT"])
             dx = hk.rmsnorm_bwd(dh1, s["x_in"], L["ln1_w"], None, add=dx_mid, eps=self.eps, out=dh1)

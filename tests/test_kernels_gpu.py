@@ -191,20 +191,20 @@ def run_attention_case(D, H, seqs, causal, same_qkv_buffer):
     max_q = max(s[0] for s in seqs)
     max_kv = max(s[1] for s in seqs)
     LTq, LTkv = hk.pad64(max_q), hk.pad64(max_kv)
-    vT = hk.seq_transpose(v, H * D, LTkv, desc, nseq, "kv")
+    vT = hk.seq_transpose(v, H * D, LTkv, desc, nseq, "kv")   # utility kernel, checked below
+    for i, (lq, lk, kvl) in enumerate(seqs):
+        koff = sum(s_[1] for s_ in seqs[:i])
+        assert torch.equal(vT[i, :, :kvl], v[koff:koff + kvl].t()) and torch.all(vT[i, :, kvl:] == 0)
     o = torch.zeros(tq, H * D, device=DEV, dtype=torch.bfloat16)
     lse = torch.zeros(nseq, H, LTq, device=DEV, dtype=torch.float32)
-    hk.attn_fwd(q, k, vT, o, lse, desc, nseq, H, D, max_q, LTq, LTkv, causal, scale)
+    hk.attn_fwd(q, k, v, o, lse, desc, nseq, H, D, max_q, LTq, causal, scale)
     # backward
-    qT = hk.seq_transpose(q, H * D, LTq, desc, nseq, "q")
-    kT = hk.seq_transpose(k, H * D, LTkv, desc, nseq, "kv")
-    doT = hk.seq_transpose(do, H * D, LTq, desc, nseq, "q")
     delta = torch.zeros(nseq, H, LTq, device=DEV, dtype=torch.float32)
     hk.attn_delta(o, do, delta, desc, nseq, H, D, max_q, LTq)
     dq = torch.full_like(q, float("nan"))
     dk = torch.full_like(k, float("nan"))
     dv = torch.full_like(v, float("nan"))
-    hk.attn_bwd(q, k, v, do, qT, kT, doT, lse, delta, dq, dk, dv, desc, nseq, H, D, max_q, max_kv, LTq, LTkv, causal, scale)
+    hk.attn_bwd(q, k, v, do, lse, delta, dq, dk, dv, desc, nseq, H, D, max_q, max_kv, LTq, causal, scale)
     torch.cuda.synchronize()
     qo = ko = 0
     for (lq, lk, kvl) in seqs:
