@@ -68,7 +68,8 @@ int lhrs_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* 
 int lhrs_seq_transpose(const void* in, long ld_in, void* out, int cols, int LT, const int* desc, int nseq, int use_kv,
                        void* stream); /* utility; the attention kernels no longer need transposed copies */
 int lhrs_attn_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, float* lse,
-                  const int* desc, int nseq, int H, int D, int max_q, int LTq, int causal, float scale, void* stream);
+                  const int* desc, int nseq, int H, int D, int max_q, int max_kv, int LTq, int causal, float scale,
+                  void* stream);
 int lhrs_attn_delta(const void* o, long ldo, const void* dout, long ld_do, float* delta, const int* desc, int nseq, int H,
                     int D, int max_q, int LTq, void* stream);
 int lhrs_attn_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout,

@@ -437,6 +437,326 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   }
 }
 
+// ================================================================================================
+// "Resident" variants: 160 KiB of LDS per CU holds BOTH operand matrices of one (sequence, head) completely
+// (K and V for forward / dQ, Q and dO for dK/dV) when they have at most 320 rows (D = 128) or 640 rows (D = 64) -
+// every attention on the LHRS-Bot training path (S = 273, ViT 257, pooler <= 320).  One 8-wave workgroup per
+// (sequence, head): the matrices are DMA'd once (global_load_lds, swizzle on the source address), one barrier, and then
+// each wave walks 16-row groups on its own - no further barriers, no per-tile global loads.  Groups are dealt to waves
+// in a zig-zag over descending causal cost so that every wave gets (almost) the same number of 64-key tiles.
+// ================================================================================================
+template <int D> constexpr int res_rows() { return 163840 / (2 * D * 2); }
+
+// DMA `rows` (multiple of 64, <= res_rows) rows of a [*, D] bf16 matrix into the swizzled resident image
+template <int D>
+__device__ __forceinline__ void res_load(char* lds, const bf16_t* base, long ld, int rows, int len, int lane, int wave) {
+  constexpr int CH = D / 8, R = 1024 / (D * 2);  // rows per wave-instruction
+  typedef const __attribute__((address_space(1))) void* gp;
+  typedef __attribute__((address_space(3))) void* lp;
+  for (int r0 = wave * R; r0 < rows; r0 += 8 * R) {
+    const int row = r0 + lane / CH;
+    const int c = (lane % CH) ^ swz<D>(row);
+    const bf16_t* src = base + (long)min(row, len - 1) * ld + c * 8;
+    __builtin_amdgcn_global_load_lds((gp)src, (lp)(lds + r0 * (D * 2)), 16, 0, 0);
+  }
+}
+__device__ __forceinline__ int zigzag_group(int p, int wave, int G, bool descending) {
+  const int k = p * 8 + ((p & 1) ? 7 - wave : wave);
+  if (k >= G) return -1;
+  return descending ? G - 1 - k : k;
+}
+
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(512, 2) void attn_fwd_res_kernel(AttnArgs a) {
+  constexpr int KS = D / 32, DB = D / 16, TILE = 64 * D * 2;
+  __shared__ __attribute__((aligned(16))) char smem[163840];
+  char* lds_k = smem;
+  char* lds_v = smem + res_rows<D>() * D * 2;
+  const int seq = blockIdx.y, h = blockIdx.x;
+  const int* ds = a.desc + seq * 8;
+  const int q_off = ds[0], q_len = ds[1], kv_off = ds[2], kv_len = ds[3], coff = ds[5];
+  const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int kv_need = kv_len;
+  if (CAUSAL) kv_need = max(0, min(kv_len, q_len + coff));
+  const int rows = ((kv_need + 63) >> 6) << 6;
+  if (rows > 0) {
+    res_load<D>(lds_k, a.k + (long)kv_off * a.ldk + h * D, a.ldk, rows, kv_len, lane, wave);
+    res_load<D>(lds_v, a.v + (long)kv_off * a.ldv + h * D, a.ldv, rows, kv_len, lane, wave);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  TrAddr<D> tv;
+  tv.init(lds_v, lane);
+  const int G = (q_len + 15) >> 4;
+  for (int p = 0;; ++p) {
+    const int g = zigzag_group(p, wave, G, CAUSAL);
+    if (g < 0) break;
+    const int qrow = g * 16 + fr;
+    const bf16_t* qp = a.q + (long)(q_off + min(qrow, q_len - 1)) * a.ldq + h * D;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32 + fg * 8);
+    float m = NEG_INF, l = 0.f;
+    f32x4 o[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int kv_end = kv_len;
+    if (CAUSAL) kv_end = max(0, min(kv_len, g * 16 + 16 + coff));
+    const int ntiles = (kv_end + 63) >> 6;
+    for (int j = 0; j < ntiles; ++j) {
+      const char* kt = lds_k + j * TILE;
+      f32x4 s[4];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        s[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s[nb] = MFMA(frag_rm<D>(kt, nb * 16 + fr, ks, fg), qf[ks], s[nb]);
+      }
+      TrAddr<D> tj;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) tj.base[db] = tv.base[db] + j * TILE;
+      bf16x4 v0lo[DB], v0hi[DB], v1lo[DB], v1hi[DB];
+      tr_issue<D, 0>(tj, v0lo, v0hi);
+      float mx = NEG_INF;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = j * 64 + nb * 16 + fg * 4 + r;
+          const bool ok = key < kv_len && (!CAUSAL || key <= qrow + coff);
+          s[nb][r] = ok ? s[nb][r] * a.scale : NEG_INF;
+          mx = fmaxf(mx, s[nb][r]);
+        }
+      mx = group_max(mx);
+      const float m_new = fmaxf(m, mx);
+      const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+      const float alpha = __expf(m - m_use);
+      float rs = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s[nb][r] = __expf(s[nb][r] - m_use);
+          rs += s[nb][r];
+        }
+      rs = group_sum(rs);
+      l = l * alpha + rs;
+      m = m_new;
+#pragma unroll
+      for (int i = 0; i < DB; ++i) o[i] *= alpha;
+      const bf16x8 p0 = pack_frag(s[0], s[1]), p1 = pack_frag(s[2], s[3]);
+      tr_wait<DB>(v0lo, v0hi);
+      tr_issue<D, 1>(tj, v1lo, v1hi);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) o[db] = MFMA(join(v0lo[db], v0hi[db]), p0, o[db]);
+      tr_wait<DB>(v1lo, v1hi);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) o[db] = MFMA(join(v1lo[db], v1hi[db]), p1, o[db]);
+    }
+    if (qrow < q_len) {
+      const float inv = l > 0.f ? 1.f / l : 0.f;
+      bf16_t* op = a.o + (long)(q_off + qrow) * a.ldo + h * D + fg * 4;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) store4bf(op + db * 16, o[db], inv);
+      if (a.lse && fg == 0) a.lse[(long)(seq * a.H + h) * a.LTq + qrow] = (l > 0.f) ? m + __logf(l) : NEG_INF;
+    }
+  }
+}
+
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq_res_kernel(AttnArgs a) {
+  constexpr int KS = D / 32, DB = D / 16, TILE = 64 * D * 2;
+  __shared__ __attribute__((aligned(16))) char smem[163840];
+  char* lds_k = smem;
+  char* lds_v = smem + res_rows<D>() * D * 2;
+  const int seq = blockIdx.y, h = blockIdx.x;
+  const int* ds = a.desc + seq * 8;
+  const int q_off = ds[0], q_len = ds[1], kv_off = ds[2], kv_len = ds[3], coff = ds[5];
+  const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int kv_need = kv_len;
+  if (CAUSAL) kv_need = max(0, min(kv_len, q_len + coff));
+  const int rows = ((kv_need + 63) >> 6) << 6;
+  if (rows > 0) {
+    res_load<D>(lds_k, a.k + (long)kv_off * a.ldk + h * D, a.ldk, rows, kv_len, lane, wave);
+    res_load<D>(lds_v, a.v + (long)kv_off * a.ldv + h * D, a.ldv, rows, kv_len, lane, wave);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  TrAddr<D> tk;
+  tk.init(lds_k, lane);
+  const int G = (q_len + 15) >> 4;
+  for (int p = 0;; ++p) {
+    const int g = zigzag_group(p, wave, G, CAUSAL);
+    if (g < 0) break;
+    const int qrow = g * 16 + fr;
+    const int qrow_c = min(qrow, q_len - 1);
+    const bf16_t* qp = a.q + (long)(q_off + qrow_c) * a.ldq + h * D;
+    const bf16_t* dop = a.dout + (long)(q_off + qrow_c) * a.ld_do + h * D;
+    bf16x8 qf[KS], dof[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32 + fg * 8);
+      dof[ks] = *reinterpret_cast<const bf16x8*>(dop + ks * 32 + fg * 8);
+    }
+    const long stat = (long)(seq * a.H + h) * a.LTq + qrow_c;
+    const float lse_q = a.lse[stat], delta_q = a.delta[stat];
+    f32x4 dq[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int kv_end = kv_len;
+    if (CAUSAL) kv_end = max(0, min(kv_len, g * 16 + 16 + coff));
+    const int ntiles = (kv_end + 63) >> 6;
+    for (int j = 0; j < ntiles; ++j) {
+      const char* kt = lds_k + j * TILE;
+      const char* vt = lds_v + j * TILE;
+      f32x4 s[4], dp[4];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        s[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          s[nb] = MFMA(frag_rm<D>(kt, nb * 16 + fr, ks, fg), qf[ks], s[nb]);
+          dp[nb] = MFMA(frag_rm<D>(vt, nb * 16 + fr, ks, fg), dof[ks], dp[nb]);
+        }
+      }
+      TrAddr<D> tj;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) tj.base[db] = tk.base[db] + j * TILE;
+      bf16x4 k0lo[DB], k0hi[DB], k1lo[DB], k1hi[DB];
+      tr_issue<D, 0>(tj, k0lo, k0hi);
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = j * 64 + nb * 16 + fg * 4 + r;
+          const bool ok = key < kv_len && (!CAUSAL || key <= qrow + coff) && qrow < q_len;
+          const float pv = ok ? __expf(s[nb][r] * a.scale - lse_q) : 0.f;
+          s[nb][r] = ok ? pv * (dp[nb][r] - delta_q) * a.scale : 0.f;
+        }
+      const bf16x8 d0 = pack_frag(s[0], s[1]), d1 = pack_frag(s[2], s[3]);
+      tr_wait<DB>(k0lo, k0hi);
+      tr_issue<D, 1>(tj, k1lo, k1hi);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) dq[db] = MFMA(join(k0lo[db], k0hi[db]), d0, dq[db]);
+      tr_wait<DB>(k1lo, k1hi);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) dq[db] = MFMA(join(k1lo[db], k1hi[db]), d1, dq[db]);
+    }
+    if (qrow < q_len) {
+      bf16_t* pq = a.dq + (long)(q_off + qrow) * a.ld_dq + h * D + fg * 4;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) store4bf(pq + db * 16, dq[db], 1.f);
+    }
+  }
+}
+
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_res_kernel(AttnArgs a) {
+  constexpr int KS = D / 32, DB = D / 16, TILE = 64 * D * 2;
+  __shared__ __attribute__((aligned(16))) char smem[163840];
+  char* lds_q = smem;
+  char* lds_do = smem + res_rows<D>() * D * 2;
+  const int seq = blockIdx.y, h = blockIdx.x;
+  const int* ds = a.desc + seq * 8;
+  const int q_off = ds[0], q_len = ds[1], kv_off = ds[2], kv_len = ds[3], kv_rows = ds[4], coff = ds[5];
+  const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nq_tiles = (q_len + 63) >> 6;
+  res_load<D>(lds_q, a.q + (long)q_off * a.ldq + h * D, a.ldq, nq_tiles * 64, q_len, lane, wave);
+  res_load<D>(lds_do, a.dout + (long)q_off * a.ld_do + h * D, a.ld_do, nq_tiles * 64, q_len, lane, wave);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  TrAddr<D> tq, tdo;
+  tq.init(lds_q, lane);
+  tdo.init(lds_do, lane);
+  const float* lsebase = a.lse + (long)(seq * a.H + h) * a.LTq;
+  const float* deltabase = a.delta + (long)(seq * a.H + h) * a.LTq;
+  const int G = (kv_rows + 15) >> 4;
+  for (int p = 0;; ++p) {
+    const int g = zigzag_group(p, wave, G, !CAUSAL);  // causal: low key groups see the most query tiles
+    if (g < 0) break;
+    const int key = g * 16 + fr;
+    const int key_c = min(key, kv_rows - 1);
+    const bf16_t* kp = a.k + (long)(kv_off + key_c) * a.ldk + h * D;
+    const bf16_t* vp = a.v + (long)(kv_off + key_c) * a.ldv + h * D;
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      kf[ks] = *reinterpret_cast<const bf16x8*>(kp + ks * 32 + fg * 8);
+      vf[ks] = *reinterpret_cast<const bf16x8*>(vp + ks * 32 + fg * 8);
+    }
+    f32x4 dk[DB], dv[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i) { dk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    int i0 = 0;
+    if (CAUSAL) i0 = max(0, (g * 16 - coff) >> 6);
+    for (int i = i0; i < nq_tiles; ++i) {
+      const char* qt = lds_q + i * TILE;
+      const char* dot = lds_do + i * TILE;
+      f32x4 s[4], dp[4];
+#pragma unroll
+      for (int qb = 0; qb < 4; ++qb) {
+        s[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          s[qb] = MFMA(frag_rm<D>(qt, qb * 16 + fr, ks, fg), kf[ks], s[qb]);
+          dp[qb] = MFMA(frag_rm<D>(dot, qb * 16 + fr, ks, fg), vf[ks], dp[qb]);
+        }
+      }
+      TrAddr<D> tqi, tdi;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) { tqi.base[db] = tq.base[db] + i * TILE; tdi.base[db] = tdo.base[db] + i * TILE; }
+      bf16x4 alo[DB], ahi[DB], blo[DB], bhi[DB];
+      tr_issue<D, 0>(tdi, alo, ahi);
+#pragma unroll
+      for (int qb = 0; qb < 4; ++qb) {
+        const f32x4 lq = *reinterpret_cast<const f32x4*>(lsebase + i * 64 + qb * 16 + fg * 4);
+        const f32x4 dl = *reinterpret_cast<const f32x4*>(deltabase + i * 64 + qb * 16 + fg * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = i * 64 + qb * 16 + fg * 4 + r;
+          const bool ok = q < q_len && key < kv_len && (!CAUSAL || key <= q + coff);
+          const float pv = ok ? __expf(s[qb][r] * a.scale - lq[r]) : 0.f;
+          dp[qb][r] = ok ? pv * (dp[qb][r] - dl[r]) * a.scale : 0.f;
+          s[qb][r] = pv;
+        }
+      }
+      const bf16x8 p0 = pack_frag(s[0], s[1]), p1 = pack_frag(s[2], s[3]);
+      const bf16x8 d0 = pack_frag(dp[0], dp[1]), d1 = pack_frag(dp[2], dp[3]);
+      tr_wait<DB>(alo, ahi);
+      tr_issue<D, 0>(tqi, blo, bhi);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) dv[db] = MFMA(join(alo[db], ahi[db]), p0, dv[db]);
+      tr_wait<DB>(blo, bhi);
+      tr_issue<D, 1>(tdi, alo, ahi);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) dk[db] = MFMA(join(blo[db], bhi[db]), d0, dk[db]);
+      tr_wait<DB>(alo, ahi);
+      tr_issue<D, 1>(tqi, blo, bhi);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) dv[db] = MFMA(join(alo[db], ahi[db]), p1, dv[db]);
+      tr_wait<DB>(blo, bhi);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) dk[db] = MFMA(join(blo[db], bhi[db]), d1, dk[db]);
+    }
+    if (key < kv_rows) {
+      bf16_t* pk = a.dk + (long)(kv_off + key) * a.ld_dk + h * D + fg * 4;
+      bf16_t* pv = a.dv + (long)(kv_off + key) * a.ld_dv + h * D + fg * 4;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) { store4bf(pk + db * 16, dk[db], 1.f); store4bf(pv + db * 16, dv[db], 1.f); }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- delta = rowsum(dO * O)
 template <int D>
 __global__ void attn_delta_kernel(const bf16_t* __restrict__ o, long ldo, const bf16_t* __restrict__ dout, long ld_do,
@@ -499,14 +819,26 @@ extern "C" int lhrs_seq_transpose(const void* in, long ld_in, void* out, int col
 }
 
 extern "C" int lhrs_attn_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
-                             float* lse, const int* desc, int nseq, int H, int D, int max_q, int LTq, int causal,
-                             float scale, void* stream) {
+                             float* lse, const int* desc, int nseq, int H, int D, int max_q, int max_kv, int LTq,
+                             int causal, float scale, void* stream) {
   AttnArgs a; memset(&a, 0, sizeof(a));
   a.q = (const bf16_t*)q; a.ldq = ldq; a.k = (const bf16_t*)k; a.ldk = ldk; a.v = (const bf16_t*)v; a.ldv = ldv;
   a.o = (bf16_t*)o; a.ldo = ldo; a.lse = lse; a.desc = desc; a.H = H; a.LTq = LTq; a.scale = scale;
   if (check_common(a, D, nseq, "attn_fwd")) return -1;
   const dim3 grid(cdiv(max_q, 64), H, nseq), blk(256);
   hipStream_t s = (hipStream_t)stream;
+  if (max_kv > 0 && max_kv <= (D == 128 ? res_rows<128>() : res_rows<64>())) {  // both operands fit one CU's LDS
+    const dim3 rg(H, nseq), rb(512);
+    if (D == 128) {
+      if (causal) hipLaunchKernelGGL((attn_fwd_res_kernel<128, true>), rg, rb, 0, s, a);
+      else hipLaunchKernelGGL((attn_fwd_res_kernel<128, false>), rg, rb, 0, s, a);
+    } else {
+      if (causal) hipLaunchKernelGGL((attn_fwd_res_kernel<64, true>), rg, rb, 0, s, a);
+      else hipLaunchKernelGGL((attn_fwd_res_kernel<64, false>), rg, rb, 0, s, a);
+    }
+    LHRS_CHECK_LAUNCH("attn_fwd_res");
+    return 0;
+  }
   if (D == 128) {
     if (causal) hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, blk, 0, s, a);
     else hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, blk, 0, s, a);
@@ -545,23 +877,28 @@ extern "C" int lhrs_attn_bwd(const void* q, long ldq, const void* k, long ldk, c
   if (check_common(a, D, nseq, "attn_bwd")) return -1;
   hipStream_t s = (hipStream_t)stream;
   const dim3 gq(cdiv(max_q, 64), H, nseq), gk(cdiv(max_kv, 64), H, nseq), blk(256);
-  if (D == 128) {
-    if (causal) {
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<128, true>), gq, blk, 0, s, a);
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, true>), gk, blk, 0, s, a);
-    } else {
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<128, false>), gq, blk, 0, s, a);
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, false>), gk, blk, 0, s, a);
-    }
-  } else {
-    if (causal) {
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<64, true>), gq, blk, 0, s, a);
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, true>), gk, blk, 0, s, a);
-    } else {
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<64, false>), gq, blk, 0, s, a);
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, false>), gk, blk, 0, s, a);
-    }
+  const int rmax = D == 128 ? res_rows<128>() : res_rows<64>();
+  const dim3 rg(H, nseq), rb(512);
+  bool dq_done = false, dkv_done = false;
+  if (max_kv <= rmax) {
+    if (D == 128) { if (causal) hipLaunchKernelGGL((attn_bwd_dq_res_kernel<128, true>), rg, rb, 0, s, a); else hipLaunchKernelGGL((attn_bwd_dq_res_kernel<128, false>), rg, rb, 0, s, a); }
+    else { if (causal) hipLaunchKernelGGL((attn_bwd_dq_res_kernel<64, true>), rg, rb, 0, s, a); else hipLaunchKernelGGL((attn_bwd_dq_res_kernel<64, false>), rg, rb, 0, s, a); }
+    dq_done = true;
   }
+  if (max_q <= rmax) {
+    if (D == 128) { if (causal) hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<128, true>), rg, rb, 0, s, a); else hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<128, false>), rg, rb, 0, s, a); }
+    else { if (causal) hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<64, true>), rg, rb, 0, s, a); else hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<64, false>), rg, rb, 0, s, a); }
+    dkv_done = true;
+  }
+  if (dq_done && dkv_done) { LHRS_CHECK_LAUNCH("attn_bwd_res"); return 0; }
+#define LAUNCH_TILED(KERN, GRID)                                                                 \
+  do {                                                                                           \
+    if (D == 128) { if (causal) hipLaunchKernelGGL((KERN<128, true>), GRID, blk, 0, s, a); else hipLaunchKernelGGL((KERN<128, false>), GRID, blk, 0, s, a); } \
+    else { if (causal) hipLaunchKernelGGL((KERN<64, true>), GRID, blk, 0, s, a); else hipLaunchKernelGGL((KERN<64, false>), GRID, blk, 0, s, a); }          \
+  } while (0)
+  if (!dq_done) LAUNCH_TILED(attn_bwd_dq_kernel, gq);
+  if (!dkv_done) LAUNCH_TILED(attn_bwd_dkv_kernel, gk);
+#undef LAUNCH_TILED
   LHRS_CHECK_LAUNCH("attn_bwd");
   return 0;
 }

@@ -19,6 +19,7 @@
 //   * block id -> tile map is XCD-aware (block b runs on XCD b%8; each XCD gets a contiguous run of tiles,
 //     rastered in groups of 8 tile-rows) so neighbouring tiles share A/B panels in one XCD's L2.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -349,7 +350,7 @@ __device__ __forceinline__ void lds_wait6(bf16x8 (&a)[4], bf16x8 (&b)[2]) {
 
 #define LDS_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 
-template <int ACT, bool ILV>
+template <int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_nt_256p_kernel(GemmArgs g) {
   constexpr int BM = 256, BN = 256, BK = 32, NS = 4;
   constexpr int A_BYTES = BM * BK * 2, STAGE = A_BYTES + BN * BK * 2;
@@ -378,11 +379,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256p_kernel(GemmArgs g) {
       dst_off[j] = A_BYTES + (idx - 16) * 1024;
     }
   }
-  auto issue = [&](int kt) {
-    char* base = smem + (kt & (NS - 1)) * STAGE;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + (long)kt * BK), (lptr_t)(base + dst_off[j]), 16, 0, 0);
+  auto issue1 = [&](int kt, int j) {
+    __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + (long)kt * BK), (lptr_t)(smem + (kt & (NS - 1)) * STAGE + dst_off[j]), 16, 0, 0);
   };
 
   const int wm = wave >> 2, wn = wave & 3;
@@ -402,84 +400,136 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256p_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   bf16x8 a0[4], b0[2], a1[4], b1[2];  // set0 = k-step 0 fragments, set1 = k-step 1 fragments
-#define MFMA8(A_, B_)                                                                                   \
-  _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)     \
-      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B_[ni], A_[mi], acc[mi][ni], 0, 0, 0);      \
-  __builtin_amdgcn_sched_barrier(0);
+#define MF(A_, B_, mi, ni) \
+  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B_[ni], A_[mi], acc[mi][ni], 0, 0, 0); __builtin_amdgcn_sched_barrier(0);
+#define MFMA8(A_, B_) \
+  MF(A_, B_, 0, 0) MF(A_, B_, 0, 1) MF(A_, B_, 1, 0) MF(A_, B_, 1, 1) MF(A_, B_, 2, 0) MF(A_, B_, 2, 1) MF(A_, B_, 3, 0) MF(A_, B_, 3, 1)
 
-  const int nk = g.K / BK;  // >= 2 (host guarantees)
-  issue(0);
-  issue(1);
+  const int nk = g.K / BK;  // >= 3 (host guarantees)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) issue1(0, j);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) issue1(1, j);
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  if (2 < nk) issue(2);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) issue1(2, j);
   lds_read6(a0, b0, a_base + koff0, b_base + koff0);
   lds_read6(a1, b1, a_base + koff1, b_base + koff1);
   asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(b0[0]), "+v"(b0[1]), "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]));
   __builtin_amdgcn_sched_barrier(0);
   MFMA8(a0, b0)
-  auto issue1 = [&](int kt, int j) {
-    __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + (long)kt * BK), (lptr_t)(smem + (kt & (NS - 1)) * STAGE + dst_off[j]), 16, 0, 0);
-  };
-#define MF(A_, B_, mi, ni) \
-  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B_[ni], A_[mi], acc[mi][ni], 0, 0, 0); __builtin_amdgcn_sched_barrier(0);
-  for (int kt = 0; kt < nk - 1; ++kt) {
-    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+
+  // One iteration = [publish stage kt+1] + 16 MFMAs (k1 of stage kt, k0 of stage kt+1); behind every MFMA sits one filler:
+  // a ds_read of the next k-step's fragments or one DMA piece of stage kt+3.
+  auto body = [&](auto dma_c, auto vm4_c, int kt) {
+    constexpr bool DMA = decltype(dma_c)::value, VM4 = decltype(vm4_c)::value;
+    if constexpr (VM4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const unsigned so = ((kt + 1) & (NS - 1)) * STAGE;
-    if (!ILV) {
-      if (kt + 3 < nk) issue(kt + 3);
-      lds_wait6(a1, b1);                                          // k1(kt) landed (issued one MFMA block ago)
-      lds_read6(a0, b0, a_base + so + koff0, b_base + so + koff0);  // k0(kt+1)
-      __builtin_amdgcn_sched_barrier(0);
-      MFMA8(a1, b1)
-      lds_wait6(a0, b0);
-      lds_read6(a1, b1, a_base + so + koff1, b_base + so + koff1);  // k1(kt+1)
-      __builtin_amdgcn_sched_barrier(0);
-      MFMA8(a0, b0)
-    } else {
-      // one filler (ds_read of the next k-step, or one DMA piece of stage kt+3) behind every MFMA
-      const bool dma = kt + 3 < nk;
-      const unsigned aa0 = a_base + so + koff0, ba0 = b_base + so + koff0;
-      const unsigned aa1 = a_base + so + koff1, ba1 = b_base + so + koff1;
-      lds_wait6(a1, b1);
-      MF(a1, b1, 0, 0) LDS_RD(b0[0], ba0, 0);    __builtin_amdgcn_sched_barrier(0);
-      MF(a1, b1, 0, 1) LDS_RD(b0[1], ba0, 2048); __builtin_amdgcn_sched_barrier(0);
-      MF(a1, b1, 1, 0) LDS_RD(a0[0], aa0, 0);    __builtin_amdgcn_sched_barrier(0);
-      MF(a1, b1, 1, 1) LDS_RD(a0[1], aa0, 2048); __builtin_amdgcn_sched_barrier(0);
-      MF(a1, b1, 2, 0) LDS_RD(a0[2], aa0, 4096); __builtin_amdgcn_sched_barrier(0);
-      MF(a1, b1, 2, 1) LDS_RD(a0[3], aa0, 6144); __builtin_amdgcn_sched_barrier(0);
-      MF(a1, b1, 3, 0) if (dma) issue1(kt + 3, 0); __builtin_amdgcn_sched_barrier(0);
-      MF(a1, b1, 3, 1) if (dma) issue1(kt + 3, 1); __builtin_amdgcn_sched_barrier(0);
-      lds_wait6(a0, b0);
-      MF(a0, b0, 0, 0) LDS_RD(b1[0], ba1, 0);    __builtin_amdgcn_sched_barrier(0);
-      MF(a0, b0, 0, 1) LDS_RD(b1[1], ba1, 2048); __builtin_amdgcn_sched_barrier(0);
-      MF(a0, b0, 1, 0) LDS_RD(a1[0], aa1, 0);    __builtin_amdgcn_sched_barrier(0);
-      MF(a0, b0, 1, 1) LDS_RD(a1[1], aa1, 2048); __builtin_amdgcn_sched_barrier(0);
-      MF(a0, b0, 2, 0) LDS_RD(a1[2], aa1, 4096); __builtin_amdgcn_sched_barrier(0);
-      MF(a0, b0, 2, 1) LDS_RD(a1[3], aa1, 6144); __builtin_amdgcn_sched_barrier(0);
-      MF(a0, b0, 3, 0) if (dma) issue1(kt + 3, 2); __builtin_amdgcn_sched_barrier(0);
-      MF(a0, b0, 3, 1) if (dma) issue1(kt + 3, 3); __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-#undef MF
+    const unsigned aa0 = a_base + so + koff0, ba0 = b_base + so + koff0;
+    const unsigned aa1 = a_base + so + koff1, ba1 = b_base + so + koff1;
+    lds_wait6(a1, b1);
+    MF(a1, b1, 0, 0) LDS_RD(b0[0], ba0, 0);    __builtin_amdgcn_sched_barrier(0);
+    MF(a1, b1, 0, 1) LDS_RD(b0[1], ba0, 2048); __builtin_amdgcn_sched_barrier(0);
+    MF(a1, b1, 1, 0) LDS_RD(a0[0], aa0, 0);    __builtin_amdgcn_sched_barrier(0);
+    MF(a1, b1, 1, 1) LDS_RD(a0[1], aa0, 2048); __builtin_amdgcn_sched_barrier(0);
+    MF(a1, b1, 2, 0) LDS_RD(a0[2], aa0, 4096); __builtin_amdgcn_sched_barrier(0);
+    MF(a1, b1, 2, 1) LDS_RD(a0[3], aa0, 6144); __builtin_amdgcn_sched_barrier(0);
+    MF(a1, b1, 3, 0) if constexpr (DMA) issue1(kt + 3, 0); __builtin_amdgcn_sched_barrier(0);
+    MF(a1, b1, 3, 1) if constexpr (DMA) issue1(kt + 3, 1); __builtin_amdgcn_sched_barrier(0);
+    lds_wait6(a0, b0);
+    MF(a0, b0, 0, 0) LDS_RD(b1[0], ba1, 0);    __builtin_amdgcn_sched_barrier(0);
+    MF(a0, b0, 0, 1) LDS_RD(b1[1], ba1, 2048); __builtin_amdgcn_sched_barrier(0);
+    MF(a0, b0, 1, 0) LDS_RD(a1[0], aa1, 0);    __builtin_amdgcn_sched_barrier(0);
+    MF(a0, b0, 1, 1) LDS_RD(a1[1], aa1, 2048); __builtin_amdgcn_sched_barrier(0);
+    MF(a0, b0, 2, 0) LDS_RD(a1[2], aa1, 4096); __builtin_amdgcn_sched_barrier(0);
+    MF(a0, b0, 2, 1) LDS_RD(a1[3], aa1, 6144); __builtin_amdgcn_sched_barrier(0);
+    MF(a0, b0, 3, 0) if constexpr (DMA) issue1(kt + 3, 2); __builtin_amdgcn_sched_barrier(0);
+    MF(a0, b0, 3, 1) if constexpr (DMA) issue1(kt + 3, 3); __builtin_amdgcn_sched_barrier(0);
+  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+  for (int kt = 0; kt < nk - 3; ++kt) body(T_{}, T_{}, kt);   // steady state: DMA two stages ahead, vmcnt never 0
+  body(F_{}, T_{}, nk - 3);                                   // stage nk-1 is already in flight
+  body(F_{}, F_{}, nk - 2);
   lds_wait6(a1, b1);
   MFMA8(a1, b1)
 #undef MFMA8
+#undef MF
 
+  if (g.out_f32) {
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int m = tm * BM + wm * 128 + mi * 32 + fr;
-    if (m >= g.M) continue;
+    for (int mi = 0; mi < 4; ++mi) {
+      const int m = tm * BM + wm * 128 + mi * 32 + fr;
+      if (m >= g.M) continue;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4;
+          if (n >= g.N) continue;
+          store4<ACT>(g, m, n, f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]});
+        }
+    }
+    return;
+  }
+  // ---- bf16 epilogue through LDS: each wave transposes its own 128 x 64 sub-tile in a private 16 KiB region of the
+  // (now idle) ring so that global stores are 16 B per lane, 128 contiguous bytes per row (full cache lines).
+  //   stage value = bf16(act(alpha*acc + bias));  final = bf16(stage + residual)  (the reference's rounding order)
+  __builtin_amdgcn_s_barrier();  // every wave is done reading the last stages
+  char* reg = smem + wave * 16384;
+  {
+    float bias_v[2][4][4];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n = tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4;
-        if (n >= g.N) continue;
-        store4<ACT>(g, m, n, f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]});
+        const int n = min(tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4, g.N - 4);
+        uint2 bb = make_uint2(0, 0);
+        if (g.bias) bb = *reinterpret_cast<const uint2*>(g.bias + n);
+        bias_v[ni][q][0] = bflo(bb.x); bias_v[ni][q][1] = bfhi(bb.x); bias_v[ni][q][2] = bflo(bb.y); bias_v[ni][q][3] = bfhi(bb.y);
       }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int row = mi * 32 + fr;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[i] = acc[mi][ni][4 * q + i] * g.alpha + bias_v[ni][q][i];
+            if (ACT) v[i] = apply_act(v[i], ACT);
+          }
+          const int u = ni * 8 + q * 2 + fh;  // 8-byte unit inside the 128-B row
+          *reinterpret_cast<uint2*>(reg + row * 128 + ((u ^ ((row & 7) << 1)) << 3)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        }
+    }
+  }
+  // a wave reads back only what it wrote itself: its own LDS writes are visible to it once lgkmcnt drains
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  {
+    const int rsub = lane >> 3, c = lane & 7;
+    const int n = tn * BN + wn * 64 + c * 8;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = i * 8 + rsub;
+      const int m = tm * BM + wm * 128 + row;
+      uint4 val = *reinterpret_cast<const uint4*>(reg + row * 128 + ((c ^ (row & 7)) << 4));
+      if (m < g.M && n < g.N) {
+        if (g.res) {
+          const uint4 r = *reinterpret_cast<const uint4*>(g.res + (long)m * g.ldr + n);
+          val.x = pack2bf(bflo(val.x) + bflo(r.x), bfhi(val.x) + bfhi(r.x));
+          val.y = pack2bf(bflo(val.y) + bflo(r.y), bfhi(val.y) + bfhi(r.y));
+          val.z = pack2bf(bflo(val.z) + bflo(r.z), bfhi(val.z) + bfhi(r.z));
+          val.w = pack2bf(bflo(val.w) + bflo(r.w), bfhi(val.w) + bfhi(r.w));
+        }
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n) = val;
+      }
+    }
   }
 }
 
@@ -530,8 +580,8 @@ extern "C" int lhrs_gemm_profile_read(double* out) {
   return 0;
 }
 
-static int g_gemm_allow_256 = 3;
-// tile policy switch for A/B measurements: 0 = never use a 256x256 kernel, 1 = simple ring kernel, 2 = pipelined
+static int g_gemm_allow_256 = 2;
+// tile policy switch for A/B measurements: 0 = never use a 256x256 kernel, 1 = simple ring kernel, 2 = pipelined (default)
 extern "C" int lhrs_gemm_set_policy(int allow_256) { g_gemm_allow_256 = allow_256; return 0; }
 
 // C ABI ------------------------------------------------------------------------------------------
@@ -567,7 +617,8 @@ extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
     }                                                                                                  \
   } while (0)
   const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
-  const bool use256 = g_gemm_allow_256 && t256 >= 160 && K >= 96 && K % 32 == 0;  // ring prologue needs >= 3 stages
+  const bool al16 = out_f32 || (N % 8 == 0 && ldc % 8 == 0 && (residual == nullptr || ldr % 8 == 0));  // 16-B epilogue rows
+  const bool use256 = g_gemm_allow_256 && t256 >= 160 && K >= 96 && K % 32 == 0 && al16;  // ring prologue needs >= 3 stages
   LHRS_REQUIRE(use256 || K % 64 == 0, "gemm: K=%d must be a multiple of 64 for this problem size (zero-pad the reduction dim)", K);
   const bool big = t128 >= 384;
   int slot = -1;
@@ -582,14 +633,7 @@ extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
   if (use256) {
     g.tilesM = cdiv(M, 256); g.tilesN = cdiv(N, 256);
     const dim3 grid(g.tilesM * g.tilesN), blk(512);
-    if (g_gemm_allow_256 == 3) {
-      switch (act) {
-        case 0: hipLaunchKernelGGL((gemm_nt_256p_kernel<0, true>), grid, blk, 0, s, g); break;
-        case 1: hipLaunchKernelGGL((gemm_nt_256p_kernel<1, true>), grid, blk, 0, s, g); break;
-        case 2: hipLaunchKernelGGL((gemm_nt_256p_kernel<2, true>), grid, blk, 0, s, g); break;
-        default: hipLaunchKernelGGL((gemm_nt_256p_kernel<3, true>), grid, blk, 0, s, g); break;
-      }
-    } else if (g_gemm_allow_256 == 1) {
+    if (g_gemm_allow_256 == 1) {
       switch (act) {
         case 0: hipLaunchKernelGGL((gemm_nt_256_kernel<0>), grid, blk, 0, s, g); break;
         case 1: hipLaunchKernelGGL((gemm_nt_256_kernel<1>), grid, blk, 0, s, g); break;
@@ -598,10 +642,10 @@ extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
       }
     } else {
       switch (act) {
-        case 0: hipLaunchKernelGGL((gemm_nt_256p_kernel<0, false>), grid, blk, 0, s, g); break;
-        case 1: hipLaunchKernelGGL((gemm_nt_256p_kernel<1, false>), grid, blk, 0, s, g); break;
-        case 2: hipLaunchKernelGGL((gemm_nt_256p_kernel<2, false>), grid, blk, 0, s, g); break;
-        default: hipLaunchKernelGGL((gemm_nt_256p_kernel<3, false>), grid, blk, 0, s, g); break;
+        case 0: hipLaunchKernelGGL((gemm_nt_256p_kernel<0>), grid, blk, 0, s, g); break;
+        case 1: hipLaunchKernelGGL((gemm_nt_256p_kernel<1>), grid, blk, 0, s, g); break;
+        case 2: hipLaunchKernelGGL((gemm_nt_256p_kernel<2>), grid, blk, 0, s, g); break;
+        default: hipLaunchKernelGGL((gemm_nt_256p_kernel<3>), grid, blk, 0, s, g); break;
       }
     }
   } else if (big) LAUNCH_TILE(4, 4);

@@ -127,9 +127,10 @@ def seq_transpose(x, cols, LT, desc, nseq, which: str):
     return out
 
 
-def attn_fwd(q, k, v, o, lse, desc, nseq, H, D, max_q, LTq, causal, scale):
+def attn_fwd(q, k, v, o, lse, desc, nseq, H, D, max_q, max_kv, LTq, causal, scale):
     st = _L().lhrs_attn_fwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), o.data_ptr(),
-                            o.stride(0), _p(lse), desc.data_ptr(), nseq, H, D, max_q, LTq, int(causal), float(scale), _stream())
+                            o.stride(0), _p(lse), desc.data_ptr(), nseq, H, D, max_q, max_kv, LTq, int(causal), float(scale),
+                            _stream())
     _lib.check(st, "attn_fwd")
 
 

@@ -166,7 +166,7 @@ class AttnPooler:
             kvp = hk.gemm_nt(kvn, Win[d:], bias=bin_[d:])                      # [B*912, 2d] = K | V
             o = torch.empty((M, d), device=self.device, dtype=torch.bfloat16)
             lse = torch.empty((nseq, H, LTq), device=self.device, dtype=torch.float32)
-            hk.attn_fwd(q, kvp[:, :d], kvp[:, d:], o, lse, desc, nseq, H, d // H, max(STAGE_NUM), LTq, False, scale)
+            hk.attn_fwd(q, kvp[:, :d], kvp[:, d:], o, lse, desc, nseq, H, d // H, max(STAGE_NUM), LTkv, LTq, False, scale)
             t1 = hk.gemm_nt(o, w[b + "attn.out_proj.weight"], bias=w[b + "attn.out_proj.bias"], residual=t)
             t1n, t1_mean, t1_rstd = hk.layernorm_fwd(t1, w[b + "ln_2.weight"], w[b + "ln_2.bias"], save_stats=True)
             hpre = hk.gemm_nt(t1n, w[b + "mlp.c_fc.weight"], bias=w[b + "mlp.c_fc.bias"])

@@ -114,7 +114,7 @@ class TextModal:
         hk.rope_(qkv, M, 2 * H, hd, self.cos, self.sin, pos_mod=S)
         o = torch.empty((M, d), device=self.device, dtype=torch.bfloat16)
         lse = torch.empty((B, H, LT), device=self.device, dtype=torch.float32)
-        hk.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, desc, B, H, hd, S, LT, True, 1.0 / math.sqrt(hd))
+        hk.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, desc, B, H, hd, S, S, LT, True, 1.0 / math.sqrt(hd))
         x_mid = hk.gemm_nt(o, L["o_w"], residual=x)
         h = hk.rmsnorm_fwd(x_mid, L["ln2_w"], self.eps, out=h)
         gu = hk.gemm_nt(h, L["gu_w"])

@@ -78,7 +78,7 @@ class VisionModal:
         for li, L in enumerate(p["layers"]):
             h = hk.layernorm_fwd(x, L["ln1_w"], L["ln1_b"])
             qkv = hk.gemm_nt(h, L["qkv_w"], bias=L["qkv_b"])
-            hk.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, None, desc, B, H, d // H, n, LT, False, scale)
+            hk.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, None, desc, B, H, d // H, n, n, LT, False, scale)
             x = hk.gemm_nt(o, L["o_w"], bias=L["o_b"], residual=x, out=x)
             h = hk.layernorm_fwd(x, L["ln2_w"], L["ln2_b"], out=h)
             f = hk.gemm_nt(h, L["fc1_w"], bias=L["fc1_b"], act=hk.ACT_QUICK_GELU)

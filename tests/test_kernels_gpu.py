@@ -25,7 +25,7 @@ def bf(x):
 # ------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 1024, 1024), (2184, 4096, 4096), (1000, 12288, 4096),
                                    (273, 4096, 11008), (64, 64, 64), (33, 132, 128), (1152, 1024, 4096),
-                                   (4095, 4096, 128), (3000, 4100, 96), (8190, 4096, 4096), (2184, 22016, 4096),
+                                   (4095, 4096, 128), (3000, 4104, 96), (8190, 4096, 4096), (2184, 22016, 4096),
                                    (4095, 4096, 22016)])
 def test_gemm_plain(M, N, K):
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
@@ -197,7 +197,7 @@ def run_attention_case(D, H, seqs, causal, same_qkv_buffer):
         assert torch.equal(vT[i, :, :kvl], v[koff:koff + kvl].t()) and torch.all(vT[i, :, kvl:] == 0)
     o = torch.zeros(tq, H * D, device=DEV, dtype=torch.bfloat16)
     lse = torch.zeros(nseq, H, LTq, device=DEV, dtype=torch.float32)
-    hk.attn_fwd(q, k, v, o, lse, desc, nseq, H, D, max_q, LTq, causal, scale)
+    hk.attn_fwd(q, k, v, o, lse, desc, nseq, H, D, max_q, max_kv, LTq, causal, scale)
     # backward
     delta = torch.zeros(nseq, H, LTq, device=DEV, dtype=torch.float32)
     hk.attn_delta(o, do, delta, desc, nseq, H, D, max_q, LTq)
@@ -234,6 +234,11 @@ def test_attention_pooler_groups():
 
 def test_attention_llama_causal():
     run_attention_case(128, 32, [(273, 273, 273), (273, 273, 250)], causal=True, same_qkv_buffer=False)
+
+
+def test_attention_long_sequences_use_tiled_kernels():
+    run_attention_case(128, 2, [(700, 700, 650), (330, 330, 330)], causal=True, same_qkv_buffer=False)
+    run_attention_case(64, 4, [(100, 900, 900)], causal=False, same_qkv_buffer=False)
 
 
 def test_attention_small_ragged():
