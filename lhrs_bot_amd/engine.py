@@ -198,6 +198,36 @@ class LHRSEngine:
         pool.refresh_transposed()
         self.optimizer._global_grad_norm = self.gnorm_sq  # device scalar (squared, un-averaged); see grad_norm()
 
+    # ------------------------------------------------------------------ checkpoint (engine.save/load_checkpoint surface)
+    def state_dict(self) -> Dict:
+        sd = dict(global_steps=self.global_steps, opt=self.opt_name, master=self.pool.master.cpu(), exp_avg=self.exp_avg.cpu(),
+                  exp_avg_sq=self.exp_avg_sq.cpu(), param_groups=[dict(g) for g in self.optimizer.param_groups])
+        if self.opt_name.startswith("adan"):
+            sd.update(exp_avg_diff=self.exp_avg_diff.cpu(), pre_grad=self.pre_grad.cpu())
+        return sd
+
+    def load_state_dict(self, sd: Dict) -> None:
+        assert sd["opt"] == self.opt_name, f"checkpoint optimizer {sd['opt']} != {self.opt_name}"
+        self.global_steps = int(sd["global_steps"])
+        self.pool.master.copy_(sd["master"])
+        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        if self.opt_name.startswith("adan"):
+            self.exp_avg_diff.copy_(sd["exp_avg_diff"]); self.pre_grad.copy_(sd["pre_grad"])
+        for g, s in zip(self.optimizer.param_groups, sd["param_groups"]):
+            g.update(s)
+        self.pool.sync_shadow()
+
+    def save_checkpoint(self, save_dir: str, tag: str, client_state: Optional[Dict] = None) -> None:
+        import os
+        os.makedirs(os.path.join(save_dir, tag), exist_ok=True)
+        torch.save(dict(engine=self.state_dict(), client_state=client_state or {}), os.path.join(save_dir, tag, "engine.pt"))
+
+    def load_checkpoint(self, path: str):
+        import os
+        st = torch.load(os.path.join(path, "engine.pt") if os.path.isdir(path) else path, map_location="cpu")
+        self.load_state_dict(st["engine"])
+        return path, st.get("client_state", {})
+
     def grad_norm(self) -> float:
         """Host read of the global gradient norm of the last step (synchronises; for logging only)."""
         return float(self.gnorm_sq.sqrt().item()) / self.world

@@ -2,6 +2,7 @@
 exactly as EpochBasedTrainer.get_specific_hooks builds it (EpochBasedTrainer.py:71-80) with the stage-1 YAML values, and
 store lr(it).  Build-container only; the committed lr_schedule.npz is what the tests read."""
 import importlib
+import importlib.util
 import os
 import sys
 import types
@@ -52,3 +53,23 @@ for max_iters in (1000, 20000):
 np.savez(os.path.join(HERE, "lr_schedule.npz"), base_lr=np.array(cfg["lr"]), min_lr=np.array(sch["min_lr"]),
          warmup_iters=np.array(sch["warmup_epochs"]), warmup_ratio=np.array(sch["warmup_factor"]), **out)
 print("lr golden:", out["lrs_1000"][:3], out["lrs_1000"][-2:])
+
+# ---- config-parser golden: the reference's own ConfigArgumentParser on the shipped stage-1 YAML + a CLI overlay
+spec = importlib.util.spec_from_file_location("ref_config_parser", f"{REF}/lhrs/CustomTrainer/utils/config_parser.py")
+cp = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(cp)
+import json
+
+def build(parser_cls):
+    p = parser_cls()
+    p.add_argument("--batch-size", type=int, default=8)
+    p.add_argument("--lr", type=float, default=None)
+    p.add_argument("--output", type=str, default="out")
+    return p
+
+argv = ["-c", f"{REF}/Config/multi_modal_stage1.yaml", "--batch-size", "4", "--output", "xyz"]
+cli_wins = build(cp.ConfigArgumentParser).parse_args(wandb=True, args=argv)
+yaml_wins = build(cp.ConfigArgumentParser).parse_args(wandb=False, args=argv)
+json.dump({"yaml": yaml.safe_load(open(f"{REF}/Config/multi_modal_stage1.yaml")), "argv_tail": argv[2:], "cli_wins": cli_wins,
+           "yaml_wins": yaml_wins}, open(os.path.join(HERE, "config_parser.json"), "w"), indent=1, default=str)
+print("config golden keys:", len(cli_wins), cli_wins["batch_size"], cli_wins["lr"], yaml_wins["lr"])

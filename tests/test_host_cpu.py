@@ -108,3 +108,26 @@ def test_grad_reducer_world2_gloo(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+def test_config_parser_matches_reference_parser(tmp_path):
+    import json
+
+    import yaml
+
+    from lhrs_bot_amd.trainer import ConfigArgumentParser
+
+    z = json.load(open(os.path.join(G, "config_parser.json")))
+    cfg = tmp_path / "stage1.yaml"
+    cfg.write_text(yaml.safe_dump(z["yaml"]))
+
+    def build():
+        p = ConfigArgumentParser()
+        p.add_argument("--batch-size", type=int, default=8)
+        p.add_argument("--lr", type=float, default=None)
+        p.add_argument("--output", type=str, default="out")
+        return p
+
+    argv = ["-c", str(cfg)] + z["argv_tail"]
+    assert build().parse_args(wandb=True, args=argv) == z["cli_wins"]     # CLI (even its defaults) overrides the YAML
+    assert build().parse_args(wandb=False, args=argv) == z["yaml_wins"]   # YAML overrides the CLI
