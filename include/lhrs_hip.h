@@ -111,6 +111,8 @@ int lhrs_splice_fwd(const long* ids, const long* labels, const uint8_t* mask, co
 int lhrs_splice_bwd(const void* d_embeds, const int* img_pos, void* d_image, int B, int NI, int dim, int S, void* stream);
 int lhrs_gather_rows(const void* src, long ld_src, const int* idx, void* dst, long ld_dst, int n, int dim, void* stream);
 int lhrs_scatter_rows(const void* src, long ld_src, const int* idx, void* dst, long ld_dst, int n, int dim, void* stream);
+/* greedy decoding pick (HF GenerationMixin argmax, do_sample=False: main_vqa.py:205-214, cli_qa.py:176-186) */
+int lhrs_argmax_rows(const float* x, long ld, long* out, int n, int V, void* stream);
 int lhrs_cross_entropy(const void* logits, long ld, const int* target, float* row_loss, float* loss_out, void* dlogits,
                        long ld_d, int n, int V, void* stream);
 

@@ -142,7 +142,40 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__
   if (threadIdx.x == 0) *out = s * scale;
 }
 
+// greedy pick: index of the first maximum of each fp32 row (HF argmax tie rule: lowest index)
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, long ld, long* __restrict__ out, int V) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const float* row = x + (long)blockIdx.x * ld;
+  float best = -__builtin_huge_valf();
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < V; i += 256) {
+    const float v = row[i];
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+    out[blockIdx.x] = bi;
+  }
+}
+
 }  // namespace
+
+extern "C" int lhrs_argmax_rows(const float* x, long ld, long* out, int n, int V, void* stream) {
+  LHRS_REQUIRE(n > 0 && V > 0, "argmax_rows: n=%d V=%d", n, V);
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, x, ld, out, V);
+  LHRS_CHECK_LAUNCH("argmax_rows");
+  return 0;
+}
 
 extern "C" int lhrs_splice_fwd(const long* ids, const long* labels, const uint8_t* mask, const void* image,
                                const void* embed, void* out_embeds, long* out_labels, uint8_t* out_mask, int* img_pos,

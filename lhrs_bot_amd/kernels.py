@@ -281,6 +281,13 @@ def scatter_rows(src, idx, dst):
     return dst
 
 
+def argmax_rows(logits_f32):
+    n, V = logits_f32.shape
+    out = torch.empty(n, device=logits_f32.device, dtype=torch.int64)
+    _lib.check(_L().lhrs_argmax_rows(logits_f32.data_ptr(), logits_f32.stride(0), out.data_ptr(), n, V, _stream()), "argmax_rows")
+    return out
+
+
 def cross_entropy(logits, target, want_grad=True, inplace=True):
     n, V = logits.shape
     row_loss = torch.empty(n, device=logits.device, dtype=torch.float32)

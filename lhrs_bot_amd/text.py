@@ -162,6 +162,88 @@ class TextModal:
 
     __call__ = decode
 
+    # ------------------------------------------------------------------ generate (KV cache)
+    def _layer_step(self, L, x, B, S_new, ctx, cache, desc, max_ctx):
+        """One decoder layer over S_new new positions per sequence with `ctx` cached positions (prefill: ctx = 0)."""
+        d, H, hd, ff = self.d, self.heads, self.hd, self.ff
+        M = x.shape[0]
+        h = hk.rmsnorm_fwd(x, L["ln1_w"], self.eps)
+        qkv = hk.gemm_nt(h, L["qkv_w"])
+        hk.rope_(qkv, M, 2 * H, hd, self.cos, self.sin, pos_mod=S_new, pos0=ctx)
+        kc, vc = cache
+        row_b = d * 2
+        for b in range(B):  # append the new K / V rows of sequence b at position ctx of its cache
+            src = qkv.data_ptr() + b * S_new * 3 * row_b
+            hk.copy_2d(kc.data_ptr() + (b * max_ctx + ctx) * row_b, row_b, src + row_b, 3 * row_b, row_b, S_new)
+            hk.copy_2d(vc.data_ptr() + (b * max_ctx + ctx) * row_b, row_b, src + 2 * row_b, 3 * row_b, row_b, S_new)
+        o = torch.empty((M, d), device=self.device, dtype=torch.bfloat16)
+        hk.attn_fwd(qkv[:, :d], kc, vc, o, None, desc, B, H, hd, S_new, 1 << 30, hk.pad64(S_new), True, 1.0 / math.sqrt(hd))
+        x = hk.gemm_nt(o, L["o_w"], residual=x)
+        h = hk.rmsnorm_fwd(x, L["ln2_w"], self.eps, out=h)
+        act = hk.swiglu_fwd(hk.gemm_nt(h, L["gu_w"]), ff)
+        return hk.gemm_nt(act, L["down_w"], residual=x)
+
+    @torch.no_grad()
+    def generate(self, input_ids, image_embedding=None, attention_mask=None, do_sample=False, temperature=1.0, top_p=None,
+                 top_k=None, max_new_tokens=512, use_cache=True, stopping_criteria=None, streamer=None, eos_token_id=None,
+                 return_logits=False, **_kw):
+        """TextModal.generate (text_modal.py:528-627): prefill over the spliced embeddings, then one token at a time with
+        a KV cache; returns only the NEW token ids [B, n_new] (HF generate started from inputs_embeds).  Greedy
+        (do_sample=False, the evaluation scripts' mode) runs entirely in HIP kernels; with do_sample=True the HIP-computed
+        fp32 logits go through HF's temperature / top-k / top-p warpers and one multinomial draw per token."""
+        embeds, _, mask, _ = self.prepare_inputs_for_multimodal(input_ids, attention_mask, None, image_embedding)
+        B, S0, d = embeds.shape
+        if mask is not None and not bool(mask.bool().all()):
+            raise NotImplementedError("padded prompts in generate (batched eval with left padding) - SURVEY.md §8 f-3")
+        max_ctx = S0 + max_new_tokens
+        dev, nl = self.device, len(self.p["layers"])
+        caches = [(torch.empty((B * max_ctx, d), device=dev, dtype=torch.bfloat16), torch.empty((B * max_ctx, d), device=dev, dtype=torch.bfloat16))
+                  for _ in range(nl)]
+        out_ids, all_logits = [], []
+        finished = torch.zeros(B, dtype=torch.bool, device=dev)
+        x = embeds.reshape(B * S0, d)
+        ctx, S_new = 0, S0
+        for step in range(max_new_tokens):
+            desc = hk.make_desc([(b * S_new, S_new, b * max_ctx, ctx + S_new, ctx + S_new, ctx) for b in range(B)], dev)
+            for L, cache in zip(self.p["layers"], caches):
+                x = self._layer_step(L, x, B, S_new, ctx, cache, desc, max_ctx)
+            last = x.view(B, S_new, d)[:, -1].contiguous()
+            hn = hk.rmsnorm_fwd(last, self.p["norm_w"], self.eps)
+            logits = hk.gemm_nt(hn, self.p["lm_head"], out_f32=True)  # [B, V] fp32 (HF: logits.float())
+            if return_logits:
+                all_logits.append(logits.clone())
+            if do_sample:
+                z = logits / max(float(temperature), 1e-6)
+                if top_k:
+                    kth = torch.topk(z, int(top_k), dim=-1).values[:, -1:]
+                    z = z.masked_fill(z < kth, float("-inf"))
+                if top_p is not None and top_p < 1.0:
+                    sz, si = torch.sort(z, descending=False, dim=-1)
+                    cp = torch.softmax(sz, -1).cumsum(-1)
+                    rm = cp <= (1 - top_p)
+                    rm[:, -1] = False
+                    z = z.masked_fill(rm.scatter(1, si, rm), float("-inf"))
+                nxt = torch.multinomial(torch.softmax(z, -1), 1).squeeze(1)
+            else:
+                nxt = hk.argmax_rows(logits)
+            if eos_token_id is not None:
+                nxt = torch.where(finished, torch.full_like(nxt, self.tokenizer.pad_token_id), nxt)
+                finished |= nxt == eos_token_id
+            out_ids.append(nxt)
+            if streamer is not None:
+                streamer.put(nxt.cpu())
+            ids_so_far = torch.stack(out_ids, 1)
+            if (eos_token_id is not None and bool(finished.all())) or (
+                    stopping_criteria is not None and any(c(ids_so_far, logits) for c in stopping_criteria)):
+                break
+            ctx += S_new
+            S_new = 1
+            x = hk.gather_rows(self.p["embed"], nxt.clamp(0, self.vocab - 1).to(torch.int32))
+        if streamer is not None:
+            streamer.end()
+        ids = torch.stack(out_ids, 1)
+        return (ids, torch.stack(all_logits, 1)) if return_logits else ids
+
     # ------------------------------------------------------------------ backward (activation gradients only)
     def backward(self, loss_scale: float = 1.0) -> torch.Tensor:
         """d loss / d image_embedding  [B, NI, d] bf16."""

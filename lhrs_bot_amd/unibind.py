@@ -100,6 +100,18 @@ class UniBind:
 
     __call__ = forward
 
+    @torch.no_grad()
+    def generate(self, input_ids, images=None, do_sample=True, temperature=0.2, max_new_tokens=1024, streamer=None, use_cache=True,
+                 stopping_criteria=None, **kwargs):
+        """UniBind.generate (lhrs/models/UniBind.py:214-242): encode the image once, then TextModal.generate."""
+        assert hasattr(self, "text"), "text modal is not activate"
+        image_embedding = self.encode_image(images, pool=False) if images is not None else None
+        if image_embedding is None:
+            raise NotImplementedError("text-only generate")
+        return self.text.generate(input_ids=input_ids, image_embedding=image_embedding, do_sample=do_sample, temperature=temperature,
+                                  max_new_tokens=max_new_tokens, streamer=streamer, use_cache=use_cache,
+                                  stopping_criteria=stopping_criteria, **kwargs)
+
     def backward(self, loss_scale: float = 1.0) -> None:
         d_image = self.text.backward(loss_scale)
         self.rgb_pooler.backward(d_image)

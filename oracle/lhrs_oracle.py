@@ -223,3 +223,27 @@ def unibind_forward(P: Dict, batch: Dict, collect: Optional[Dict] = None) -> tor
     if collect is not None:
         collect.update(taps=taps, image=img, embeds=embeds, labels=labels, mask=mask, hidden=hidden)
     return loss
+
+
+# ------------------------------------------------------------------------------------------------- generate (greedy)
+@torch.no_grad()
+def generate_logits(P: Dict, rgb: torch.Tensor, input_ids: torch.Tensor, forced_tokens: torch.Tensor) -> torch.Tensor:
+    """UniBind.generate / TextModal.generate (lhrs/models/UniBind.py:214-242, lhrs/models/text_modal.py:528-627) restated
+    WITHOUT a KV cache: for step t the full sequence [spliced prompt | forced_tokens[:, :t]] is re-run and the logits of the
+    last position are returned -> [B, n_new, V].  Greedy decoding = argmax of these logits (HF do_sample=False)."""
+    img = pooler_forward(P["pooler"], vit_forward(P["vit"], rgb))
+    src, _, _ = splice(input_ids, None, None, img.shape[1])
+    B, S0 = src.shape
+    emb = P["llama"]["embed"]
+    tok = emb[torch.gather(input_ids.clamp(min=0), 1, src.clamp(min=0))]
+    img_rows = img[torch.arange(B)[:, None], (-src - 1).clamp(0, img.shape[1] - 1)]
+    embeds = torch.where((src < 0)[..., None], img_rows, tok)
+    out = []
+    for t in range(forced_tokens.shape[1] + 1):
+        if t > 0:
+            embeds = torch.cat([embeds, emb[forced_tokens[:, t - 1]][:, None]], 1)
+        if t == forced_tokens.shape[1]:
+            break
+        h = llama_hidden(P["llama"], embeds, None)
+        out.append(F.linear(h[:, -1], P["llama"]["lm_head"]).float())
+    return torch.stack(out, 1)
