@@ -41,9 +41,21 @@ int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, i
                       float alpha, void* stream);
 
 /* live HIP-event timing of the dominant (128x128-tile) GEMM launches for bench.py's roofline leg; see gemm.hip */
+/* fused LoRA: C = alpha * (A.B^T + A2.B2^T) + bias + residual, A2 [M,K2] = (alpha_lora/r) * X.A_lora^T, B2 [N,K2] = B_lora
+ * (peft lora.Linear.forward reached from lhrs/models/text_modal.py:133-151); K2 % 64 == 0 (zero padded). */
+int lhrs_gemm_bf16_nt_lora(const void* A, int lda, const void* B, int ldb, const void* A2, int lda2, const void* B2, int ldb2,
+                           int K2, void* C, int ldc, int M, int N, int K, const void* bias, const void* residual, int ldr,
+                           int out_f32, int accumulate, float alpha, void* stream);
 int lhrs_gemm_set_policy(int allow_256);
 int lhrs_gemm_profile_enable(int max_samples);
 int lhrs_gemm_profile_read(double* out5_host);
+
+/* ---- LoRA gradients (peft lora.Linear backward; lhrs/models/text_modal.py:133-151) ------------------------- *
+ * C[KP,N] (+)= P[M,KP]^T . Q[M,N]: dA = (s dy B)^T x and dB^T = (s x A^T)^T dy straight from token-major operands.  */
+int lhrs_tn_skinny_splits(int M, int N); /* host helper: workspace = splits * KP * N floats */
+int lhrs_gemm_tn_skinny(const void* P, long ldp, const void* Q, long ldq, float* C, long ldc, float* partial, int M, int N,
+                        int KP, int accumulate, void* stream);
+int lhrs_blockdiag_mask(float* g, long ld, int rows, int cols, int r, int w, int active_mask, void* stream);
 
 /* ---- normalisation ---------------------------------------------------------------------------------- *
  * LayerNorm: lhrs/models/common_arch.py:253-259 (+ HF CLIP pre_layrnorm / layer_norm1/2); eps 1e-5.

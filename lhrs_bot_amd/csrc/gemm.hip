@@ -36,6 +36,11 @@ struct GemmArgs {
   int out_f32;   // 0 -> bf16 C, 1 -> f32 C
   int accum;     // f32 only: C += result
   int tilesM, tilesN;
+  // optional second operand pair, reduced in the same k-loop: C = alpha * (A.B^T + A2.B2^T) ...  (fused LoRA: A2 = s*X*A_lora^T,
+  // B2 = B_lora).  K2 = 0 disables it.
+  const bf16_t* A2;
+  const bf16_t* B2;
+  int lda2, ldb2, K2;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -379,8 +384,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256p_kernel(GemmArgs g) {
       dst_off[j] = A_BYTES + (idx - 16) * 1024;
     }
   }
+  const bf16_t* src2[4];
+  const int nk1 = g.K / BK;
+  if (g.K2 > 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = wave * 4 + j;
+      if (idx < 16) src2[j] = g.A2 + (long)min(tm * BM + idx * 16 + lrow, g.M - 1) * g.lda2 + lchunk * 8;
+      else src2[j] = g.B2 + (long)min(tn * BN + (idx - 16) * 16 + lrow, g.N - 1) * g.ldb2 + lchunk * 8;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) src2[j] = src[j];
+  }
   auto issue1 = [&](int kt, int j) {
-    __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + (long)kt * BK), (lptr_t)(smem + (kt & (NS - 1)) * STAGE + dst_off[j]), 16, 0, 0);
+    const bf16_t* p = kt < nk1 ? src[j] + (long)kt * BK : src2[j] + (long)(kt - nk1) * BK;
+    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + (kt & (NS - 1)) * STAGE + dst_off[j]), 16, 0, 0);
   };
 
   const int wm = wave >> 2, wn = wave & 3;
@@ -405,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256p_kernel(GemmArgs g) {
 #define MFMA8(A_, B_) \
   MF(A_, B_, 0, 0) MF(A_, B_, 0, 1) MF(A_, B_, 1, 0) MF(A_, B_, 1, 1) MF(A_, B_, 2, 0) MF(A_, B_, 2, 1) MF(A_, B_, 3, 0) MF(A_, B_, 3, 1)
 
-  const int nk = g.K / BK;  // >= 3 (host guarantees)
+  const int nk = (g.K + g.K2) / BK;  // >= 3 (host guarantees)
 #pragma unroll
   for (int j = 0; j < 4; ++j) issue1(0, j);
 #pragma unroll
@@ -585,9 +604,31 @@ static int g_gemm_allow_256 = 2;
 extern "C" int lhrs_gemm_set_policy(int allow_256) { g_gemm_allow_256 = allow_256; return 0; }
 
 // C ABI ------------------------------------------------------------------------------------------
+static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* bias,
+                       const void* residual, int ldr, int act, int out_f32, int accumulate, float alpha, const void* A2,
+                       int lda2, const void* B2, int ldb2, int K2, void* stream);
+
 extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N,
                                  int K, const void* bias, const void* residual, int ldr, int act, int out_f32,
                                  int accumulate, float alpha, void* stream) {
+  return gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, out_f32, accumulate, alpha, nullptr, 0, nullptr, 0,
+                     0, stream);
+}
+
+// C = alpha * (A.B^T + A2.B2^T) + bias + residual: the rank-K2 LoRA update rides in the k-loop of the base GEMM
+// (peft lora.Linear forward, y = W x + (alpha/r) B A x, reached from lhrs/models/text_modal.py:133-151).
+extern "C" int lhrs_gemm_bf16_nt_lora(const void* A, int lda, const void* B, int ldb, const void* A2, int lda2, const void* B2,
+                                      int ldb2, int K2, void* C, int ldc, int M, int N, int K, const void* bias,
+                                      const void* residual, int ldr, int out_f32, int accumulate, float alpha, void* stream) {
+  LHRS_REQUIRE(A2 && B2 && K2 > 0 && K2 % 64 == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && lda2 >= K2 && ldb2 >= K2,
+               "gemm_lora: bad second operand pair (K2=%d lda2=%d ldb2=%d)", K2, lda2, ldb2);
+  return gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, 0, out_f32, accumulate, alpha, A2, lda2, B2, ldb2, K2,
+                     stream);
+}
+
+static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* bias,
+                       const void* residual, int ldr, int act, int out_f32, int accumulate, float alpha, const void* A2,
+                       int lda2, const void* B2, int ldb2, int K2, void* stream) {
   LHRS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
   LHRS_REQUIRE(K % 32 == 0, "gemm: K=%d must be a multiple of 32 (zero-pad the reduction dim)", K);
   LHRS_REQUIRE(N % 4 == 0, "gemm: N=%d must be a multiple of 4", N);
@@ -601,6 +642,7 @@ extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
   g.bias = (const bf16_t*)bias; g.res = (const bf16_t*)residual;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
   g.alpha = alpha; g.act = act; g.out_f32 = out_f32; g.accum = accumulate;
+  g.A2 = (const bf16_t*)A2; g.B2 = (const bf16_t*)B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
   hipStream_t s = (hipStream_t)stream;
   // Tile choice: fill the 256 CUs.  Small problems (projector, ViT at small batch) take smaller tiles.
   const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
@@ -619,14 +661,20 @@ extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
   const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
   const bool al16 = out_f32 || (N % 8 == 0 && ldc % 8 == 0 && (residual == nullptr || ldr % 8 == 0));  // 16-B epilogue rows
   const bool use256 = g_gemm_allow_256 && t256 >= 160 && K >= 96 && K % 32 == 0 && al16;  // ring prologue needs >= 3 stages
+  if (K2 > 0 && !use256) {  // small problems: base GEMM, then the rank-K2 update accumulated on top of it
+    if (gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, out_f32, accumulate, alpha, nullptr, 0, nullptr, 0, 0, stream))
+      return -1;
+    return gemm_launch(A2, lda2, B2, ldb2, C, ldc, M, N, K2, nullptr, out_f32 ? nullptr : C, ldc, 0, out_f32, out_f32 ? 1 : 0, alpha,
+                       nullptr, 0, nullptr, 0, 0, stream);
+  }
   LHRS_REQUIRE(use256 || K % 64 == 0, "gemm: K=%d must be a multiple of 64 for this problem size (zero-pad the reduction dim)", K);
   const bool big = t128 >= 384;
   int slot = -1;
   if (g_prof.on) {
-    g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * K;
+    g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * (K + K2);
     if ((big || use256) && g_prof.used < g_prof.cap) {
       slot = g_prof.used++;
-      g_prof.flops[slot] = 2.0 * M * N * K;
+      g_prof.flops[slot] = 2.0 * M * N * (K + K2);
       (void)hipEventRecord(g_prof.ev[2 * slot], s);
     }
   }

@@ -1,0 +1,154 @@
+// LoRA gradient kernels for gfx950.
+//
+// peft lora.Linear (reached from /root/reference lhrs/models/text_modal.py:133-151, find_all_linear_names :658-667):
+//     y = W x + s * B (A x),  s = lora_alpha / r
+// The forward / dX products ride inside the base GEMM (lhrs_gemm_bf16_nt_lora).  What remains for the adapters is
+//     dA = (s * dy B)^T x      [r, in]        dB^T = (s * x A^T)^T dy      [r, out]
+// i.e. "TN" products that reduce over the TOKEN axis of two token-major matrices - the one shape the NT GEMM family
+// cannot take.  tn_skinny_kernel computes C[KP, N] = P[M, KP]^T . Q[M, N] for a skinny P (KP = 64..384 stacked adapter
+// rows) straight from the row-major operands: 64-token tiles are staged in LDS as they lie in HBM and BOTH MFMA operands
+// are formed by transposing LDS reads (ds_read_b64_tr_b16), so no transposed copy of an activation is ever written.
+// HBM-bound: Q is read exactly once (M*N*2 bytes), P once per 64-column tile (L2-resident).
+// peft is not importable in the build container: parity for LoRA is pinned against oracle autograd only ("unpinned"
+// w.r.t. peft 0.7.1 itself).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int sub_off(int row, int c) { return row * 128 + ((c ^ (row & 7)) << 4); }  // [64][64] bf16, swizzled
+
+// global [rows m0.., 64 cols c0..] -> LDS sub-tile; rows >= m_end are ZERO (they are summed over)
+__device__ __forceinline__ void load_sub(char* lds, const bf16_t* base, long ld, int m0, int m_end, int c0, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + i * 256;
+    const int r = idx >> 3, c = idx & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (m0 + r < m_end) v = *reinterpret_cast<const uint4*>(base + (long)(m0 + r) * ld + c0 + c * 8);
+    *reinterpret_cast<uint4*>(lds + sub_off(r, c)) = v;
+  }
+}
+
+#define TR_RD(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+
+// fragment of 16 columns (block cb) x k-step t of a [64 tokens][64 cols] sub-tile: lane (L, g) gets col cb*16+L, tokens (g, j)
+__device__ __forceinline__ unsigned tr_base(const char* lds, int lane, int cb) {
+  const int L = lane & 15, g = lane >> 4;
+  const int r0 = 4 * g + (L >> 2);
+  return (unsigned)(size_t)((__attribute__((address_space(3))) const char*)lds) + r0 * 128 +
+         (((2 * cb + ((L & 3) >> 1)) ^ (r0 & 7)) << 4) + (L & 1) * 8;
+}
+
+template <int NSUB>  // KP = 64 * NSUB
+__global__ __launch_bounds__(256) void tn_skinny_kernel(const bf16_t* __restrict__ P, long ldp, const bf16_t* __restrict__ Q, long ldq,
+                                                        float* __restrict__ partial, int M, int N, int tiles_per_split) {
+  constexpr int KP = 64 * NSUB, IB = KP / 16;
+  __shared__ __attribute__((aligned(16))) char lds_q[8192];
+  __shared__ __attribute__((aligned(16))) char lds_p[NSUB * 8192];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fg = lane >> 4;
+  const int n0 = blockIdx.x * 64;
+  const int t0 = blockIdx.y * tiles_per_split;
+  const int t1 = min(t0 + tiles_per_split, (M + 63) >> 6);
+  f32x4 acc[IB];
+#pragma unroll
+  for (int i = 0; i < IB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned qb = tr_base(lds_q, lane, wave);  // this wave's 16 output columns
+  for (int t = t0; t < t1; ++t) {
+    __syncthreads();
+    load_sub(lds_q, Q, ldq, t * 64, M, n0, tid);
+#pragma unroll
+    for (int sI = 0; sI < NSUB; ++sI) load_sub(lds_p + sI * 8192, P, ldp, t * 64, M, sI * 64, tid);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x4 qlo, qhi;
+      if (ks == 0) { TR_RD(qlo, qb, 0); TR_RD(qhi, qb, 16 * 128); } else { TR_RD(qlo, qb, 32 * 128); TR_RD(qhi, qb, 48 * 128); }
+      bf16x4 plo[IB], phi[IB];
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) {
+        const unsigned pb = tr_base(lds_p + (ib >> 2) * 8192, lane, ib & 3);
+        if (ks == 0) { TR_RD(plo[ib], pb, 0); TR_RD(phi[ib], pb, 16 * 128); } else { TR_RD(plo[ib], pb, 32 * 128); TR_RD(phi[ib], pb, 48 * 128); }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qlo), "+v"(qhi));
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) asm volatile("" : "+v"(plo[ib]), "+v"(phi[ib]));
+      __builtin_amdgcn_sched_barrier(0);
+      const bf16x8 qf{qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) {
+        const bf16x8 pf{plo[ib][0], plo[ib][1], plo[ib][2], plo[ib][3], phi[ib][0], phi[ib][1], phi[ib][2], phi[ib][3]};
+        acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, qf, acc[ib], 0, 0, 0);  // D[i = kp][j = n]
+      }
+    }
+  }
+  // lane holds C[kp = ib*16 + fg*4 + r][n = n0 + wave*16 + (lane&15)]
+  const int n = n0 + wave * 16 + (lane & 15);
+  if (n < N) {
+    float* out = partial + (long)blockIdx.y * KP * N;
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(long)(ib * 16 + fg * 4 + r) * N + n] = acc[ib][r];
+  }
+}
+
+__global__ void tn_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, long ldc, int KP, int N, int splits,
+                                 int accumulate) {
+  const long total = (long)KP * N;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += partial[(long)k * total + i];
+    const long o = (i / N) * ldc + (i % N);
+    C[o] = accumulate ? C[o] + s : s;
+  }
+}
+
+// keep only the block-diagonal of a stacked adapter gradient: rows [p*r, (p+1)*r) x cols [p*w, (p+1)*w) for active p
+__global__ void blockdiag_mask_kernel(float* __restrict__ g, long ld, int rows, int cols, int r, int w, int active_mask) {
+  const long total = (long)rows * cols;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int row = i / cols, col = i % cols;
+    const int pr = row / r, pc = col / w;
+    if (pr != pc || !((active_mask >> pr) & 1)) g[(long)row * ld + col] = 0.f;
+  }
+}
+
+}  // namespace
+
+extern "C" int lhrs_tn_skinny_splits(int M, int N) {
+  const int mt = (M + 63) / 64, nt = (N + 63) / 64;
+  int s = (1024 + nt - 1) / nt;
+  if (s > mt) s = mt;
+  if (s > 16) s = 16;
+  return s < 1 ? 1 : s;
+}
+
+// C[KP, N] (+)= P[M, KP]^T . Q[M, N]; KP in {64, 128, 192, 256, 320, 384}; partial: splits * KP * N floats
+extern "C" int lhrs_gemm_tn_skinny(const void* P, long ldp, const void* Q, long ldq, float* C, long ldc, float* partial, int M,
+                                   int N, int KP, int accumulate, void* stream) {
+  LHRS_REQUIRE(M > 0 && N > 0 && N % 64 == 0, "gemm_tn_skinny: M=%d N=%d (N %% 64 == 0)", M, N);
+  LHRS_REQUIRE(KP % 64 == 0 && KP >= 64 && KP <= 384, "gemm_tn_skinny: KP=%d must be 64..384 in steps of 64", KP);
+  LHRS_REQUIRE(ldp % 8 == 0 && ldq % 8 == 0 && partial != nullptr, "gemm_tn_skinny: strides must be multiples of 8");
+  const int splits = lhrs_tn_skinny_splits(M, N);
+  const int mt = (M + 63) / 64, tps = (mt + splits - 1) / splits;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(N / 64, splits), blk(256);
+#define TN_CASE(NS) case NS: hipLaunchKernelGGL((tn_skinny_kernel<NS>), grid, blk, 0, s, (const bf16_t*)P, ldp, (const bf16_t*)Q, ldq, partial, M, N, tps); break;
+  switch (KP / 64) { TN_CASE(1) TN_CASE(2) TN_CASE(3) TN_CASE(4) TN_CASE(5) TN_CASE(6) }
+#undef TN_CASE
+  LHRS_CHECK_LAUNCH("gemm_tn_skinny");
+  long work = (long)KP * N;
+  int rg = (int)((work + 255) / 256); if (rg > 4096) rg = 4096;
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3(rg), dim3(256), 0, s, partial, C, ldc, KP, N, splits, accumulate);
+  LHRS_CHECK_LAUNCH("gemm_tn_skinny_reduce");
+  return 0;
+}
+
+extern "C" int lhrs_blockdiag_mask(float* g, long ld, int rows, int cols, int r, int w, int active_mask, void* stream) {
+  LHRS_REQUIRE(rows > 0 && cols > 0 && r > 0 && w > 0, "blockdiag_mask: rows=%d cols=%d r=%d w=%d", rows, cols, r, w);
+  long work = (long)rows * cols;
+  int grid = (int)((work + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(blockdiag_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, ld, rows, cols, r, w, active_mask);
+  LHRS_CHECK_LAUNCH("blockdiag_mask");
+  return 0;
+}

@@ -110,6 +110,32 @@ class GradReducer:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
 
+class _TrainStore:
+    """Uniform view of one trainable flat parameter set (projector or LoRA adapters) for the optimizer and the reducer."""
+
+    def __init__(self, name, master, grad, shadow, refresh, wd_ranges, buckets, numel_decay, numel_nodecay):
+        self.name, self.master, self.grad, self.shadow, self.refresh = name, master, grad, shadow, refresh
+        self.wd_ranges, self.buckets = wd_ranges, buckets
+        self.numel = master.numel()
+        self.numel_decay, self.numel_nodecay = numel_decay, numel_nodecay
+
+
+def _pooler_wd_ranges(pool):
+    out = []
+    for name, shape in pool.spec:
+        off, _ = pool.offsets[name]
+        n = 1
+        for s in shape:
+            n *= s
+        padded = (n + 63) // 64 * 64
+        dec = not (len(shape) == 1 or name.endswith(".bias"))  # build_optimizer.py:41-73: 1-D tensors and biases do not decay
+        if out and out[-1][2] == dec and out[-1][1] == off:
+            out[-1][1] = off + padded
+        else:
+            out.append([off, off + padded, dec])
+    return out
+
+
 class LHRSEngine:
     def __init__(self, model, optimizer: str = "adanp", lr: float = 2e-4, weight_decay: float = 0.0,
                  max_grad_norm: float = 0.3, betas=None, eps: float = 1e-8, process_group=None, comm_dtype=torch.float32):
@@ -120,42 +146,41 @@ class LHRSEngine:
             raise ValueError(f"optimizer {optimizer!r}: the reference builds adanp (stage 1) or adamw (stage 2/3)")
         self.betas = betas or ((0.98, 0.92, 0.99) if self.opt_name.startswith("adan") else (0.9, 0.95))
         self.eps, self.max_grad_norm = eps, float(max_grad_norm or 0.0)
-        dev, n = self.pool.device, self.pool.numel
-        self.exp_avg = torch.zeros(n, device=dev)
-        self.exp_avg_sq = torch.zeros(n, device=dev)
-        if self.opt_name.startswith("adan"):
-            self.exp_avg_diff = torch.zeros(n, device=dev)
-            self.pre_grad = torch.zeros(n, device=dev)
+        dev = self.pool.device
+        # ---- trainable sets: the projector (stage 1/2) and / or the LoRA adapters (stage 2/3)
+        self.stores: List[_TrainStore] = []
+        if self.pool.requires_grad:
+            nodecay = sum(v.numel() for nme, v in self.pool.named_parameters() if v.dim() == 1 or nme.endswith(".bias"))
+            self.stores.append(_TrainStore("rgb_pooler", self.pool.master, self.pool.grad, self.pool.shadow, self.pool.refresh_transposed,
+                                           _pooler_wd_ranges(self.pool), bucket_ranges(self.pool), self.pool.num_parameters() - nodecay,
+                                           nodecay))
+        lora = getattr(model.text, "lora", None)
+        if lora is not None:
+            lb = [(str(l), s, e_) for l, (s, e_) in enumerate(lora.layer_range)]
+            self.stores.append(_TrainStore("lora", lora.master, lora.grad, lora.shadow, lora.refresh, [[0, lora.numel, True]], lb,
+                                           lora.num_parameters(), 0))
+        if not self.stores:
+            raise ValueError("nothing to train: the projector is frozen and no LoRA adapters are enabled")
+        self.state = {}
+        for st in self.stores:
+            z = lambda: torch.zeros(st.numel, device=dev)  # noqa: E731
+            self.state[st.name] = dict(exp_avg=z(), exp_avg_sq=z())
+            if self.opt_name.startswith("adan"):
+                self.state[st.name].update(exp_avg_diff=z(), pre_grad=z())
         self.gnorm_sq = torch.zeros((), device=dev)
         self.global_steps = 0
-        # no-decay = 1-D params and biases (build_optimizer.py:41-73); wd is applied per element range
-        nodecay = sum(v.numel() for nme, v in self.pool.named_parameters() if v.dim() == 1 or nme.endswith(".bias"))
-        self.optimizer = _Optimizer(lr, weight_decay, self.pool.num_parameters() - nodecay, nodecay)
-        self._ranges = self._build_wd_ranges()
+        self.optimizer = _Optimizer(lr, weight_decay, sum(s.numel_decay for s in self.stores), sum(s.numel_nodecay for s in self.stores))
         # ---- data parallel
         self.pg = process_group
         self.world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(self.pg)
-        self.buckets = bucket_ranges(self.pool)
-        self.reducer = GradReducer(self.pool.grad, self.buckets, self.pg, comm_dtype) if self.world > 1 else None
+        self.reducers = {st.name: GradReducer(st.grad, st.buckets, self.pg, comm_dtype) for st in self.stores} if self.world > 1 else {}
 
-    # ------------------------------------------------------------------ layout helpers
-    def _build_wd_ranges(self):
-        """Contiguous [start, end, decays] element ranges of the flat buffer, in order."""
-        out = []
-        for name, shape in self.pool.spec:
-            off, _ = self.pool.offsets[name]
-            n = 1
-            for s in shape:
-                n *= s
-            padded = (n + 63) // 64 * 64
-            dec = not (len(shape) == 1 or name.endswith(".bias"))
-            if out and out[-1][2] == dec and out[-1][1] == off:
-                out[-1][1] = off + padded
-            else:
-                out.append([off, off + padded, dec])
-        return out
+    # back-compat accessors used by tests / tools (stage-1: the projector's optimizer state)
+    @property
+    def exp_avg(self):
+        return self.state[self.stores[0].name]["exp_avg"]
 
     # ------------------------------------------------------------------ engine surface
     def __call__(self, batch):
@@ -167,55 +192,66 @@ class LHRSEngine:
 
     def backward(self, loss=None):
         """Hand-written backward; gradient ranges are all-reduced on the comm stream as they become final."""
-        d_image = self.model.text.backward()
-        self.pool.backward(d_image, on_ready=self.reducer.ready if self.reducer else None)
+        pool_on = self.pool.requires_grad
+        r_lora = self.reducers.get("lora")
+        d_image = self.model.text.backward(need_input_grad=pool_on,
+                                           on_layer_ready=(lambda l: r_lora.ready(str(l))) if r_lora else None)
+        if pool_on:
+            r_pool = self.reducers.get("rgb_pooler")
+            self.pool.backward(d_image, on_ready=r_pool.ready if r_pool else None)
 
     def step(self, lr_kwargs: Optional[Dict] = None):
-        pool, dev = self.pool, self.pool.device
-        if self.reducer:
-            self.reducer.finish()
+        for r in self.reducers.values():
+            r.finish()
         self.global_steps += 1
         step = self.global_steps
         gscale = 1.0 / self.world
         if self.max_grad_norm > 0:
-            hk.sqnorm(pool.grad, self.gnorm_sq)
+            for i, st in enumerate(self.stores):
+                hk.sqnorm(st.grad, self.gnorm_sq, accumulate=i > 0)
         gn = self.gnorm_sq if self.max_grad_norm > 0 else None
         g_dec, g_nodec = self.optimizer.param_groups
-        ranges = self._ranges
-        if g_dec["lr"] == g_nodec["lr"] and g_dec["weight_decay"] == g_nodec["weight_decay"]:
-            ranges = [[0, pool.numel, True]]  # one launch over the whole flat buffer (stage-1 YAML: wd = 0)
-        for start, end, dec in ranges:
-            grp = g_dec if dec else g_nodec
-            sl = slice(start, end)
-            if self.opt_name.startswith("adan"):
-                hk.adan_step(pool.master[sl], pool.grad[sl], self.exp_avg[sl], self.exp_avg_diff[sl], self.exp_avg_sq[sl],
-                             self.pre_grad[sl], pool.shadow[sl], step, grp["lr"], self.betas, self.eps, grp["weight_decay"],
-                             no_prox=self.opt_name == "adanp", gnorm_sq=gn, max_norm=self.max_grad_norm, grad_scale=gscale)
-            else:
-                hk.adamw_step(pool.master[sl], pool.grad[sl], self.exp_avg[sl], self.exp_avg_sq[sl], pool.shadow[sl], step,
-                              grp["lr"], self.betas, self.eps, grp["weight_decay"], gnorm_sq=gn, max_norm=self.max_grad_norm,
-                              grad_scale=gscale)
-        pool.refresh_transposed()
+        for st in self.stores:
+            ranges = st.wd_ranges
+            if g_dec["lr"] == g_nodec["lr"] and g_dec["weight_decay"] == g_nodec["weight_decay"]:
+                ranges = [[0, st.numel, True]]  # one launch over the whole flat buffer (the shipped YAMLs: wd = 0)
+            S = self.state[st.name]
+            for start, end, dec in ranges:
+                grp = g_dec if dec else g_nodec
+                sl = slice(start, end)
+                if self.opt_name.startswith("adan"):
+                    hk.adan_step(st.master[sl], st.grad[sl], S["exp_avg"][sl], S["exp_avg_diff"][sl], S["exp_avg_sq"][sl],
+                                 S["pre_grad"][sl], st.shadow[sl], step, grp["lr"], self.betas, self.eps, grp["weight_decay"],
+                                 no_prox=self.opt_name == "adanp", gnorm_sq=gn, max_norm=self.max_grad_norm, grad_scale=gscale)
+                else:
+                    hk.adamw_step(st.master[sl], st.grad[sl], S["exp_avg"][sl], S["exp_avg_sq"][sl], st.shadow[sl], step, grp["lr"],
+                                  self.betas, self.eps, grp["weight_decay"], gnorm_sq=gn, max_norm=self.max_grad_norm,
+                                  grad_scale=gscale)
+            st.refresh()
         self.optimizer._global_grad_norm = self.gnorm_sq  # device scalar (squared, un-averaged); see grad_norm()
 
     # ------------------------------------------------------------------ checkpoint (engine.save/load_checkpoint surface)
     def state_dict(self) -> Dict:
-        sd = dict(global_steps=self.global_steps, opt=self.opt_name, master=self.pool.master.cpu(), exp_avg=self.exp_avg.cpu(),
-                  exp_avg_sq=self.exp_avg_sq.cpu(), param_groups=[dict(g) for g in self.optimizer.param_groups])
-        if self.opt_name.startswith("adan"):
-            sd.update(exp_avg_diff=self.exp_avg_diff.cpu(), pre_grad=self.pre_grad.cpu())
+        sd = dict(global_steps=self.global_steps, opt=self.opt_name, param_groups=[dict(g) for g in self.optimizer.param_groups],
+                  stores={})
+        for st in self.stores:
+            sd["stores"][st.name] = dict(master=st.master.cpu(), **{k: v.cpu() for k, v in self.state[st.name].items()})
+        if "rgb_pooler" in sd["stores"]:
+            sd["master"] = sd["stores"]["rgb_pooler"]["master"]  # stage-1 convenience alias
         return sd
 
     def load_state_dict(self, sd: Dict) -> None:
         assert sd["opt"] == self.opt_name, f"checkpoint optimizer {sd['opt']} != {self.opt_name}"
         self.global_steps = int(sd["global_steps"])
-        self.pool.master.copy_(sd["master"])
-        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        if self.opt_name.startswith("adan"):
-            self.exp_avg_diff.copy_(sd["exp_avg_diff"]); self.pre_grad.copy_(sd["pre_grad"])
+        for st in self.stores:
+            rec = sd["stores"][st.name]
+            st.master.copy_(rec["master"])
+            for k in self.state[st.name]:
+                self.state[st.name][k].copy_(rec[k])
+            hk.cast_f32_to_bf16(st.master, st.shadow)
+            st.refresh()
         for g, s in zip(self.optimizer.param_groups, sd["param_groups"]):
             g.update(s)
-        self.pool.sync_shadow()
 
     def save_checkpoint(self, save_dir: str, tag: str, client_state: Optional[Dict] = None) -> None:
         import os

@@ -52,6 +52,38 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     return out
 
 
+def gemm_nt_lora(a, b, a2, b2, out=None, *, bias=None, residual=None, out_f32=False, accumulate=False, alpha=1.0):
+    """out = alpha * (a @ b^T + a2 @ b2^T) + bias + residual  (rank-K2 LoRA update fused into the base GEMM's k-loop)."""
+    M, K = a.shape
+    N, K2 = b.shape[0], a2.shape[1]
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    ldr = residual.stride(0) if residual is not None else 0
+    st = _L().lhrs_gemm_bf16_nt_lora(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), a2.data_ptr(), a2.stride(0), b2.data_ptr(),
+                                     b2.stride(0), K2, out.data_ptr(), out.stride(0), M, N, K, _p(bias), _p(residual), ldr,
+                                     int(out_f32), int(accumulate), float(alpha), _stream())
+    _lib.check(st, "gemm_bf16_nt_lora")
+    return out
+
+
+def gemm_tn_skinny(p, q, out, accumulate=False):
+    """out[KP, N] (+)= p[M, KP]^T @ q[M, N]  (fp32 out; p, q token-major bf16, row strides free)."""
+    M, KP = p.shape
+    N = q.shape[1]
+    ns = _L().lhrs_tn_skinny_splits(M, N)
+    part = torch.empty(ns * KP * N, device=p.device, dtype=torch.float32)
+    st = _L().lhrs_gemm_tn_skinny(p.data_ptr(), p.stride(0), q.data_ptr(), q.stride(0), out.data_ptr(), out.stride(0), part.data_ptr(),
+                                  M, N, KP, int(accumulate), _stream())
+    _lib.check(st, "gemm_tn_skinny")
+    return out
+
+
+def blockdiag_mask(g, r, w, active_mask):
+    rows, cols = g.shape
+    _lib.check(_L().lhrs_blockdiag_mask(g.data_ptr(), g.stride(0), rows, cols, r, w, active_mask, _stream()), "blockdiag_mask")
+    return g
+
+
 # --------------------------------------------------------------------------------------------- norms
 def layernorm_fwd(x, gamma, beta, eps=1e-5, save_stats=False, out=None):
     rows, cols = x.shape

@@ -36,6 +36,99 @@ class SyntheticTokenizer:
         return 32000
 
 
+LORA_GROUPS = {  # fused GEMM group -> (sub-projections, in_features, out_features per projection)
+    "qkv": (("q", "k", "v"), 4096, 4096), "o": (("o",), 4096, 4096), "gu": (("gate", "up"), 4096, 11008), "down": (("down",), 11008, 4096)}
+LORA_ALL = ("q", "k", "v", "o", "gate", "up", "down")  # find_all_linear_names: every nn.Linear except lm_head (text_modal.py:658-667)
+
+
+class LoraStore:
+    """peft-style LoRA adapters (lora.Linear: y = W x + (alpha/r) B A x; A ~ kaiming-uniform(a=sqrt 5), B = 0) for the fused
+    GEMM groups, in three flat buffers (fp32 master, bf16 shadow, fp32 grad) ordered layer-major so that a layer's
+    gradients form one contiguous all-reduce bucket.  Per (layer, group) two stacked tensors:
+        A  [KP, in]          rows p*r..p*r+r = A_p                      (KP = r * n_proj padded to 64, padding rows stay 0)
+        BD [KP, out_total]   block p = B_p^T at rows p*r.., cols p*out.. (block diagonal; off-blocks are masked to 0)
+    and two derived bf16 operands rebuilt after every optimizer step: AT = A^T [in, KP], Bfull = BD^T [out_total, KP]."""
+
+    def __init__(self, n_layers, r, alpha, targets, dims, device, seed=0):
+        self.r, self.s, self.targets, self.device, self.nl = int(r), float(alpha) / float(r), tuple(targets), device, n_layers
+        self.groups = {}
+        for gname, (projs, fin, fout) in dims.items():
+            mask = sum(1 << i for i, p in enumerate(projs) if p in self.targets)
+            if mask:
+                self.groups[gname] = dict(projs=projs, fin=fin, fout=fout, mask=mask, KP=(self.r * len(projs) + 63) // 64 * 64,
+                                          out_total=fout * len(projs))
+        self.offsets, off = {}, 0
+        self.layer_range = []
+        for l in range(n_layers):
+            start = off
+            for gname, G in self.groups.items():
+                for kind, shape in (("A", (G["KP"], G["fin"])), ("BD", (G["KP"], G["out_total"]))):
+                    self.offsets[(l, gname, kind)] = (off, shape)
+                    off += shape[0] * shape[1]
+            self.layer_range.append((start, off))
+        self.numel = off
+        self.master = torch.zeros(off, device=device, dtype=torch.float32)
+        self.shadow = torch.zeros(off, device=device, dtype=torch.bfloat16)
+        self.grad = torch.zeros(off, device=device, dtype=torch.float32)
+        self.derived = {}
+        g = torch.Generator(device=device).manual_seed(seed)
+        for l in range(n_layers):
+            for gname, G in self.groups.items():
+                A = self.view(self.master, l, gname, "A")
+                bound = 1.0 / math.sqrt(G["fin"])
+                for i, p in enumerate(G["projs"]):
+                    if (G["mask"] >> i) & 1:
+                        A[i * self.r:(i + 1) * self.r].copy_((torch.rand((self.r, G["fin"]), device=device, generator=g) * 2 - 1) * bound)
+        self.refresh()
+
+    def view(self, flat, l, gname, kind):
+        off, shape = self.offsets[(l, gname, kind)]
+        return flat[off: off + shape[0] * shape[1]].view(*shape)
+
+    def num_parameters(self):
+        n = 0
+        for G in self.groups.values():
+            n += bin(G["mask"]).count("1") * self.r * (G["fin"] + G["fout"])
+        return n * self.nl
+
+    def refresh(self):
+        """bf16 shadow + transposed operands after a load / optimizer step."""
+        hk.cast_f32_to_bf16(self.master, self.shadow)
+        for l in range(self.nl):
+            for gname in self.groups:
+                self.derived[(l, gname, "AT")] = hk.transpose(self.view(self.shadow, l, gname, "A"), out=self.derived.get((l, gname, "AT")))
+                self.derived[(l, gname, "Bfull")] = hk.transpose(self.view(self.shadow, l, gname, "BD"),
+                                                                 out=self.derived.get((l, gname, "Bfull")))
+
+    # peft-layout accessors (A_p [r, in], B_p [out, r]) for tests / checkpoints
+    def get_adapter(self, l, proj):
+        for gname, G in self.groups.items():
+            if proj in G["projs"]:
+                i = G["projs"].index(proj)
+                A = self.view(self.master, l, gname, "A")[i * self.r:(i + 1) * self.r]
+                Bt = self.view(self.master, l, gname, "BD")[i * self.r:(i + 1) * self.r, i * G["fout"]:(i + 1) * G["fout"]]
+                return A, Bt.t()
+        raise KeyError(proj)
+
+    def set_adapter(self, l, proj, A, B):
+        for gname, G in self.groups.items():
+            if proj in G["projs"]:
+                i = G["projs"].index(proj)
+                self.view(self.master, l, gname, "A")[i * self.r:(i + 1) * self.r].copy_(A.to(self.device))
+                self.view(self.master, l, gname, "BD")[i * self.r:(i + 1) * self.r, i * G["fout"]:(i + 1) * G["fout"]].copy_(B.t().to(self.device))
+                return
+        raise KeyError(proj)
+
+    def grad_adapter(self, l, proj):
+        for gname, G in self.groups.items():
+            if proj in G["projs"]:
+                i = G["projs"].index(proj)
+                dA = self.view(self.grad, l, gname, "A")[i * self.r:(i + 1) * self.r]
+                dBt = self.view(self.grad, l, gname, "BD")[i * self.r:(i + 1) * self.r, i * G["fout"]:(i + 1) * G["fout"]]
+                return dA, dBt.t()
+        raise KeyError(proj)
+
+
 class TextModal:
     def __init__(self, config=None, device="cuda", layers=32, dim=4096, ff=11008, heads=32, vocab=32000, eps=1e-5,
                  rope_theta=10000.0, max_pos=2048):
@@ -50,6 +143,7 @@ class TextModal:
         self.cos = fr.cos().to(torch.bfloat16).float().to(self.device).contiguous()
         self.sin = fr.sin().to(torch.bfloat16).float().to(self.device).contiguous()
         self._ctx = None
+        self.lora: Optional[LoraStore] = None
         self.text_encoder = self  # attribute path used by the entry scripts (.text.text_encoder)
 
     def get_text_encoder(self):
@@ -90,6 +184,37 @@ class TextModal:
                                      "ln2_w": rn(d, std=0.0, mean=1.0), "gu_w": rn(2 * ff, d), "down_w": rn(d, ff)})
         self._finish()
 
+    def enable_lora(self, r=128, alpha=256, targets=LORA_ALL, seed=0) -> LoraStore:
+        """TextModal.__init__ LoRA branch (text_modal.py:133-151): LoraConfig(r, lora_alpha, target_modules=all linears).
+        BASELINE config 4 uses r=8 on ("q","k","v","o").  Dropout is not applied (stage 3 runs text.eval())."""
+        dims = {"qkv": (("q", "k", "v"), self.d, self.d), "o": (("o",), self.d, self.d), "gu": (("gate", "up"), self.d, self.ff),
+                "down": (("down",), self.ff, self.d)}
+        self.lora = LoraStore(len(self.p["layers"]), r, alpha, targets, dims, self.device, seed)
+        return self.lora
+
+    def _lin(self, li, gname, x, W, residual=None, save=None):
+        """y = x W^T (+ s (x A^T) B^T when the group carries adapters) (+ residual)."""
+        lo = self.lora
+        if lo is None or gname not in lo.groups:
+            return hk.gemm_nt(x, W, residual=residual)
+        T = hk.gemm_nt(x, lo.view(lo.shadow, li, gname, "A"), alpha=lo.s)          # [M, KP] = s * x A^T
+        if save is not None:
+            save["T_" + gname] = T
+        return hk.gemm_nt_lora(x, W, T, lo.derived[(li, gname, "Bfull")], residual=residual)
+
+    def _lin_bwd(self, li, gname, dy, WT, x, T):
+        """dx = dy W (+ s (dy B) A); adapter gradients dA = (s dy B)^T x, dB^T = (s x A^T)^T dy written into lora.grad."""
+        lo = self.lora
+        if lo is None or gname not in lo.groups:
+            return hk.gemm_nt(dy, WT)
+        G = lo.groups[gname]
+        U = hk.gemm_nt(dy, lo.view(lo.shadow, li, gname, "BD"), alpha=lo.s)         # [M, KP] = s * dy B
+        dx = hk.gemm_nt_lora(dy, WT, U, lo.derived[(li, gname, "AT")])
+        hk.gemm_tn_skinny(U, x, lo.view(lo.grad, li, gname, "A"))
+        dBD = hk.gemm_tn_skinny(T, dy, lo.view(lo.grad, li, gname, "BD"))
+        hk.blockdiag_mask(dBD, lo.r, G["fout"], G["mask"])
+        return dx
+
     # ------------------------------------------------------------------ splice
     def prepare_inputs_for_multimodal(self, input_ids, attention_mask, labels, image_embedding):
         """Device-side restatement of text_modal.py:296-526 (one <image> per sample, tune_im_start off)."""
@@ -106,22 +231,24 @@ class TextModal:
         return hk.splice_fwd(ids, lab, msk, image_embedding.contiguous(), self.p["embed"], S)
 
     # ------------------------------------------------------------------ forward
-    def _layer_fwd(self, L, x, B, S, desc, LT, save):
+    def _layer_fwd(self, L, x, B, S, desc, LT, save, li=0):
         d, H, hd, ff = self.d, self.heads, self.hd, self.ff
         M = x.shape[0]
+        rec = {} if save is not None else None
         h = hk.rmsnorm_fwd(x, L["ln1_w"], self.eps)
-        qkv = hk.gemm_nt(h, L["qkv_w"])
+        qkv = self._lin(li, "qkv", h, L["qkv_w"], save=rec)
         hk.rope_(qkv, M, 2 * H, hd, self.cos, self.sin, pos_mod=S)
         o = torch.empty((M, d), device=self.device, dtype=torch.bfloat16)
         lse = torch.empty((B, H, LT), device=self.device, dtype=torch.float32)
         hk.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, desc, B, H, hd, S, S, LT, True, 1.0 / math.sqrt(hd))
-        x_mid = hk.gemm_nt(o, L["o_w"], residual=x)
+        x_mid = self._lin(li, "o", o, L["o_w"], residual=x, save=rec)
         h = hk.rmsnorm_fwd(x_mid, L["ln2_w"], self.eps, out=h)
-        gu = hk.gemm_nt(h, L["gu_w"])
+        gu = self._lin(li, "gu", h, L["gu_w"], save=rec)
         act = hk.swiglu_fwd(gu, ff)
-        x_out = hk.gemm_nt(act, L["down_w"], residual=x_mid)
+        x_out = self._lin(li, "down", act, L["down_w"], residual=x_mid, save=rec)
         if save is not None:
-            save.append(dict(x_in=x, qkv=qkv, o=o, lse=lse, x_mid=x_mid, gu=gu))
+            rec.update(x_in=x, qkv=qkv, o=o, lse=lse, x_mid=x_mid, gu=gu)
+            save.append(rec)
         return x_out
 
     def forward_hidden(self, embeds, mask_u8, save_ctx=True):
@@ -132,8 +259,8 @@ class TextModal:
         LT = hk.pad64(S)
         saved: Optional[List] = [] if save_ctx else None
         x = embeds.reshape(B * S, d)
-        for L in self.p["layers"]:
-            x = self._layer_fwd(L, x, B, S, desc, LT, saved)
+        for li, L in enumerate(self.p["layers"]):
+            x = self._layer_fwd(L, x, B, S, desc, LT, saved, li)
         hidden = hk.rmsnorm_fwd(x, self.p["norm_w"], self.eps)
         if save_ctx:
             self._ctx = dict(B=B, S=S, desc=desc, LT=LT, layers=saved, x_last=x)
@@ -245,12 +372,14 @@ class TextModal:
         return (ids, torch.stack(all_logits, 1)) if return_logits else ids
 
     # ------------------------------------------------------------------ backward (activation gradients only)
-    def backward(self, loss_scale: float = 1.0) -> torch.Tensor:
-        """d loss / d image_embedding  [B, NI, d] bf16."""
+    def backward(self, loss_scale: float = 1.0, need_input_grad: bool = True, on_layer_ready=None):
+        """d loss / d image_embedding [B, NI, d] bf16 (None when need_input_grad is False).  With LoRA enabled the adapter
+        gradients of layer l are final when its backward finishes; on_layer_ready(l) lets the engine all-reduce them."""
         c = self._ctx
         assert c is not None, "decode(save_ctx=True) must precede backward"
         B, S, desc, LT = c["B"], c["S"], c["desc"], c["LT"]
         d, H, hd, ff, p = self.d, self.heads, self.hd, self.ff, self.p
+        lo = self.lora
         M = B * S
         dhv = hk.gemm_nt(c["dlogits"], p["lm_headT"], alpha=loss_scale)
         dhid = torch.zeros((M, d), device=self.device, dtype=torch.bfloat16)
@@ -259,20 +388,27 @@ class TextModal:
         scale = 1.0 / math.sqrt(hd)
         delta = torch.empty((B, H, LT), device=self.device, dtype=torch.float32)
         dqkv = torch.empty((M, 3 * d), device=self.device, dtype=torch.bfloat16)
-        for L, s in zip(reversed(p["layers"]), reversed(c["layers"])):
+        nl = len(p["layers"])
+        for li in reversed(range(nl)):
+            L, s = p["layers"][li], c["layers"][li]
             gu, qkv = s["gu"], s["qkv"]
-            dact = hk.gemm_nt(dx, L["down_wT"])
+            act = hk.swiglu_fwd(gu, ff) if lo is not None and "down" in lo.groups else None      # x of the down projection
+            dact = self._lin_bwd(li, "down", dx, L["down_wT"], act, s.get("T_down"))
+            h2 = hk.rmsnorm_fwd(s["x_mid"], L["ln2_w"], self.eps) if lo is not None and "gu" in lo.groups else None
             dgu = hk.swiglu_bwd(dact, gu, ff, out=gu)
-            dh = hk.gemm_nt(dgu, L["gu_wT"])
+            dh = self._lin_bwd(li, "gu", dgu, L["gu_wT"], h2, s.get("T_gu"))
             dx_mid = hk.rmsnorm_bwd(dh, s["x_mid"], L["ln2_w"], None, add=dx, eps=self.eps, out=dh)
-            do = hk.gemm_nt(dx_mid, L["o_wT"])
+            do = self._lin_bwd(li, "o", dx_mid, L["o_wT"], s["o"], s.get("T_o"))
             hk.attn_delta(s["o"], do, delta, desc, B, H, hd, S, LT)
             hk.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], do, s["lse"], delta, dqkv[:, :d], dqkv[:, d:2 * d],
                         dqkv[:, 2 * d:], desc, B, H, hd, S, S, LT, True, scale)
             hk.rope_(dqkv, M, 2 * H, hd, self.cos, self.sin, pos_mod=S, inverse=True)
-            dh1 = hk.gemm_nt(dqkv, L["qkv_wT"])
+            h1 = hk.rmsnorm_fwd(s["x_in"], L["ln1_w"], self.eps) if lo is not None and "qkv" in lo.groups else None
+            dh1 = self._lin_bwd(li, "qkv", dqkv, L["qkv_wT"], h1, s.get("T_qkv"))
             dx = hk.rmsnorm_bwd(dh1, s["x_in"], L["ln1_w"], None, add=dx_mid, eps=self.eps, out=dh1)
             s.clear()
-        d_image = hk.splice_bwd(dx.view(B, S, d), c["img_pos"], c["NI"])
+            if on_layer_ready is not None:
+                on_layer_ready(li)
+        d_image = hk.splice_bwd(dx.view(B, S, d), c["img_pos"], c["NI"]) if need_input_grad else None
         self._ctx = None
         return d_image

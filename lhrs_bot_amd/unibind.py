@@ -53,8 +53,11 @@ class UniBind:
     # ------------------------------------------------------------------ reference surface
     def prepare_for_training(self, freeze_vision=True, freeze_text=True, tune_rgb_pooler=True, model_path=None,
                              tune_im_start=False, compute_dtype=torch.bfloat16):
-        if not freeze_vision or not freeze_text or tune_im_start:
-            raise NotImplementedError("stage-1 scope: frozen ViT / LLaMA, projector-only training (BASELINE configs 1-3)")
+        if not freeze_vision or tune_im_start:
+            raise NotImplementedError("the ViT and the embedding tables stay frozen (every shipped stage: tune_rgb_bk / tune_im_start False)")
+        if not freeze_text and self.text.lora is None:
+            raise NotImplementedError("freeze_text=False means LoRA training (freeze_text = not config.lora.enable): call "
+                                      "model.enable_lora(...) first; full LLaMA fine-tuning is not on the reference's path")
         self.rgb_pooler.requires_grad = bool(tune_rgb_pooler)
         self.train()
         if model_path is not None:
@@ -86,14 +89,20 @@ class UniBind:
         self.text.load_params(P["llama"])
         return self
 
+    def enable_lora(self, r=128, alpha=256, targets=None, seed=0):
+        """lora.enable / lora_r / lora_alpha of Config/multi_modal_stage2.yaml:81-86 (text_modal.py:133-151)."""
+        from .text import LORA_ALL
+        return self.text.enable_lora(r=r, alpha=alpha, targets=targets or LORA_ALL, seed=seed)
+
     def encode_image(self, image, pool: bool = False):
         emb = self.rgb_pooler.forward(self.rgb.encode(image), save_ctx=False)
         return emb.float().mean(dim=1).to(emb.dtype) if pool else emb
 
     def forward(self, data: Dict) -> Dict[str, torch.Tensor]:
         """UniBind.forward: {"text_loss", "total_loss"} as 0-dim device tensors."""
-        grad = self.training and self.rgb_pooler.requires_grad
-        image_embedding = self.rgb_pooler.forward(self.rgb.encode(data["rgb"]), save_ctx=grad)
+        pool_grad = self.training and self.rgb_pooler.requires_grad
+        grad = pool_grad or (self.training and self.text.lora is not None)
+        image_embedding = self.rgb_pooler.forward(self.rgb.encode(data["rgb"]), save_ctx=pool_grad)
         loss = self.text.decode(data["input_ids"], image_embedding=image_embedding, attention_mask=data.get("attention_mask"),
                                 labels=data["labels"], save_ctx=grad)
         return {"text_loss": loss, "total_loss": loss}
@@ -113,8 +122,9 @@ class UniBind:
                                   stopping_criteria=stopping_criteria, **kwargs)
 
     def backward(self, loss_scale: float = 1.0) -> None:
-        d_image = self.text.backward(loss_scale)
-        self.rgb_pooler.backward(d_image)
+        d_image = self.text.backward(loss_scale, need_input_grad=self.rgb_pooler.requires_grad)
+        if self.rgb_pooler.requires_grad:
+            self.rgb_pooler.backward(d_image)
 
     def custom_save_checkpoint(self, file_name: str):
         import os

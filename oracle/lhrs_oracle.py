@@ -169,6 +169,16 @@ def _rms(x, w, eps):
     return w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))
 
 
+def _lora(L, proj, x):
+    """peft lora.Linear delta (peft 0.7.1, absent here - PARITY UNPINNED): s * (x A^T) B^T with s = lora_alpha / r; call site
+    lhrs/models/text_modal.py:133-151.  L["lora"] = {"scale": s, proj: (A [r,in], B [out,r])}."""
+    lo = L.get("lora")
+    if not lo or proj not in lo:
+        return 0.0
+    A, B = lo[proj]
+    return lo["scale"] * F.linear(F.linear(x, A), B)
+
+
 def llama_hidden(p: Dict, embeds: torch.Tensor, mask: Optional[torch.Tensor], heads: int = 32, eps: float = 1e-5,
                  collect=None) -> torch.Tensor:
     """HF LlamaModel.forward as called by TextModal.decode (lhrs/models/text_modal.py:258-294): per layer
@@ -183,15 +193,20 @@ def llama_hidden(p: Dict, embeds: torch.Tensor, mask: Optional[torch.Tensor], he
     x = embeds
     for L in p["layers"]:
         h = _rms(x, L["ln1_w"], eps)
-        qkv = F.linear(h, L["qkv_w"]).view(B, S, 3, heads, hd)
+        qkv = F.linear(h, L["qkv_w"])
+        qkv = qkv + torch.cat([_lora(L, pr, h) + torch.zeros_like(qkv[..., :d]) for pr in ("q", "k", "v")], -1)
+        qkv = qkv.view(B, S, 3, heads, hd)
         q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
         q, k = _rope(q, cos, sin), _rope(k, cos, sin)
         a = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd) + bias, -1) @ v
-        x = x + F.linear(a.transpose(1, 2).reshape(B, S, d), L["o_w"])
+        a = a.transpose(1, 2).reshape(B, S, d)
+        x = x + F.linear(a, L["o_w"]) + _lora(L, "o", a)
         h = _rms(x, L["ln2_w"], eps)
         ff = L["gu_w"].shape[0] // 2
         gu = F.linear(h, L["gu_w"])
-        x = x + F.linear(F.silu(gu[..., :ff]) * gu[..., ff:], L["down_w"])
+        gu = gu + torch.cat([_lora(L, pr, h) + torch.zeros_like(gu[..., :ff]) for pr in ("gate", "up")], -1)
+        act = F.silu(gu[..., :ff]) * gu[..., ff:]
+        x = x + F.linear(act, L["down_w"]) + _lora(L, "down", act)
         if collect is not None:
             collect.append(x)
     return _rms(x, p["norm_w"], eps)

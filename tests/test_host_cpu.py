@@ -91,7 +91,7 @@ for comm_dtype in (torch.float32, torch.bfloat16):
     assert err <= tol + 1e-6, (str(comm_dtype), err)
 dist.barrier()
 dist.destroy_process_group()
-print("rank", rank, "ok")
+open(os.path.join(sys.argv[2], f"ok{rank}"), "w").write("ok")
 '''
 
 
@@ -104,10 +104,10 @@ def test_grad_reducer_world2_gloo(tmp_path):
         port = str(sk.getsockname()[1])
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", port, str(script), ROOT]
+           "--master-port", port, str(script), ROOT, str(tmp_path)]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()  # (stdout of the two ranks interleaves)
 
 
 def test_config_parser_matches_reference_parser(tmp_path):

@@ -115,6 +115,38 @@ def test_gemm_rejects_bad_k():
         hk.gemm_nt(a, a)
 
 
+def test_gemm_lora_fused_and_fallback():
+    g = torch.Generator().manual_seed(77)
+    for (M, N, Kd, K2) in [(4095, 4096, 4096, 64), (300, 512, 256, 128)]:   # 256-tile fused path / small two-launch path
+        a = bf(torch.randn(M, Kd, generator=g)).to(DEV); b = bf(torch.randn(N, Kd, generator=g) * 0.05).to(DEV)
+        a2 = bf(torch.randn(M, K2, generator=g)).to(DEV); b2 = bf(torch.randn(N, K2, generator=g) * 0.05).to(DEV)
+        res = bf(torch.randn(M, N, generator=g)).to(DEV)
+        out = hk.gemm_nt_lora(a, b, a2, b2, residual=res, alpha=0.5)
+        ref = 0.5 * (a.float() @ b.float().t() + a2.float() @ b2.float().t()) + res.float()
+        assert rel_err(out, ref) < 5e-3
+        o32 = hk.gemm_nt_lora(a, b, a2, b2, out_f32=True)
+        assert rel_err(o32, a.float() @ b.float().t() + a2.float() @ b2.float().t()) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,KP", [(8190, 4096, 64), (1000, 12288, 128), (70, 64, 384)])
+def test_gemm_tn_skinny(M, N, KP):
+    g = torch.Generator().manual_seed(M + KP)
+    pbig = bf(torch.randn(M, KP + 64, generator=g)).to(DEV)
+    p = pbig[:, 32:32 + KP] if False else pbig[:, :KP]          # strided rows
+    q = bf(torch.randn(M, N, generator=g)).to(DEV)
+    out = torch.full((KP, N), 7.0, device=DEV)
+    hk.gemm_tn_skinny(p, q, out)
+    ref = p.float().t() @ q.float()
+    assert rel_err(out, ref) < 1e-5
+    hk.gemm_tn_skinny(p, q, out, accumulate=True)
+    assert rel_err(out, 2 * ref) < 1e-5
+    m = hk.blockdiag_mask(ref.clone(), 16, N // (KP // 16) if N % (KP // 16) == 0 else N, 0b101)
+    rr = torch.arange(KP, device=DEV)[:, None] // 16
+    cc = torch.arange(N, device=DEV)[None, :] // (N // (KP // 16) if N % (KP // 16) == 0 else N)
+    keep = (rr == cc) & (((0b101 >> rr) & 1) == 1)
+    assert torch.equal(m, torch.where(keep, ref, torch.zeros_like(ref)))
+
+
 # ------------------------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("rows,cols", [(7, 1024), (2057, 1024), (100, 512)])
 def test_layernorm_fwd_bwd(rows, cols):

@@ -1,0 +1,84 @@
+"""Stage-2/3 path: LoRA adapters fused into the LLaMA GEMMs (forward, dX, dA, dB) + AdamW, against oracle autograd.
+peft / deepspeed are not importable anywhere (parity unpinned w.r.t. them); the oracle restates lora.Linear."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from lhrs_bot_amd.engine import LHRSEngine  # noqa: E402
+from lhrs_bot_amd.unibind import UniBind  # noqa: E402
+from oracle import lhrs_oracle as O  # noqa: E402
+from oracle import params as OP  # noqa: E402
+from oracle.optim_oracle import adamw_step_ref  # noqa: E402
+
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def make(targets, r, train_pooler):
+    nl = 2
+    P = {"vit": OP.make_vit_params(seed=2), "pooler": OP.make_pooler_params(seed=1), "llama": OP.make_llama_params(seed=3, layers=nl)}
+    model = UniBind(("rgb", "text"), None, device=DEV, llama_layers=nl).load_params(P)
+    lora = model.enable_lora(r=r, alpha=2 * r, targets=targets, seed=4)
+    g = torch.Generator().manual_seed(9)
+    for l in range(nl):  # non-zero B so that dA is exercised (peft starts B at 0)
+        P["llama"]["layers"][l]["lora"] = {"scale": 2.0}
+        for pr in targets:
+            A, B = lora.get_adapter(l, pr)
+            Bn = torch.randn(B.shape, generator=g) * 0.02
+            lora.set_adapter(l, pr, A.cpu(), Bn)
+            P["llama"]["layers"][l]["lora"][pr] = (A.cpu().clone().requires_grad_(True), Bn.clone().requires_grad_(True))
+    lora.refresh()
+    model.prepare_for_training(freeze_vision=True, freeze_text=False, tune_rgb_pooler=train_pooler)
+    B_, T = 2, 20
+    ids = torch.randint(3, 32000, (B_, T), generator=g)
+    ids[:, 0] = 1
+    ids[:, 1] = -200
+    ids[1, 16:] = 0
+    labels = ids.clone()
+    labels[:, :2] = -100
+    labels[ids == 0] = -100
+    batch = dict(rgb=torch.randn(B_, 3, 224, 224, generator=g), input_ids=ids, labels=labels, attention_mask=ids.ne(0))
+    return model, lora, P, batch
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("targets,r,train_pooler", [(("q", "k", "v", "o"), 8, False), (("q", "k", "v", "o", "gate", "up", "down"), 16, True)])
+def test_lora_forward_backward_and_adamw(targets, r, train_pooler):
+    model, lora, P, batch = make(targets, r, train_pooler)
+    assert lora.num_parameters() == 2 * r * sum({"q": 8192, "k": 8192, "v": 8192, "o": 8192, "gate": 15104, "up": 15104, "down": 15104}[t] for t in targets)
+    eng = LHRSEngine(model, optimizer="adamw", lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
+    out = eng(batch)
+    eng.backward(out["total_loss"])
+    torch.cuda.synchronize()
+    loss = O.unibind_forward(P, batch)
+    loss.backward()
+    assert abs(out["total_loss"].item() - loss.item()) < 3e-3 * loss.item()
+    for l in range(2):
+        for pr in targets:
+            dA, dB = lora.grad_adapter(l, pr)
+            Ao, Bo = P["llama"]["layers"][l]["lora"][pr]
+            assert rel(dA, Ao.grad) < 5e-2, (l, pr, "dA")
+            assert rel(dB, Bo.grad) < 5e-2, (l, pr, "dB")
+    # everything outside the adapter blocks stays exactly zero (padding rows, off-diagonal blocks of the stacked B)
+    tot = sum(float(g.float().pow(2).sum()) for l in range(2) for pr in targets for g in lora.grad_adapter(l, pr))
+    assert abs(float(lora.grad.pow(2).sum()) - tot) <= 1e-6 * tot
+    if not train_pooler:
+        assert len(eng.stores) == 1 and eng.stores[0].name == "lora"
+    # one AdamW step with the DeepSpeed clip: compare against the restated update on the engine's own gradients
+    g_all = torch.cat([s.grad.flatten() for s in eng.stores]).double().cpu()
+    before = [dict(p=s.master.double().cpu().clone(), m=torch.zeros(s.numel).double(), v=torch.zeros(s.numel).double()) for s in eng.stores]
+    coef = min(1.0, 1.0 / (g_all.norm().item() + 1e-6))
+    eng.step()
+    torch.cuda.synchronize()
+    for s, st in zip(eng.stores, before):
+        adamw_step_ref(st, s.grad.double().cpu() * coef, 1, lr=1e-3, betas=(0.9, 0.95), wd=0.0)
+        assert (s.master.double().cpu() - st["p"]).abs().max() < 2e-6
+        assert torch.equal(s.shadow, s.master.to(torch.bfloat16))
+    # the refreshed operands are used by the next forward: loss must change and stay finite
+    out2 = eng(batch)
+    assert torch.isfinite(out2["total_loss"]) and out2["total_loss"].item() != out["total_loss"].item()
