@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--caption-tokens", type=int, default=128)
     ap.add_argument("--llama-layers", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage", type=int, default=1, choices=[1, 2, 3],
+                    help="1: projector-only + Adan (the headline metric, BASELINE configs[1..2]); 3: LoRA r=8 on q,k,v,o + AdamW, projector "
+                         "frozen (BASELINE configs[3]); 2: LoRA r=128 on every linear + projector, AdamW (Config/multi_modal_stage2.yaml)")
     ap.add_argument("--comm-dtype", default="float32", choices=["float32", "bfloat16"])
     a = ap.parse_args()
 
@@ -123,9 +126,17 @@ def main():
     B, T = a.micro_batch, a.caption_tokens + 2
     S = T - 1 + 144
     model = UniBind(("rgb", "text"), None, device=dev, llama_layers=a.llama_layers).init_random(seed=0)  # same weights on every rank
-    model.prepare_for_training()
-    engine = LHRSEngine(model, optimizer="adanp", lr=2e-4, weight_decay=0.0, max_grad_norm=0.3,
-                        comm_dtype=getattr(torch, a.comm_dtype))
+    if a.stage == 1:
+        model.prepare_for_training()
+        engine = LHRSEngine(model, optimizer="adanp", lr=2e-4, weight_decay=0.0, max_grad_norm=0.3, comm_dtype=getattr(torch, a.comm_dtype))
+    else:
+        if a.stage == 3:
+            model.enable_lora(r=8, alpha=16, targets=("q", "k", "v", "o"))
+        else:
+            model.enable_lora(r=128, alpha=256)
+        model.prepare_for_training(freeze_text=False, tune_rgb_pooler=a.stage == 2)
+        engine = LHRSEngine(model, optimizer="adamw", lr=1e-4 if a.stage == 3 else 2e-4, weight_decay=0.0, max_grad_norm=1.0,
+                            comm_dtype=getattr(torch, a.comm_dtype))
     batch = make_batch(B, T, dev, seed=322 + rank)  # reference seed convention (main_pretrain_stage1.py:281-287)
 
     def step():
@@ -168,15 +179,18 @@ def main():
         if os.path.exists(tpath) and B == 30 and scale_layers == 1.0:
             traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
         res = {
-            "metric": "stage-1 pretrain samples/sec (224^2 image + 128-tok caption)", "value": round(sps, 3), "unit": "samples/s",
+            "metric": ("stage-1 pretrain samples/sec (224^2 image + 128-tok caption)" if a.stage == 1 else
+                       f"stage-{a.stage} LoRA train samples/sec (224^2 image + 128-tok sequence)"), "value": round(sps, 3), "unit": "samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: stage-1 projector-only, CLIP ViT-L/14@224 + AttnPooler + LLaMA2-7B "
                                    f"({a.llama_layers} layers), S={S}, random-init weights",
                        "micro_batch_per_gpu": B, "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
-                       "optimizer": "adanp", "grad_allreduce": a.comm_dtype if world > 1 else "none"},
+                       "optimizer": "adanp" if a.stage == 1 else "adamw", "stage": a.stage,
+                       "lora": None if a.stage == 1 else ("r=8 on q,k,v,o" if a.stage == 3 else "r=128 on all 7 linears"),
+                       "grad_allreduce": a.comm_dtype if world > 1 else "none"},
             "loss": round(final_loss, 4),
-            "step_mfma_frac": round(sps / world * f_alg(S) / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 else None,
+            "step_mfma_frac": round(sps / world * f_alg(S) / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 and a.stage == 1 else None,
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_256p_kernel (256x256 tile, 4-stage BK=32 LDS ring, v_mfma_f32_32x32x16_bf16)", "achieved": round(ach, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "launches_timed": int(n_samp), "avg_launch_us": round(1e3 * ms / max(n_samp, 1), 2),
