@@ -128,6 +128,19 @@ int lhrs_argmax_rows(const float* x, long ld, long* out, int n, int V, void* str
 int lhrs_cross_entropy(const void* logits, long ld, const int* target, float* row_loss, float* loss_out, void* dlogits,
                        long ld_d, int n, int V, void* stream);
 
+/* ---- single-token decode (TextModal.generate with use_cache, lhrs/models/text_modal.py:586-627; cli_qa.py:176-186) ---- *
+ * gemv: y[B,N] = x[B,K] . W[N,K]^T (+ residual), B <= 8 - HBM-bound weight streaming.  decode_advance / kv_append keep the
+ * context length on the device so that one captured hipGraph (lhrs_graph_*) replays for every generated token.        */
+int lhrs_gemv_bf16(const void* W, long ldw, const void* x, long ldx, const void* residual, long ldr, void* y, long ldy, int B,
+                   int N, int K, int out_f32, void* stream);
+int lhrs_decode_advance(int* state, int* desc, int* pos, int B, int max_ctx, int step_inc, void* stream);
+int lhrs_kv_append(const void* qkv, long ld, void* kcache, void* vcache, const int* pos, int B, int d, int max_ctx, void* stream);
+int lhrs_decode_emit(const long* next_ids, int* tok32, long* out_ids, int* state, int B, int max_new, void* stream);
+int lhrs_graph_begin(void* stream);
+int lhrs_graph_end(void* stream, void** exec_out);
+int lhrs_graph_launch(void* exec, void* stream);
+int lhrs_graph_destroy(void* exec);
+
 /* ---- optimizer -------------------------------------------------------------------------------------- *
  * Adan(no_prox) = timm "adanp" built at lhrs/optimizer/build_optimizer.py:76-86; AdamW + global-norm clip =
  * DeepSpeed engine.step() configured at main_pretrain_stage1.py:28-85 and driven by

@@ -313,9 +313,9 @@ def scatter_rows(src, idx, dst):
     return dst
 
 
-def argmax_rows(logits_f32):
+def argmax_rows(logits_f32, out=None):
     n, V = logits_f32.shape
-    out = torch.empty(n, device=logits_f32.device, dtype=torch.int64)
+    out = torch.empty(n, device=logits_f32.device, dtype=torch.int64) if out is None else out
     _lib.check(_L().lhrs_argmax_rows(logits_f32.data_ptr(), logits_f32.stride(0), out.data_ptr(), n, V, _stream()), "argmax_rows")
     return out
 
@@ -331,6 +331,58 @@ def cross_entropy(logits, target, want_grad=True, inplace=True):
                                  _p(dl), dl.stride(0) if dl is not None else 0, n, V, _stream())
     _lib.check(st, "cross_entropy")
     return loss, dl
+
+
+# --------------------------------------------------------------------------------------------- decode
+def gemv(W, x, out, residual=None, out_f32=False):
+    """out[B, N] = x[B, K] @ W[N, K]^T (+ residual): batch <= 8 weight-streaming kernel of the decode step."""
+    B, K = x.shape
+    N = W.shape[0]
+    st = _L().lhrs_gemv_bf16(W.data_ptr(), W.stride(0), x.data_ptr(), x.stride(0), _p(residual),
+                             residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0), B, N, K, int(out_f32),
+                             _stream())
+    _lib.check(st, "gemv_bf16")
+    return out
+
+
+def decode_advance(state, desc, pos, B, max_ctx, inc=1):
+    _lib.check(_L().lhrs_decode_advance(state.data_ptr(), desc.data_ptr(), pos.data_ptr(), B, max_ctx, inc, _stream()), "decode_advance")
+
+
+def kv_append(qkv, kc, vc, pos, B, d, max_ctx):
+    _lib.check(_L().lhrs_kv_append(qkv.data_ptr(), qkv.stride(0), kc.data_ptr(), vc.data_ptr(), pos.data_ptr(), B, d, max_ctx, _stream()),
+               "kv_append")
+
+
+def decode_emit(next_ids, tok32, out_ids, state, B, max_new):
+    _lib.check(_L().lhrs_decode_emit(next_ids.data_ptr(), tok32.data_ptr(), out_ids.data_ptr(), state.data_ptr(), B, max_new, _stream()),
+               "decode_emit")
+
+
+class HipGraph:
+    """hipGraph capture / replay of the launches enqueued on the current (non-default) HIP stream."""
+
+    def __init__(self):
+        self.exec = None
+
+    def begin(self):
+        _lib.check(_L().lhrs_graph_begin(_stream()), "graph_begin")
+
+    def end(self):
+        import ctypes
+        h = ctypes.c_void_p()
+        _lib.check(_L().lhrs_graph_end(_stream(), ctypes.byref(h)), "graph_end")
+        self.exec = h.value
+
+    def launch(self):
+        _lib.check(_L().lhrs_graph_launch(self.exec, _stream()), "graph_launch")
+
+    def __del__(self):
+        try:
+            if self.exec:
+                _L().lhrs_graph_destroy(self.exec)
+        except Exception:
+            pass
 
 
 # --------------------------------------------------------------------------------------------- optimizer

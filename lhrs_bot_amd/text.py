@@ -11,6 +11,7 @@ Activation memory per layer and token: x_in, x_mid, o (3 x 4096), qkv (12288), g
 from __future__ import annotations
 
 import math
+import types
 from typing import Dict, List, Optional
 
 import torch
@@ -310,65 +311,166 @@ class TextModal:
         act = hk.swiglu_fwd(hk.gemm_nt(h, L["gu_w"]), ff)
         return hk.gemm_nt(act, L["down_w"], residual=x)
 
+    def _decode_session(self, B, max_ctx, caches, max_new):
+        """Static buffers + one captured hipGraph for the single-token step (batch <= 8): embedding gather, 32 x [RMSNorm,
+        QKV GEMV, RoPE, KV append, attention over the cache, O GEMV + residual, RMSNorm, gate|up GEMV, SwiGLU, down GEMV +
+        residual], final norm, lm_head GEMV -> fp32 logits.  Context length / positions live on the device
+        (decode_advance), so the graph is captured once and replayed for every token."""
+        dev, d, ff, H, hd, V = self.device, self.d, self.ff, self.heads, self.hd, self.vocab
+        bf = torch.bfloat16
+        s = types.SimpleNamespace()
+        s.B, s.max_ctx, s.max_new, s.caches = B, max_ctx, max_new, caches
+        s.x, s.x2, s.h, s.o = (torch.zeros((B, d), device=dev, dtype=bf) for _ in range(4))
+        s.qkv = torch.zeros((B, 3 * d), device=dev, dtype=bf)
+        s.gu = torch.zeros((B, 2 * ff), device=dev, dtype=bf)
+        s.act = torch.zeros((B, ff), device=dev, dtype=bf)
+        s.logits = torch.zeros((B, V), device=dev, dtype=torch.float32)
+        s.next_ids = torch.zeros(B, device=dev, dtype=torch.int64)
+        s.tok32 = torch.zeros(B, device=dev, dtype=torch.int32)
+        s.out_ids = torch.zeros((B, max_new), device=dev, dtype=torch.int64)
+        s.state = torch.zeros(4, device=dev, dtype=torch.int32)
+        s.desc = torch.zeros((B, 8), device=dev, dtype=torch.int32)
+        s.pos = torch.zeros(B, device=dev, dtype=torch.int32)
+        scale = 1.0 / math.sqrt(hd)
+
+        def enqueue():
+            hk.decode_advance(s.state, s.desc, s.pos, B, max_ctx, 1)
+            hk.gather_rows(self.p["embed"], s.tok32, out=s.x)
+            x, x2 = s.x, s.x2
+            for L, (kc, vc) in zip(self.p["layers"], caches):
+                hk.rmsnorm_fwd(x, L["ln1_w"], self.eps, out=s.h)
+                hk.gemv(L["qkv_w"], s.h, s.qkv)
+                hk.rope_(s.qkv, B, 2 * H, hd, self.cos, self.sin, pos_mod=1, pos_ids=s.pos)
+                hk.kv_append(s.qkv, kc, vc, s.pos, B, d, max_ctx)
+                hk.attn_fwd(s.qkv[:, :d], kc, vc, s.o, None, s.desc, B, H, hd, 1, 1 << 30, 64, True, scale)
+                hk.gemv(L["o_w"], s.o, x2, residual=x)
+                hk.rmsnorm_fwd(x2, L["ln2_w"], self.eps, out=s.h)
+                hk.gemv(L["gu_w"], s.h, s.gu)
+                hk.swiglu_fwd(s.gu, ff, out=s.act)
+                hk.gemv(L["down_w"], s.act, x, residual=x2)
+            hk.rmsnorm_fwd(x, self.p["norm_w"], self.eps, out=s.h)
+            hk.gemv(self.p["lm_head"], s.h, s.logits, out_f32=True)
+
+        s.enqueue = enqueue
+        s.graph = None
+        return s
+
     @torch.no_grad()
     def generate(self, input_ids, image_embedding=None, attention_mask=None, do_sample=False, temperature=1.0, top_p=None,
                  top_k=None, max_new_tokens=512, use_cache=True, stopping_criteria=None, streamer=None, eos_token_id=None,
-                 return_logits=False, **_kw):
+                 return_logits=False, use_graph=True, **_kw):
         """TextModal.generate (text_modal.py:528-627): prefill over the spliced embeddings, then one token at a time with
         a KV cache; returns only the NEW token ids [B, n_new] (HF generate started from inputs_embeds).  Greedy
         (do_sample=False, the evaluation scripts' mode) runs entirely in HIP kernels; with do_sample=True the HIP-computed
-        fp32 logits go through HF's temperature / top-k / top-p warpers and one multinomial draw per token."""
+        fp32 logits go through HF's temperature / top-k / top-p warpers and one multinomial draw per token.  The
+        single-token step is a captured hipGraph over static buffers (batch <= 8); without eos / stopping criteria / streamer
+        the host never synchronises inside the loop."""
         embeds, _, mask, _ = self.prepare_inputs_for_multimodal(input_ids, attention_mask, None, image_embedding)
         B, S0, d = embeds.shape
         if mask is not None and not bool(mask.bool().all()):
             raise NotImplementedError("padded prompts in generate (batched eval with left padding) - SURVEY.md §8 f-3")
         max_ctx = S0 + max_new_tokens
-        dev, nl = self.device, len(self.p["layers"])
+        dev = self.device
         caches = [(torch.empty((B * max_ctx, d), device=dev, dtype=torch.bfloat16), torch.empty((B * max_ctx, d), device=dev, dtype=torch.bfloat16))
-                  for _ in range(nl)]
-        out_ids, all_logits = [], []
-        finished = torch.zeros(B, dtype=torch.bool, device=dev)
+                  for _ in range(len(self.p["layers"]))]
+
+        def pick(logits):
+            if not do_sample:
+                return hk.argmax_rows(logits)
+            z = logits / max(float(temperature), 1e-6)
+            if top_k:
+                kth = torch.topk(z, int(top_k), dim=-1).values[:, -1:]
+                z = z.masked_fill(z < kth, float("-inf"))
+            if top_p is not None and top_p < 1.0:
+                sz, si = torch.sort(z, descending=False, dim=-1)
+                cp = torch.softmax(sz, -1).cumsum(-1)
+                rm = cp <= (1 - top_p)
+                rm[:, -1] = False
+                z = z.masked_fill(rm.scatter(1, si, rm), float("-inf"))
+            return torch.multinomial(torch.softmax(z, -1), 1).squeeze(1)
+
+        # ---- prefill (GEMM path) -> logits of the last prompt position -> first new token
+        desc = hk.make_desc([(b * S0, S0, b * max_ctx, S0, S0, 0) for b in range(B)], dev)
         x = embeds.reshape(B * S0, d)
-        ctx, S_new = 0, S0
-        for step in range(max_new_tokens):
-            desc = hk.make_desc([(b * S_new, S_new, b * max_ctx, ctx + S_new, ctx + S_new, ctx) for b in range(B)], dev)
-            for L, cache in zip(self.p["layers"], caches):
-                x = self._layer_step(L, x, B, S_new, ctx, cache, desc, max_ctx)
-            last = x.view(B, S_new, d)[:, -1].contiguous()
-            hn = hk.rmsnorm_fwd(last, self.p["norm_w"], self.eps)
-            logits = hk.gemm_nt(hn, self.p["lm_head"], out_f32=True)  # [B, V] fp32 (HF: logits.float())
-            if return_logits:
-                all_logits.append(logits.clone())
-            if do_sample:
-                z = logits / max(float(temperature), 1e-6)
-                if top_k:
-                    kth = torch.topk(z, int(top_k), dim=-1).values[:, -1:]
-                    z = z.masked_fill(z < kth, float("-inf"))
-                if top_p is not None and top_p < 1.0:
-                    sz, si = torch.sort(z, descending=False, dim=-1)
-                    cp = torch.softmax(sz, -1).cumsum(-1)
-                    rm = cp <= (1 - top_p)
-                    rm[:, -1] = False
-                    z = z.masked_fill(rm.scatter(1, si, rm), float("-inf"))
-                nxt = torch.multinomial(torch.softmax(z, -1), 1).squeeze(1)
-            else:
-                nxt = hk.argmax_rows(logits)
-            if eos_token_id is not None:
-                nxt = torch.where(finished, torch.full_like(nxt, self.tokenizer.pad_token_id), nxt)
-                finished |= nxt == eos_token_id
-            out_ids.append(nxt)
+        for L, cache in zip(self.p["layers"], caches):
+            x = self._layer_step(L, x, B, S0, 0, cache, desc, max_ctx)
+        hn = hk.rmsnorm_fwd(x.view(B, S0, d)[:, -1].contiguous(), self.p["norm_w"], self.eps)
+        logits = hk.gemm_nt(hn, self.p["lm_head"], out_f32=True)  # [B, V] fp32 (HF: logits.float())
+        all_logits = [logits.clone()] if return_logits else []
+        nxt = pick(logits)
+
+        host_checks = eos_token_id is not None or stopping_criteria is not None or streamer is not None
+        finished = torch.zeros(B, dtype=torch.bool, device=dev)
+
+        def host_step(ids_so_far, lg):  # -> stop?
+            nonlocal finished
             if streamer is not None:
-                streamer.put(nxt.cpu())
-            ids_so_far = torch.stack(out_ids, 1)
-            if (eos_token_id is not None and bool(finished.all())) or (
-                    stopping_criteria is not None and any(c(ids_so_far, logits) for c in stopping_criteria)):
-                break
-            ctx += S_new
-            S_new = 1
-            x = hk.gather_rows(self.p["embed"], nxt.clamp(0, self.vocab - 1).to(torch.int32))
+                streamer.put(ids_so_far[:, -1].cpu())
+            if eos_token_id is not None:
+                finished |= ids_so_far[:, -1] == eos_token_id
+                if bool(finished.all()):
+                    return True
+            return stopping_criteria is not None and any(c(ids_so_far, lg) for c in stopping_criteria)
+
+        n_done = 1
+        if B <= 8:
+            s = self._decode_session(B, max_ctx, caches, max_new_tokens)
+            s.state[0], s.state[1] = S0, 0
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                s.next_ids.copy_(nxt)
+                hk.decode_emit(s.next_ids, s.tok32, s.out_ids, s.state, B, max_new_tokens)
+                stop = host_checks and host_step(s.out_ids[:, :1], logits)
+                while not stop and n_done < max_new_tokens:
+                    if use_graph and s.graph is None and n_done >= 2:  # one eager step first (lazy kernel attributes), then capture
+                        g = hk.HipGraph()
+                        g.begin()
+                        s.enqueue()
+                        g.end()
+                        s.graph = g
+                        s.graph.launch()
+                    elif s.graph is not None:
+                        s.graph.launch()
+                    else:
+                        s.enqueue()
+                    if return_logits:
+                        all_logits.append(s.logits.clone())
+                    if do_sample:
+                        s.next_ids.copy_(pick(s.logits))
+                    else:
+                        hk.argmax_rows(s.logits, out=s.next_ids)
+                    if eos_token_id is not None:
+                        s.next_ids.copy_(torch.where(finished, torch.full_like(s.next_ids, self.tokenizer.pad_token_id), s.next_ids))
+                    hk.decode_emit(s.next_ids, s.tok32, s.out_ids, s.state, B, max_new_tokens)
+                    n_done += 1
+                    if host_checks:
+                        stop = host_step(s.out_ids[:, :n_done], s.logits)
+            torch.cuda.current_stream().wait_stream(side)
+            ids = s.out_ids[:, :n_done].clone()
+        else:
+            out_ids = [nxt]
+            ctx = S0
+            stop = host_checks and host_step(torch.stack(out_ids, 1), logits)
+            while not stop and n_done < max_new_tokens:
+                x = hk.gather_rows(self.p["embed"], out_ids[-1].clamp(0, self.vocab - 1).to(torch.int32))
+                desc = hk.make_desc([(b, 1, b * max_ctx, ctx + 1, ctx + 1, ctx) for b in range(B)], dev)
+                for L, cache in zip(self.p["layers"], caches):
+                    x = self._layer_step(L, x, B, 1, ctx, cache, desc, max_ctx)
+                logits = hk.gemm_nt(hk.rmsnorm_fwd(x, self.p["norm_w"], self.eps), self.p["lm_head"], out_f32=True)
+                if return_logits:
+                    all_logits.append(logits.clone())
+                nxt = pick(logits)
+                if eos_token_id is not None:
+                    nxt = torch.where(finished, torch.full_like(nxt, self.tokenizer.pad_token_id), nxt)
+                out_ids.append(nxt)
+                ctx += 1
+                n_done += 1
+                if host_checks:
+                    stop = host_step(torch.stack(out_ids, 1), logits)
+            ids = torch.stack(out_ids, 1)
         if streamer is not None:
             streamer.end()
-        ids = torch.stack(out_ids, 1)
         return (ids, torch.stack(all_logits, 1)) if return_logits else ids
 
     # ------------------------------------------------------------------ backward (activation gradients only)

@@ -57,3 +57,24 @@ def test_sampling_path_runs_and_respects_eos():
     first = model.generate(ids, images=rgb, do_sample=False, max_new_tokens=4)
     stop = model.generate(ids, images=rgb, do_sample=False, max_new_tokens=4, eos_token_id=int(first[0, 1]))
     assert stop.shape[1] == 2 and torch.equal(stop[0], first[0, :2])
+
+
+def test_gemv_and_graph_decode_equal_eager_decode():
+    g = torch.Generator().manual_seed(3)
+    W = (torch.randn(4096, 11008, generator=g) * 0.02).to(DEV, torch.bfloat16)
+    for B in (1, 3, 8):
+        x = torch.randn(B, 11008, generator=g).to(DEV, torch.bfloat16)
+        res = torch.randn(B, 4096, generator=g).to(DEV, torch.bfloat16)
+        y = torch.empty(B, 4096, device=DEV, dtype=torch.bfloat16)
+        hk.gemv(W, x, y, residual=res)
+        ref = x.float() @ W.float().t() + res.float()
+        assert rel(y, ref) < 4e-3
+        y32 = torch.empty(B, 4096, device=DEV, dtype=torch.float32)
+        hk.gemv(W, x, y32, out_f32=True)
+        assert rel(y32, x.float() @ W.float().t()) < 1e-5
+    model = UniBind(("rgb", "text"), None, device=DEV, llama_layers=2).init_random(seed=1).eval()
+    ids = torch.tensor([[1, -200, 9, 8, 7, 6], [1, -200, 5, 4, 3, 2]])
+    rgb = torch.randn(2, 3, 224, 224, generator=g)
+    a_ids, a_lg = model.generate(ids, images=rgb, do_sample=False, max_new_tokens=9, return_logits=True, use_graph=True)
+    b_ids, b_lg = model.generate(ids, images=rgb, do_sample=False, max_new_tokens=9, return_logits=True, use_graph=False)
+    assert torch.equal(a_ids, b_ids) and torch.equal(a_lg, b_lg)   # replayed graph == eager launches, bit for bit
