@@ -133,6 +133,11 @@ int lhrs_cross_entropy(const void* logits, long ld, const int* target, float* ro
  * context length on the device so that one captured hipGraph (lhrs_graph_*) replays for every generated token.        */
 int lhrs_gemv_bf16(const void* W, long ldw, const void* x, long ldx, const void* residual, long ldr, void* y, long ldy, int B,
                    int N, int K, int out_f32, void* stream);
+int lhrs_gemv(const void* W, long ldw, const float* wscale, int w_fp8, const void* x, long ldx, int prologue, const void* norm_w,
+              float eps, const void* residual, long ldr, void* y, long ldy, int B, int N, int K, int out_f32, void* stream);
+int lhrs_quant_fp8_rows(const void* W, long ldw, void* W8, long ld8, float* scale, int N, int K, void* stream);
+int lhrs_rope_kv_append(void* qkv, long ld, void* kcache, void* vcache, const float* cos_t, const float* sin_t, const int* pos, int B,
+                        int H, int D, int max_ctx, void* stream);
 int lhrs_decode_advance(int* state, int* desc, int* pos, int B, int max_ctx, int step_inc, void* stream);
 int lhrs_kv_append(const void* qkv, long ld, void* kcache, void* vcache, const int* pos, int B, int d, int max_ctx, void* stream);
 int lhrs_decode_emit(const long* next_ids, int* tok32, long* out_ids, int* state, int B, int max_new, void* stream);

@@ -11,40 +11,104 @@
 
 namespace {
 
-template <int NB>  // batch rows of x handled together (weights are read once for all of them)
-__global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W, long ldw, const bf16_t* __restrict__ x, long ldx,
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+// PRO: what the block does to the activation rows while staging them in LDS (every block redoes it: 8-22 KB from L2)
+//   0 plain copy            1 RMSNorm (HF LlamaRMSNorm: w * bf16(x * rsqrt(mean x^2 + eps)))       2 SwiGLU: silu(x[k]) * x[K + k]
+// FP8: W is OCP e4m3 with one fp32 scale per output row (the 6.7 GB / token weight stream of SURVEY.md §8d)
+template <int NB, int PRO, bool FP8>
+__global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, long ldw, const float* __restrict__ wscale,
+                                                   const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ norm_w, float eps,
                                                    const bf16_t* res, long ldr, void* y, long ldy, int N, int K, int out_f32) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float red[4];
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);  // [NB][K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nch = K / 8;
-  for (int b = 0; b < NB; ++b)
-    for (int c = tid; c < nch; c += 256) *reinterpret_cast<uint4*>(xs + b * K + c * 8) = *reinterpret_cast<const uint4*>(x + b * ldx + c * 8);
+  for (int b = 0; b < NB; ++b) {
+    if (PRO == 2) {
+      for (int c = tid; c < nch; c += 256) {
+        const uint4 g = *reinterpret_cast<const uint4*>(x + b * ldx + c * 8);
+        const uint4 u = *reinterpret_cast<const uint4*>(x + b * ldx + K + c * 8);
+        uint4 o;
+        o.x = pack2bf(silu(bflo(g.x)) * bflo(u.x), silu(bfhi(g.x)) * bfhi(u.x));
+        o.y = pack2bf(silu(bflo(g.y)) * bflo(u.y), silu(bfhi(g.y)) * bfhi(u.y));
+        o.z = pack2bf(silu(bflo(g.z)) * bflo(u.z), silu(bfhi(g.z)) * bfhi(u.z));
+        o.w = pack2bf(silu(bflo(g.w)) * bflo(u.w), silu(bfhi(g.w)) * bfhi(u.w));
+        *reinterpret_cast<uint4*>(xs + b * K + c * 8) = o;
+      }
+    } else {
+      float q = 0.f;
+      for (int c = tid; c < nch; c += 256) {
+        const uint4 v = *reinterpret_cast<const uint4*>(x + b * ldx + c * 8);
+        *reinterpret_cast<uint4*>(xs + b * K + c * 8) = v;
+        if (PRO == 1)
+          q += bflo(v.x) * bflo(v.x) + bfhi(v.x) * bfhi(v.x) + bflo(v.y) * bflo(v.y) + bfhi(v.y) * bfhi(v.y) + bflo(v.z) * bflo(v.z) +
+               bfhi(v.z) * bfhi(v.z) + bflo(v.w) * bflo(v.w) + bfhi(v.w) * bfhi(v.w);
+      }
+      if (PRO == 1) {
+        const float rstd = rsqrtf(block_sum<4>(q, red) / (float)K + eps);
+        __syncthreads();
+        for (int c = tid; c < K; c += 256) xs[b * K + c] = f2bf(bf2f(norm_w[c]) * bf2f(f2bf(bf2f(xs[b * K + c]) * rstd)));
+      }
+    }
+  }
   __syncthreads();
-  const int rows_per_block = 4 * 4;  // 4 waves x 4 rows in flight per wave
-  const int row0 = blockIdx.x * rows_per_block + wave * 4;
+  const int row0 = blockIdx.x * 16 + wave * 4;  // 4 waves x 4 rows in flight per wave
   float acc[4][NB];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
-  for (int c = lane; c < nch; c += 64) {
-    uint4 w[4];
+  if (!FP8) {
+    const bf16_t* W = reinterpret_cast<const bf16_t*>(Wv);
+    for (int c = lane; c < nch; c += 64) {
+      uint4 w[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = min(row0 + r, N - 1);
-      const i32x4 t = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(W + (long)row * ldw + c * 8));
-      w[r] = make_uint4((unsigned)t[0], (unsigned)t[1], (unsigned)t[2], (unsigned)t[3]);
+      for (int r = 0; r < 4; ++r) {
+        const int row = min(row0 + r, N - 1);
+        const i32x4 t = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(W + (long)row * ldw + c * 8));
+        w[r] = make_uint4((unsigned)t[0], (unsigned)t[1], (unsigned)t[2], (unsigned)t[3]);
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const uint4 xv = *reinterpret_cast<const uint4*>(xs + b * K + c * 8);
+        const float x0 = bflo(xv.x), x1 = bfhi(xv.x), x2 = bflo(xv.y), x3 = bfhi(xv.y), x4 = bflo(xv.z), x5 = bfhi(xv.z), x6 = bflo(xv.w),
+                    x7 = bfhi(xv.w);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[r][b] += bflo(w[r].x) * x0 + bfhi(w[r].x) * x1 + bflo(w[r].y) * x2 + bfhi(w[r].y) * x3 + bflo(w[r].z) * x4 +
+                       bfhi(w[r].z) * x5 + bflo(w[r].w) * x6 + bfhi(w[r].w) * x7;
+      }
     }
+  } else {
+    const uint8_t* W = reinterpret_cast<const uint8_t*>(Wv);
+    const int nch16 = K / 16;  // 16 fp8 per lane load
+    for (int c = lane; c < nch16; c += 64) {
+      i32x4 w[4];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const uint4 xv = *reinterpret_cast<const uint4*>(xs + b * K + c * 8);
-      const float x0 = bflo(xv.x), x1 = bfhi(xv.x), x2 = bflo(xv.y), x3 = bfhi(xv.y), x4 = bflo(xv.z), x5 = bfhi(xv.z), x6 = bflo(xv.w),
-                  x7 = bfhi(xv.w);
+      for (int r = 0; r < 4; ++r) {
+        const int row = min(row0 + r, N - 1);
+        w[r] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(W + (long)row * ldw + c * 16));
+      }
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        acc[r][b] += bflo(w[r].x) * x0 + bfhi(w[r].x) * x1 + bflo(w[r].y) * x2 + bfhi(w[r].y) * x3 + bflo(w[r].z) * x4 +
-                     bfhi(w[r].z) * x5 + bflo(w[r].w) * x6 + bfhi(w[r].w) * x7;
+      for (int b = 0; b < NB; ++b) {
+        float xf[16];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint4 xv = *reinterpret_cast<const uint4*>(xs + b * K + c * 16 + h * 8);
+          xf[h * 8 + 0] = bflo(xv.x); xf[h * 8 + 1] = bfhi(xv.x); xf[h * 8 + 2] = bflo(xv.y); xf[h * 8 + 3] = bfhi(xv.y);
+          xf[h * 8 + 4] = bflo(xv.z); xf[h * 8 + 5] = bfhi(xv.z); xf[h * 8 + 6] = bflo(xv.w); xf[h * 8 + 7] = bfhi(xv.w);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(w[r][j], false);
+            const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8(w[r][j], true);
+            acc[r][b] += lo[0] * xf[j * 4] + lo[1] * xf[j * 4 + 1] + hi[0] * xf[j * 4 + 2] + hi[1] * xf[j * 4 + 3];
+          }
+      }
     }
   }
 #pragma unroll
@@ -54,12 +118,70 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W,
       const float s = wave_sum(acc[r][b]);
       const int row = row0 + r;
       if (lane == 0 && row < N) {
-        float v = s;
+        float v = FP8 ? s * wscale[row] : s;
         if (res) v += bf2f(res[b * ldr + row]);
         if (out_f32) reinterpret_cast<float*>(y)[b * ldy + row] = v;
         else reinterpret_cast<bf16_t*>(y)[b * ldy + row] = f2bf(v);
       }
     }
+}
+
+// per-row e4m3 quantisation: scale[n] = max|W[n,:]| / 448, W8 = round(W / scale)
+__global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __restrict__ W, long ldw, uint8_t* __restrict__ W8, long ld8,
+                                                             float* __restrict__ scale, int K) {
+  __shared__ float red[4];
+  const int n = blockIdx.x;
+  float m = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) m = fmaxf(m, fabsf(bf2f(W[(long)n * ldw + k])));
+  m = block_max<4>(m, red);
+  const float sc = m > 0.f ? m / 448.f : 1.f;
+  if (threadIdx.x == 0) scale[n] = sc;
+  const float inv = 1.f / sc;
+  for (int k4 = threadIdx.x; k4 < K / 4; k4 += 256) {
+    const bf16_t* p = W + (long)n * ldw + k4 * 4;
+    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(p[0]) * inv, bf2f(p[1]) * inv, 0, false);
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(p[2]) * inv, bf2f(p[3]) * inv, pk, true);
+    *reinterpret_cast<int*>(W8 + (long)n * ld8 + k4 * 4) = pk;
+  }
+}
+
+// RoPE on the new q / k rows + append of (rotated k, v) to the cache at the device-resident position
+__global__ void rope_kv_append_kernel(bf16_t* qkv, long ld, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
+                                      const float* __restrict__ cos_t, const float* __restrict__ sin_t, const int* __restrict__ pos,
+                                      int H, int D, int max_ctx) {
+  const int b = blockIdx.y;
+  const int p = pos[b];
+  const int half = D / 2, d = H * D;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over 2*H*half/8 rope chunks, then d/8 v chunks
+  const int n_rope = 2 * H * (half / 8);
+  bf16_t* row = qkv + (long)b * ld;
+  if (idx < n_rope) {
+    const int c = idx % (half / 8), h = idx / (half / 8);  // h in [0, 2H): q heads then k heads
+    bf16_t* p1 = row + (long)h * D + c * 8;
+    bf16_t* p2 = p1 + half;
+    const uint4 a = *reinterpret_cast<const uint4*>(p1), bb = *reinterpret_cast<const uint4*>(p2);
+    const float av[8] = {bflo(a.x), bfhi(a.x), bflo(a.y), bfhi(a.y), bflo(a.z), bfhi(a.z), bflo(a.w), bfhi(a.w)};
+    const float bv[8] = {bflo(bb.x), bfhi(bb.x), bflo(bb.y), bfhi(bb.y), bflo(bb.z), bfhi(bb.z), bflo(bb.w), bfhi(bb.w)};
+    float o1[8], o2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float co = cos_t[(long)p * half + c * 8 + i], si = sin_t[(long)p * half + c * 8 + i];
+      o1[i] = av[i] * co - bv[i] * si;
+      o2[i] = bv[i] * co + av[i] * si;
+    }
+    const uint4 r1 = make_uint4(pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3]), pack2bf(o1[4], o1[5]), pack2bf(o1[6], o1[7]));
+    const uint4 r2 = make_uint4(pack2bf(o2[0], o2[1]), pack2bf(o2[2], o2[3]), pack2bf(o2[4], o2[5]), pack2bf(o2[6], o2[7]));
+    *reinterpret_cast<uint4*>(p1) = r1;
+    *reinterpret_cast<uint4*>(p2) = r2;
+    if (h >= H) {  // key head: also into the cache
+      bf16_t* kd = kc + ((long)b * max_ctx + p) * d + (long)(h - H) * D + c * 8;
+      *reinterpret_cast<uint4*>(kd) = r1;
+      *reinterpret_cast<uint4*>(kd + half) = r2;
+    }
+  } else if (idx < n_rope + d / 8) {
+    const int c = idx - n_rope;
+    *reinterpret_cast<uint4*>(vc + ((long)b * max_ctx + p) * d + c * 8) = *reinterpret_cast<const uint4*>(row + 2 * d + c * 8);
+  }
 }
 
 // state: int32 [4] = {ctx, -, -, -}; desc: int32 [B][8]; pos: int32 [B]
@@ -116,34 +238,68 @@ extern "C" int lhrs_decode_emit(const long* next_ids, int* tok32, long* out_ids,
 }
 
 // y[B, N] = x[B, K] . W[N, K]^T (+ residual[B, N]);  B <= 8, K % 8 == 0
-static int gemv_chunk(const bf16_t* W, long ldw, const bf16_t* x, long ldx, const bf16_t* residual, long ldr, void* y, long ldy,
-                      int B, int N, int K, int out_f32, hipStream_t s) {
+template <int PRO, bool FP8>
+static int gemv_chunk(const void* W, long ldw, const float* wscale, const bf16_t* x, long ldx, const bf16_t* norm_w, float eps,
+                      const bf16_t* residual, long ldr, void* y, long ldy, int B, int N, int K, int out_f32, hipStream_t s) {
   const dim3 grid(cdiv(N, 16)), blk(256);
   const size_t sm = (size_t)B * K * 2;
 #define GEMV_CASE(NB)                                                                                                   \
   case NB:                                                                                                              \
-    if (sm > 65536) (void)hipFuncSetAttribute((const void*)gemv_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-    hipLaunchKernelGGL((gemv_kernel<NB>), grid, blk, sm, s, W, ldw, x, ldx, residual, ldr, y, ldy, N, K, out_f32);       \
+    if (sm > 65536) (void)hipFuncSetAttribute((const void*)gemv_kernel<NB, PRO, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+    hipLaunchKernelGGL((gemv_kernel<NB, PRO, FP8>), grid, blk, sm, s, W, ldw, wscale, x, ldx, norm_w, eps, residual, ldr, y, ldy, N, K, out_f32); \
     break;
   switch (B) { GEMV_CASE(1) GEMV_CASE(2) GEMV_CASE(3) GEMV_CASE(4) GEMV_CASE(5) GEMV_CASE(6) GEMV_CASE(7) GEMV_CASE(8) }
 #undef GEMV_CASE
-  LHRS_CHECK_LAUNCH("gemv_bf16");
+  LHRS_CHECK_LAUNCH("gemv");
   return 0;
 }
 
-// y[B, N] = x[B, K] . W[N, K]^T (+ residual[B, N]);  B <= 8, K % 8 == 0.  Batches whose activations exceed the LDS are split.
-extern "C" int lhrs_gemv_bf16(const void* W, long ldw, const void* x, long ldx, const void* residual, long ldr, void* y, long ldy,
-                              int B, int N, int K, int out_f32, void* stream) {
-  LHRS_REQUIRE(B >= 1 && B <= 8 && N > 0 && K % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0, "gemv: B=%d N=%d K=%d", B, N, K);
+// y[B, N] = pro(x)[B, K] . W[N, K]^T (+ residual[B, N]);  B <= 8.  prologue: 0 none, 1 RMSNorm(norm_w, eps), 2 SwiGLU (x is [B, 2K]).
+// w_fp8 != 0: W is e4m3 bytes [N, ldw] with per-row scales `wscale` (lhrs_quant_fp8_rows).  Batches exceeding the LDS are split.
+extern "C" int lhrs_gemv(const void* W, long ldw, const float* wscale, int w_fp8, const void* x, long ldx, int prologue,
+                         const void* norm_w, float eps, const void* residual, long ldr, void* y, long ldy, int B, int N, int K,
+                         int out_f32, void* stream) {
+  LHRS_REQUIRE(B >= 1 && B <= 8 && N > 0 && K % 16 == 0 && ldx % 8 == 0, "gemv: B=%d N=%d K=%d", B, N, K);
+  LHRS_REQUIRE(w_fp8 ? (ldw % 16 == 0 && wscale != nullptr) : (ldw % 8 == 0), "gemv: weight stride / scales");
+  LHRS_REQUIRE(prologue >= 0 && prologue <= 2 && (prologue != 1 || norm_w != nullptr), "gemv: prologue %d", prologue);
   const int bmax = (int)((152L * 1024) / ((long)K * 2));
   LHRS_REQUIRE(bmax >= 1, "gemv: one activation vector does not fit LDS (K=%d)", K);
   const long esz = out_f32 ? 4 : 2;
+  hipStream_t s = (hipStream_t)stream;
   for (int b0 = 0; b0 < B; b0 += bmax) {
     const int nb = B - b0 < bmax ? B - b0 : bmax;
-    if (gemv_chunk((const bf16_t*)W, ldw, (const bf16_t*)x + b0 * ldx, ldx, residual ? (const bf16_t*)residual + b0 * ldr : nullptr, ldr,
-                   (char*)y + b0 * ldy * esz, ldy, nb, N, K, out_f32, (hipStream_t)stream))
-      return -1;
+    const bf16_t* xb = (const bf16_t*)x + b0 * ldx;
+    const bf16_t* rb = residual ? (const bf16_t*)residual + b0 * ldr : nullptr;
+    void* yb = (char*)y + b0 * ldy * esz;
+    int rc;
+#define GO(P, F) rc = gemv_chunk<P, F>(W, ldw, wscale, xb, ldx, (const bf16_t*)norm_w, eps, rb, ldr, yb, ldy, nb, N, K, out_f32, s)
+    if (w_fp8) { if (prologue == 0) GO(0, true); else if (prologue == 1) GO(1, true); else GO(2, true); }
+    else { if (prologue == 0) GO(0, false); else if (prologue == 1) GO(1, false); else GO(2, false); }
+#undef GO
+    if (rc) return -1;
   }
+  return 0;
+}
+
+extern "C" int lhrs_gemv_bf16(const void* W, long ldw, const void* x, long ldx, const void* residual, long ldr, void* y, long ldy,
+                              int B, int N, int K, int out_f32, void* stream) {
+  return lhrs_gemv(W, ldw, nullptr, 0, x, ldx, 0, nullptr, 0.f, residual, ldr, y, ldy, B, N, K, out_f32, stream);
+}
+
+extern "C" int lhrs_quant_fp8_rows(const void* W, long ldw, void* W8, long ld8, float* scale, int N, int K, void* stream) {
+  LHRS_REQUIRE(N > 0 && K % 16 == 0 && ld8 % 16 == 0, "quant_fp8_rows: N=%d K=%d ld8=%ld", N, K, ld8);
+  hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W, ldw, (uint8_t*)W8, ld8, scale, K);
+  LHRS_CHECK_LAUNCH("quant_fp8_rows");
+  return 0;
+}
+
+extern "C" int lhrs_rope_kv_append(void* qkv, long ld, void* kcache, void* vcache, const float* cos_t, const float* sin_t,
+                                   const int* pos, int B, int H, int D, int max_ctx, void* stream) {
+  LHRS_REQUIRE(B >= 1 && D % 16 == 0, "rope_kv_append: B=%d D=%d", B, D);
+  const int work = 2 * H * (D / 16) + H * D / 8;
+  hipLaunchKernelGGL(rope_kv_append_kernel, dim3(cdiv(work, 256), B), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv, ld,
+                     (bf16_t*)kcache, (bf16_t*)vcache, cos_t, sin_t, pos, H, D, max_ctx);
+  LHRS_CHECK_LAUNCH("rope_kv_append");
   return 0;
 }
 

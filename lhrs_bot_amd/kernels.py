@@ -345,6 +345,33 @@ def gemv(W, x, out, residual=None, out_f32=False):
     return out
 
 
+PRO_NONE, PRO_RMSNORM, PRO_SWIGLU = 0, 1, 2
+
+
+def gemv_fused(W, x, out, K, *, wscale=None, prologue=PRO_NONE, norm_w=None, eps=1e-5, residual=None, out_f32=False):
+    """out[B, N] = pro(x)[B, K] @ W[N, K]^T (+ residual).  W: bf16 [N, K] or (wscale given) e4m3 bytes [N, K] with per-row scales."""
+    B, N = x.shape[0], W.shape[0]
+    st = _L().lhrs_gemv(W.data_ptr(), W.stride(0), _p(wscale), int(wscale is not None), x.data_ptr(), x.stride(0), prologue, _p(norm_w),
+                        float(eps), _p(residual), residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0), B, N, K,
+                        int(out_f32), _stream())
+    _lib.check(st, "gemv")
+    return out
+
+
+def quant_fp8_rows(W):
+    """bf16 [N, K] -> (uint8 e4m3 [N, K], fp32 per-row scale [N])."""
+    N, K = W.shape
+    W8 = torch.empty((N, K), device=W.device, dtype=torch.uint8)
+    sc = torch.empty(N, device=W.device, dtype=torch.float32)
+    _lib.check(_L().lhrs_quant_fp8_rows(W.data_ptr(), W.stride(0), W8.data_ptr(), W8.stride(0), sc.data_ptr(), N, K, _stream()), "quant_fp8_rows")
+    return W8, sc
+
+
+def rope_kv_append(qkv, kc, vc, cos_t, sin_t, pos, B, H, D, max_ctx):
+    _lib.check(_L().lhrs_rope_kv_append(qkv.data_ptr(), qkv.stride(0), kc.data_ptr(), vc.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(),
+                                        pos.data_ptr(), B, H, D, max_ctx, _stream()), "rope_kv_append")
+
+
 def decode_advance(state, desc, pos, B, max_ctx, inc=1):
     _lib.check(_L().lhrs_decode_advance(state.data_ptr(), desc.data_ptr(), pos.data_ptr(), B, max_ctx, inc, _stream()), "decode_advance")
 

@@ -78,3 +78,35 @@ def test_gemv_and_graph_decode_equal_eager_decode():
     a_ids, a_lg = model.generate(ids, images=rgb, do_sample=False, max_new_tokens=9, return_logits=True, use_graph=True)
     b_ids, b_lg = model.generate(ids, images=rgb, do_sample=False, max_new_tokens=9, return_logits=True, use_graph=False)
     assert torch.equal(a_ids, b_ids) and torch.equal(a_lg, b_lg)   # replayed graph == eager launches, bit for bit
+
+
+def test_fp8_weight_decode_and_fused_prologues():
+    g = torch.Generator().manual_seed(5)
+    # fused prologues against their unfused compositions
+    W = (torch.randn(4096, 4096, generator=g) * 0.02).to(DEV, torch.bfloat16)
+    x = torch.randn(2, 4096, generator=g).to(DEV, torch.bfloat16)
+    nw = (1 + 0.1 * torch.randn(4096, generator=g)).to(DEV, torch.bfloat16)
+    y = torch.empty(2, 4096, device=DEV, dtype=torch.bfloat16)
+    hk.gemv_fused(W, x, y, 4096, prologue=hk.PRO_RMSNORM, norm_w=nw)
+    y_ref = torch.empty_like(y)
+    hk.gemv(W, hk.rmsnorm_fwd(x, nw), y_ref)
+    assert torch.equal(y, y_ref)
+    gu = torch.randn(2, 2 * 11008, generator=g).to(DEV, torch.bfloat16)
+    Wd = (torch.randn(4096, 11008, generator=g) * 0.02).to(DEV, torch.bfloat16)
+    hk.gemv_fused(Wd, gu, y, 11008, prologue=hk.PRO_SWIGLU)
+    hk.gemv(Wd, hk.swiglu_fwd(gu, 11008), y_ref)
+    assert torch.equal(y, y_ref)
+    # e4m3 weights: quantisation error only (per-row scaled): ~2^-4 relative per element, averaged down by the dot product
+    W8, sc = hk.quant_fp8_rows(W)
+    deq = W8.view(torch.float8_e4m3fn).float() * sc[:, None]
+    assert rel(deq, W.float()) < 4e-2
+    y8 = torch.empty(2, 4096, device=DEV, dtype=torch.float32)
+    hk.gemv_fused(W8, x, y8, 4096, wscale=sc, out_f32=True)
+    assert rel(y8, x.float() @ deq.t()) < 1e-5
+    model = UniBind(("rgb", "text"), None, device=DEV, llama_layers=2).init_random(seed=1).eval()
+    ids = torch.tensor([[1, -200, 9, 8, 7, 6]])
+    rgb = torch.randn(1, 3, 224, 224, generator=g)
+    _, lg_bf = model.generate(ids, images=rgb, do_sample=False, max_new_tokens=5, return_logits=True)
+    _, lg_f8 = model.generate(ids, images=rgb, do_sample=False, max_new_tokens=5, return_logits=True, weights="fp8")
+    assert rel(lg_f8[:, 0], lg_bf[:, 0]) == 0.0        # the prefill is bf16 in both
+    assert rel(lg_f8[:, 1:2], lg_bf[:, 1:2]) < 1e-1    # first decoded step: e4m3 weight error only (same token fed; random weights)
