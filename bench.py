@@ -111,11 +111,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the LHRS hot path has no CPU fallback (cpu_baseline is only the checker)")
+    if os.environ.get("LHRS_SHARE_GPU") == "1":  # smoke test: every rank on GPU 0 (gloo backend only)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("LHRS_DIST_BACKEND", "nccl")  # "nccl" = RCCL over xGMI; "gloo" only for single-GPU smoke tests
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from lhrs_bot_amd import _lib

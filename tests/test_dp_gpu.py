@@ -1,0 +1,72 @@
+"""Data-parallel step on the real engine: 2 ranks (gloo backend, both on GPU 0 - the GPU box has one device; the driver's
+multi-GPU runs use "nccl" = RCCL) must end with identical parameters, equal to a single-process step on the averaged
+gradients of the two micro-batches (DeepSpeed / DDP mean-of-means semantics)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from lhrs_bot_amd.engine import LHRSEngine
+from lhrs_bot_amd.unibind import UniBind
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+
+def batch(r):
+    g = torch.Generator().manual_seed(322 + r)
+    ids = torch.randint(3, 32000, (2, 12), generator=g); ids[:, 0] = 1; ids[:, 1] = -200
+    labels = ids.clone(); labels[:, :2] = -100
+    return dict(rgb=torch.randn(2, 3, 224, 224, generator=g), input_ids=ids, labels=labels, attention_mask=ids.ne(0))
+
+def model():
+    m = UniBind(("rgb", "text"), None, device="cuda:0", llama_layers=1).init_random(seed=0)
+    m.prepare_for_training()
+    return m
+
+# ---- reference: one process, gradients of both micro-batches averaged, one Adan step with the clip
+ref = LHRSEngine(model(), optimizer="adanp", lr=1e-3, max_grad_norm=0.3)
+assert ref.world == 1
+gs = []
+for r in range(world):
+    out = ref(batch(r)); ref.backward(out["total_loss"]); gs.append(ref.pool.grad.clone())
+ref.pool.grad.copy_(sum(gs) / world)
+ref.step()
+want = ref.pool.master.clone()
+
+# ---- data parallel: this rank's micro-batch only, bucketed all-reduce during backward, averaging folded into the step
+torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+eng = LHRSEngine(model(), optimizer="adanp", lr=1e-3, max_grad_norm=0.3)
+assert eng.world == world and eng.reducers
+out = eng(batch(rank)); eng.backward(out["total_loss"]); eng.step()
+torch.cuda.synchronize()
+err = (eng.pool.master - want).abs().max().item()
+upd = (want - model().rgb_pooler.master).abs().max().item()
+assert err <= 1e-6 + 1e-3 * upd, (err, upd)
+mine = eng.pool.master.cpu()
+other = [torch.empty_like(mine) for _ in range(world)]
+torch.distributed.all_gather(other, mine)
+assert all(torch.equal(o, other[0]) for o in other), "ranks diverged"
+torch.distributed.barrier(); torch.distributed.destroy_process_group()
+open(os.path.join(sys.argv[2], f"ok{rank}"), "w").write(f"{err} {upd}")
+'''
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_step_equals_single_process_on_averaged_gradients(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", port, str(script), ROOT, str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port), timeout=800)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
