@@ -165,6 +165,32 @@ class TextModal:
         self.nl = len(self.p["layers"])
         self._finish()
 
+    def from_pretrained(self, path: str, n_layers: Optional[int] = None) -> None:
+        """CustomLlamaForCausalLM.from_pretrained(config.text.path) (text_modal.py:79-131): HF checkpoint directory ->
+        engine layout.  Architecture numbers come from the checkpoint's own config.json, as in the reference."""
+        import json
+        import os
+        from .checkpoint import llama_from_hf, load_hf_dir
+        cfg = json.load(open(os.path.join(path, "config.json")))
+        assert cfg["hidden_size"] == self.d and cfg["intermediate_size"] == self.ff and cfg["num_attention_heads"] == self.heads, cfg
+        assert cfg.get("num_key_value_heads", self.heads) == self.heads, "GQA checkpoints are outside the reference's LLaMA-2-7B path"
+        self.eps = float(cfg.get("rms_norm_eps", self.eps))
+        self.load_params(llama_from_hf(load_hf_dir(path), n_layers))
+
+    def merge_lora(self) -> None:
+        """peft merge_and_unload (UniBind.custom_load_state_dict, stage == 0; lhrs/models/UniBind.py:112-115):
+        W <- W + (alpha/r) B A, computed per fused group as one GEMM  W + s * Bfull . AT^T, then the adapters are dropped."""
+        lo = self.lora
+        if lo is None:
+            return
+        wname = {"qkv": "qkv_w", "o": "o_w", "gu": "gu_w", "down": "down_w"}
+        for li, L in enumerate(self.p["layers"]):
+            for gname in lo.groups:
+                W = L[wname[gname]]
+                hk.gemm_nt(lo.derived[(li, gname, "Bfull")], lo.derived[(li, gname, "AT")], out=W, residual=W, alpha=lo.s)
+                L[wname[gname] + "T"] = hk.transpose(W)
+        self.lora = None
+
     def init_random(self, seed: int = 0) -> None:
         """Random-init LLaMA-2-7B shapes, N(0, 0.02) (HF initializer_range) - no weights exist offline."""
         g = torch.Generator(device=self.device).manual_seed(seed)

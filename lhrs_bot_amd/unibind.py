@@ -127,16 +127,39 @@ class UniBind:
             self.rgb_pooler.backward(d_image)
 
     def custom_save_checkpoint(self, file_name: str):
+        """FINAL.pt = {"rgb_ckpt": VisionModal state dict, "other_ckpt": {rgb_pooler, text_proj, embed_tokens, lm_head}} and, from
+        stage 2 on, the peft adapter directory TextLoRA/ next to it (lhrs/models/UniBind.py:68-81, 275-302)."""
         import os
+        from .checkpoint import save_peft_dir, vit_to_hf
         os.makedirs(file_name, exist_ok=True)
-        ckpt = {"rgb_ckpt": {}, "other_ckpt": {"rgb_pooler": self.rgb_pooler.state_dict()}}
+        ckpt = {"rgb_ckpt": vit_to_hf(self.rgb.export_params()),
+                "other_ckpt": {"rgb_pooler": self.rgb_pooler.state_dict(), "text_proj": {},
+                               "embed_tokens": {"weight": self.text.p["embed"].float().cpu()}, "lm_head": {}}}
         torch.save(ckpt, os.path.join(file_name, "FINAL.pt"))
+        if self.text.lora is not None:
+            save_peft_dir(self.text.lora, os.path.join(file_name, "TextLoRA"))
         return ckpt
 
     def custom_load_state_dict(self, path: str, strict: bool = False):
+        """lhrs/models/UniBind.py:83-117: FINAL.pt (rgb encoder + projector) and a sibling TextLoRA/ adapter, trainable when
+        stage > 2 and merged into the base weights when stage == 0 (evaluation)."""
+        import os
+        from .checkpoint import load_peft_dir, lora_from_peft
         ckpt = torch.load(path, map_location="cpu")
+        if "model" in ckpt:
+            ckpt = ckpt["model"]
+        if ckpt.get("rgb_ckpt"):
+            self.rgb.load_state_dict(ckpt["rgb_ckpt"], strict=strict)
         if "other_ckpt" in ckpt and "rgb_pooler" in ckpt["other_ckpt"]:
             self.rgb_pooler.load_state_dict(ckpt["other_ckpt"]["rgb_pooler"], strict=strict)
+        text_path = os.path.join(os.path.dirname(path), "TextLoRA")
+        if os.path.isdir(text_path):
+            cfg, targets, sd = load_peft_dir(text_path)
+            if self.text.lora is None:
+                self.text.enable_lora(r=cfg["r"], alpha=cfg["lora_alpha"], targets=targets)
+            lora_from_peft(self.text.lora, sd)
+            if self.stage == 0:
+                self.text.merge_lora()
         return None
 
 

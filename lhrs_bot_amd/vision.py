@@ -24,6 +24,7 @@ class VisionModal:
         self.kp = (3 * patch * patch + 63) // 64 * 64  # im2col K padded to the GEMM's K % 64 rule (588 -> 640)
         self.extract_stage = [layers // 3 - 1, layers // 3 * 2 - 1, layers - 2]  # rgb_vision_modal.py:159-164
         self.p: Dict = {}
+        self._src = None
         self._desc_cache: Dict[int, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ parameters
@@ -35,6 +36,7 @@ class VisionModal:
         self.p = {"patch_w": pw.to(dev, bf), "cls": p["cls"].to(dev, bf), "pos": p["pos"].to(dev, bf).contiguous(),
                   "pre_ln_w": p["pre_ln_w"].to(dev, bf), "pre_ln_b": p["pre_ln_b"].to(dev, bf),
                   "layers": [{k: v.to(dev, bf).contiguous() for k, v in L.items()} for L in p["layers"][: max(self.extract_stage)]]}
+        self._src = p  # full host copy (all 24 layers) so that FINAL.pt["rgb_ckpt"] can be written back unchanged
 
     def init_random(self, seed: int = 0) -> None:
         g = torch.Generator(device=self.device).manual_seed(seed)
@@ -52,6 +54,21 @@ class VisionModal:
                 "ln1_w": rn(d, std=0.05, mean=1.0), "ln1_b": rn(d), "qkv_w": rn(3 * d, d), "qkv_b": rn(3 * d),
                 "o_w": rn(d, d), "o_b": rn(d), "ln2_w": rn(d, std=0.05, mean=1.0), "ln2_b": rn(d),
                 "fc1_w": rn(ff, d), "fc1_b": rn(ff), "fc2_w": rn(d, ff), "fc2_b": rn(d)})
+
+    def export_params(self) -> Dict:
+        """Engine-layout host copy (what was loaded; for random init: the 22 layers that exist)."""
+        if getattr(self, "_src", None) is not None:
+            return self._src
+        P2 = 3 * self.patch ** 2
+        out = {k: v.float().cpu() for k, v in self.p.items() if torch.is_tensor(v)}
+        out["patch_w"] = out["patch_w"][:, :P2].reshape(self.dim, 3, self.patch, self.patch)
+        out["layers"] = [{k: v.float().cpu() for k, v in L.items()} for L in self.p["layers"]]
+        return out
+
+    def load_state_dict(self, sd, strict: bool = False):
+        """VisionModal.load_state_dict with the reference's key names (`encoder.vision_model.*`, UniBind.py:96-100)."""
+        from .checkpoint import vit_from_hf
+        self.load_params(vit_from_hf(sd))
 
     def _desc(self, B: int) -> torch.Tensor:
         if B not in self._desc_cache:

@@ -131,3 +131,25 @@ def test_config_parser_matches_reference_parser(tmp_path):
     argv = ["-c", str(cfg)] + z["argv_tail"]
     assert build().parse_args(wandb=True, args=argv) == z["cli_wins"]     # CLI (even its defaults) overrides the YAML
     assert build().parse_args(wandb=False, args=argv) == z["yaml_wins"]   # YAML overrides the CLI
+
+
+def test_checkpoint_key_maps_match_the_reference_module_keys():
+    """oracle/params.py's converters were loaded with strict key matching into the reference's own modules when the goldens were
+    made (tests/golden/make_golden.py); the product's maps must produce the same keys / tensors and invert exactly."""
+    from lhrs_bot_amd import checkpoint as C
+    from oracle import params as OP
+
+    pv = OP.make_vit_params(seed=2, layers=3)
+    hf = C.vit_to_hf(pv)
+    want = OP.vit_to_hf(pv, "encoder.vision_model.")
+    assert set(hf) == set(want) and all(torch.equal(hf[k], want[k]) for k in hf)
+    for prefix in ("encoder.vision_model.", "vision_model.", ""):
+        back = C.vit_from_hf({prefix + k[len("encoder.vision_model."):]: v for k, v in hf.items()})
+        assert torch.equal(back["patch_w"], pv["patch_w"]) and len(back["layers"]) == 3
+        assert all(torch.equal(back["layers"][l][k], pv["layers"][l][k]) for l in range(3) for k in pv["layers"][l])
+    pl = OP.make_llama_params(seed=3, layers=1, dim=256, ff=512, vocab=1000)
+    hf = C.llama_to_hf(pl)
+    want = OP.llama_to_hf(pl)
+    assert set(hf) == set(want) and all(torch.equal(hf[k], want[k]) for k in hf)
+    back = C.llama_from_hf(hf)
+    assert all(torch.equal(back["layers"][0][k], pl["layers"][0][k]) for k in pl["layers"][0]) and torch.equal(back["lm_head"], pl["lm_head"])
