@@ -153,3 +153,32 @@ def test_checkpoint_key_maps_match_the_reference_module_keys():
     assert set(hf) == set(want) and all(torch.equal(hf[k], want[k]) for k in hf)
     back = C.llama_from_hf(hf)
     assert all(torch.equal(back["layers"][0][k], pl["layers"][0][k]) for k in pl["layers"][0]) and torch.equal(back["lm_head"], pl["lm_head"])
+
+
+def test_data_boundary_matches_reference_functions():
+    import copy
+    import json
+
+    from lhrs_bot_amd import data as D
+    from lhrs_bot_amd.trainer import ConfigDict
+
+    z = json.load(open(os.path.join(G, "data_boundary.json")))
+
+    class ToyTok:  # must be identical to the one in tests/golden/make_golden_data.py
+        bos_token_id, pad_token_id, unk_token_id, model_max_length = 1, 0, 0, 24
+
+        def __call__(self, text):
+            ids = [self.bos_token_id]
+            for w in text.replace("\n", " \n ").split(" "):
+                if w:
+                    ids.append(13 if w == "\n" else 3 + sum(ord(c) * (i + 7) for i, c in enumerate(w)) % 31000)
+            return ConfigDict({"input_ids": ids})
+
+    tok = ToyTok()
+    assert [D.tokenizer_image_token(p, tok) for p in z["prompts"]] == z["tit"]
+    pp = D.preprocess_plain(copy.deepcopy(z["sources"]), tok)
+    assert [t.tolist() for t in pp["input_ids"]] == z["pp_ids"] and [t.tolist() for t in pp["labels"]] == z["pp_labels"]
+    inst = [{"text": {"input_ids": pp["input_ids"][i], "labels": pp["labels"][i]}, "rgb": torch.full((3, 2, 2), float(i)), "valid_image": i % 2 == 0}
+            for i in range(3)]
+    b = D.DataCollatorForSupervisedDataset(tok)(inst)
+    assert {k: v.tolist() for k, v in b.items()} == z["coll"]   # incl. truncation at model_max_length = 24
