@@ -69,6 +69,8 @@ out = {"prompts": prompts, "tit": [cd.tokenizer_image_token(p, tok) for p in pro
 sources = [{"Question": "<image>\nWhat is this?", "Answer": "an airport with two runways"}, {"Question": "Look <image>", "Answer": "dense forest"},
            {"Question": "<image>", "Answer": " ".join(["w%d" % i for i in range(40)])}]
 import copy
+cd.conversation_lib.default_conversation = cd.conversation_lib.conv_templates["plain"]  # what the stage-1 datasets set (cap_dataset.py:196,353,395)
+out["plain_sep"] = cd.conversation_lib.default_conversation.sep
 pp = cd.preprocess_plain(copy.deepcopy(sources), tok)
 out["sources"] = sources
 out["pp_ids"] = [t.tolist() for t in pp["input_ids"]]

@@ -175,6 +175,7 @@ def test_data_boundary_matches_reference_functions():
             return ConfigDict({"input_ids": ids})
 
     tok = ToyTok()
+    assert z["plain_sep"] == D.PLAIN_SEP
     assert [D.tokenizer_image_token(p, tok) for p in z["prompts"]] == z["tit"]
     pp = D.preprocess_plain(copy.deepcopy(z["sources"]), tok)
     assert [t.tolist() for t in pp["input_ids"]] == z["pp_ids"] and [t.tolist() for t in pp["labels"]] == z["pp_labels"]
