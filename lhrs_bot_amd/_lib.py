@@ -15,7 +15,7 @@ from typing import Dict, List, Tuple
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(REPO_ROOT, "include", "lhrs_hip.h")
-LIB_PATH = os.path.join(_HERE, "csrc", "liblhrs_hip.so")
+LIB_PATH = os.environ.get("LHRS_HIP_LIB") or os.path.join(_HERE, "csrc", "liblhrs_hip.so")  # override: kernel experiments only
 
 _PROTO = re.compile(r"^\s*(const\s+char\s*\*|int|void)\s+(lhrs_\w+)\s*\(([^;{]*)\)\s*;", re.M | re.S)
 

@@ -399,7 +399,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256p_kernel(GemmArgs g) {
   }
   auto issue1 = [&](int kt, int j) {
     const bf16_t* p = kt < nk1 ? src[j] + (long)kt * BK : src2[j] + (long)(kt - nk1) * BK;
-    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + (kt & (NS - 1)) * STAGE + dst_off[j]), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + ((unsigned)kt % NS) * STAGE + dst_off[j]), 16, 0, 0);
   };
 
   const int wm = wave >> 2, wn = wave & 3;
@@ -429,13 +429,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256p_kernel(GemmArgs g) {
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
-  for (int j = 0; j < 4; ++j) issue1(0, j);
+  for (int s = 0; s < NS - 2; ++s)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) issue1(1, j);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    for (int j = 0; j < 4; ++j) issue1(s, j);
+  if constexpr (NS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 #pragma unroll
-  for (int j = 0; j < 4; ++j) issue1(2, j);
+  for (int j = 0; j < 4; ++j) issue1(NS - 2, j);
   lds_read6(a0, b0, a_base + koff0, b_base + koff0);
   lds_read6(a1, b1, a_base + koff1, b_base + koff1);
   asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(b0[0]), "+v"(b0[1]), "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]));
@@ -444,12 +444,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256p_kernel(GemmArgs g) {
 
   // One iteration = [publish stage kt+1] + 16 MFMAs (k1 of stage kt, k0 of stage kt+1); behind every MFMA sits one filler:
   // a ds_read of the next k-step's fragments or one DMA piece of stage kt+3.
-  auto body = [&](auto dma_c, auto vm4_c, int kt) {
-    constexpr bool DMA = decltype(dma_c)::value, VM4 = decltype(vm4_c)::value;
-    if constexpr (VM4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  auto body = [&](auto dma_c, auto vm_c, int kt) {
+    constexpr bool DMA = decltype(dma_c)::value;
+    constexpr int VM = decltype(vm_c)::value;  // DMA pieces that may still be in flight: the stages after kt+1
+    if constexpr (VM == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (VM == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const unsigned so = ((kt + 1) & (NS - 1)) * STAGE;
+    const unsigned so = ((unsigned)(kt + 1) % NS) * STAGE;
     const unsigned aa0 = a_base + so + koff0, ba0 = b_base + so + koff0;
     const unsigned aa1 = a_base + so + koff1, ba1 = b_base + so + koff1;
     lds_wait6(a1, b1);
@@ -459,8 +461,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256p_kernel(GemmArgs g) {
     MF(a1, b1, 1, 1) LDS_RD(a0[1], aa0, 2048); __builtin_amdgcn_sched_barrier(0);
     MF(a1, b1, 2, 0) LDS_RD(a0[2], aa0, 4096); __builtin_amdgcn_sched_barrier(0);
     MF(a1, b1, 2, 1) LDS_RD(a0[3], aa0, 6144); __builtin_amdgcn_sched_barrier(0);
-    MF(a1, b1, 3, 0) if constexpr (DMA) issue1(kt + 3, 0); __builtin_amdgcn_sched_barrier(0);
-    MF(a1, b1, 3, 1) if constexpr (DMA) issue1(kt + 3, 1); __builtin_amdgcn_sched_barrier(0);
+    MF(a1, b1, 3, 0) if constexpr (DMA) issue1(kt + NS - 1, 0); __builtin_amdgcn_sched_barrier(0);
+    MF(a1, b1, 3, 1) if constexpr (DMA) issue1(kt + NS - 1, 1); __builtin_amdgcn_sched_barrier(0);
     lds_wait6(a0, b0);
     MF(a0, b0, 0, 0) LDS_RD(b1[0], ba1, 0);    __builtin_amdgcn_sched_barrier(0);
     MF(a0, b0, 0, 1) LDS_RD(b1[1], ba1, 2048); __builtin_amdgcn_sched_barrier(0);
@@ -468,14 +470,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256p_kernel(GemmArgs g) {
     MF(a0, b0, 1, 1) LDS_RD(a1[1], aa1, 2048); __builtin_amdgcn_sched_barrier(0);
     MF(a0, b0, 2, 0) LDS_RD(a1[2], aa1, 4096); __builtin_amdgcn_sched_barrier(0);
     MF(a0, b0, 2, 1) LDS_RD(a1[3], aa1, 6144); __builtin_amdgcn_sched_barrier(0);
-    MF(a0, b0, 3, 0) if constexpr (DMA) issue1(kt + 3, 2); __builtin_amdgcn_sched_barrier(0);
-    MF(a0, b0, 3, 1) if constexpr (DMA) issue1(kt + 3, 3); __builtin_amdgcn_sched_barrier(0);
+    MF(a0, b0, 3, 0) if constexpr (DMA) issue1(kt + NS - 1, 2); __builtin_amdgcn_sched_barrier(0);
+    MF(a0, b0, 3, 1) if constexpr (DMA) issue1(kt + NS - 1, 3); __builtin_amdgcn_sched_barrier(0);
   };
   using T_ = std::integral_constant<bool, true>;
   using F_ = std::integral_constant<bool, false>;
-  for (int kt = 0; kt < nk - 3; ++kt) body(T_{}, T_{}, kt);   // steady state: DMA two stages ahead, vmcnt never 0
-  body(F_{}, T_{}, nk - 3);                                   // stage nk-1 is already in flight
-  body(F_{}, F_{}, nk - 2);
+  using V8 = std::integral_constant<int, 8>;
+  using V4 = std::integral_constant<int, 4>;
+  using V0 = std::integral_constant<int, 0>;
+  if constexpr (NS == 4) {
+    for (int kt = 0; kt < nk - 3; ++kt) body(T_{}, V4{}, kt);  // steady state: DMA NS-1 stages ahead, vmcnt never 0
+    body(F_{}, V4{}, nk - 3);                                  // stage nk-1 is already in flight
+  } else {
+    for (int kt = 0; kt < nk - 4; ++kt) body(T_{}, V8{}, kt);
+    body(F_{}, V8{}, nk - 4);
+    body(F_{}, V4{}, nk - 3);
+  }
+  body(F_{}, V0{}, nk - 2);
   lds_wait6(a1, b1);
   MFMA8(a1, b1)
 #undef MFMA8
@@ -532,6 +543,205 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256p_kernel(GemmArgs g) {
     }
   }
   // a wave reads back only what it wrote itself: its own LDS writes are visible to it once lgkmcnt drains
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  {
+    const int rsub = lane >> 3, c = lane & 7;
+    const int n = tn * BN + wn * 64 + c * 8;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = i * 8 + rsub;
+      const int m = tm * BM + wm * 128 + row;
+      uint4 val = *reinterpret_cast<const uint4*>(reg + row * 128 + ((c ^ (row & 7)) << 4));
+      if (m < g.M && n < g.N) {
+        if (g.res) {
+          const uint4 r = *reinterpret_cast<const uint4*>(g.res + (long)m * g.ldr + n);
+          val.x = pack2bf(bflo(val.x) + bflo(r.x), bfhi(val.x) + bfhi(r.x));
+          val.y = pack2bf(bflo(val.y) + bflo(r.y), bfhi(val.y) + bfhi(r.y));
+          val.z = pack2bf(bflo(val.z) + bflo(r.z), bfhi(val.z) + bfhi(r.z));
+          val.w = pack2bf(bflo(val.w) + bflo(r.w), bfhi(val.w) + bfhi(r.w));
+        }
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n) = val;
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// 256x256 "q" variant: BK = 64 stages (full 128-B rows: every DMA instruction moves 8 whole cache lines instead of 16 half
+// lines), two LDS buffers, ONE barrier per 32 MFMAs.  The stage is consumed as 4 blocks of 8 MFMAs; behind every MFMA sits a
+// ds_read of the next block's fragments, and the 8 DMA pieces of the NEXT stage are issued in the first three blocks after the
+// barrier so that each has at least one full block (~500 cycles) before the vmcnt(0) that precedes the next barrier.
+//   barrier(i) sits at the top of block k3(i-1), AFTER the lgkmcnt wait that completes the last LDS reads of stage i-1: it
+//   (a) publishes stage i (every wave waited vmcnt(0) on its own pieces first) and (b) frees buffer (i-1)&1 for the DMA of
+//   stage i+1 - nothing relies on timing.
+// LDS image: A[256][64], B[256][64] bf16 per buffer; 16-B chunk index XOR ((row>>1)&7): 32-row fragment reads hit 16 distinct
+// slots per lane group (rows of equal parity get distinct chunks).
+// ------------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(512, 2) void gemm_nt_256q_kernel(GemmArgs g) {
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int A_BYTES = BM * BK * 2, STAGE = A_BYTES + BN * BK * 2;  // 32 KiB + 32 KiB
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  int tm, tn;
+  tile_coords(g, tm, tn);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // DMA: per stage 64 wave-instructions of 1 KiB (8 rows x 128 B); wave w issues #8w..8w+7 (waves 0-3: A, 4-7: B).
+  // Addresses are a wave-uniform base (SGPR pair, advanced per stage) + a 32-bit per-lane byte offset per piece.
+  const bool isA = wave < 4;
+  const char* base1 = reinterpret_cast<const char*>(isA ? g.A : g.B);
+  const char* base2 = reinterpret_cast<const char*>(isA ? g.A2 : g.B2);
+  const long ld1 = isA ? g.lda : g.ldb, ld2 = isA ? g.lda2 : g.ldb2;
+  const int row0 = isA ? tm * BM : tn * BN, rmax = (isA ? g.M : g.N) - 1;
+  unsigned off1[8], off2[8];
+  const int nk1 = g.K / BK;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ridx = (wave & 3) * 8 + j;  // 8-row group inside the operand tile
+    const int lchunk = (lane & 7) ^ ((((j & 1) << 2) + (lane >> 4)) & 7);  // (row>>1)&7 with row = ridx*8 + (lane>>3)
+    const int row = min(row0 + ridx * 8 + (lane >> 3), rmax);
+    off1[j] = (unsigned)(((long)row * ld1 + lchunk * 8) * 2);
+    off2[j] = g.K2 > 0 ? (unsigned)(((long)row * ld2 + lchunk * 8) * 2) : 0u;
+  }
+  const int dst0 = (isA ? 0 : A_BYTES) + (wave & 3) * 8192;
+  auto issue1 = [&](int kt, int j) {
+    const char* p = kt < nk1 ? base1 + (long)kt * (BK * 2) + off1[j] : base2 + (long)(kt - nk1) * (BK * 2) + off2[j];
+    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + (kt & 1) * STAGE + dst0 + j * 1024), 16, 0, 0);
+  };
+
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int sw = (fr >> 1) & 7;
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+  const unsigned a_base = lds0 + (wm * 128 + fr) * 128;
+  const unsigned b_base = lds0 + A_BYTES + (wn * 64 + fr) * 128;
+  unsigned koff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) koff[kk] = ((kk * 2 + fh) ^ sw) * 16;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  bf16x8 a0[4], b0[2], a1[4], b1[2];
+#define RDQ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+#define MFQ(A_, B_, mi, ni) \
+  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B_[ni], A_[mi], acc[mi][ni], 0, 0, 0); __builtin_amdgcn_sched_barrier(0);
+#define SB __builtin_amdgcn_sched_barrier(0);
+  // one block: 8 MFMAs on (Ac, Bc); fillers: the 6 fragment reads of the next block into (An, Bn) from (aa, ba) and, when
+  // NDMA > 0, DMA pieces [d0, d0 + NDMA) of stage `kd`
+#define BLOCK(Ac, Bc, An, Bn, aa, ba, RD, kd, d0, NDMA, C)                                       \
+  MFQ(Ac, Bc, 0, 0) if (RD) RDQ(Bn[0], ba, 0);     if (NDMA > 0 && (C)) issue1(kd, d0);     SB     \
+  MFQ(Ac, Bc, 0, 1) if (RD) RDQ(Bn[1], ba, 4096);  if (NDMA > 4 && (C)) issue1(kd, d0 + 4); SB     \
+  MFQ(Ac, Bc, 1, 0) if (RD) RDQ(An[0], aa, 0);     if (NDMA > 1 && (C)) issue1(kd, d0 + 1); SB     \
+  MFQ(Ac, Bc, 1, 1) if (RD) RDQ(An[1], aa, 4096);  if (NDMA > 5 && (C)) issue1(kd, d0 + 5); SB     \
+  MFQ(Ac, Bc, 2, 0) if (RD) RDQ(An[2], aa, 8192);  if (NDMA > 2 && (C)) issue1(kd, d0 + 2); SB     \
+  MFQ(Ac, Bc, 2, 1) if (RD) RDQ(An[3], aa, 12288); if (NDMA > 6 && (C)) issue1(kd, d0 + 6); SB     \
+  MFQ(Ac, Bc, 3, 0)                                if (NDMA > 3 && (C)) issue1(kd, d0 + 3); SB     \
+  MFQ(Ac, Bc, 3, 1)                                if (NDMA > 7 && (C)) issue1(kd, d0 + 7); SB
+
+  const int nk = (g.K + g.K2) / BK;  // >= 2 (host guarantees)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) issue1(0, j);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) issue1(1, j);
+  {  // k0(0) -> set0
+    const unsigned aa = a_base + koff[0], ba = b_base + koff[0];
+    RDQ(b0[0], ba, 0); RDQ(b0[1], ba, 4096); RDQ(a0[0], aa, 0); RDQ(a0[1], aa, 4096); RDQ(a0[2], aa, 8192); RDQ(a0[3], aa, 12288);
+  }
+  // blocks k0, k1, k2 of stage 0 (DMA of stage 1 is already in flight)
+  lds_wait6(a0, b0);
+  { const unsigned aa = a_base + koff[1], ba = b_base + koff[1]; BLOCK(a0, b0, a1, b1, aa, ba, true, 0, 0, 0, true) }
+  lds_wait6(a1, b1);
+  { const unsigned aa = a_base + koff[2], ba = b_base + koff[2]; BLOCK(a1, b1, a0, b0, aa, ba, true, 0, 0, 0, true) }
+  lds_wait6(a0, b0);
+  { const unsigned aa = a_base + koff[3], ba = b_base + koff[3]; BLOCK(a0, b0, a1, b1, aa, ba, true, 0, 0, 0, true) }
+
+  // DMA placement: 6 pieces behind the MFMAs of the first block after the barrier, 2 in the second - issued as early as the
+  // freed buffer allows (measured: (6,2,0) +3 % over (3,3,2); splitting the two waves of a SIMD over different blocks -8 %)
+  constexpr int QD3 = 6, QD0 = 2, QD1 = 0, QO0 = QD3, QO1 = QD3 + QD0;
+  constexpr bool c3 = true, c0 = true;
+  auto stage = [&](auto dma_c, int kt) {
+    constexpr bool DMA = decltype(dma_c)::value;
+    const unsigned so = (kt & 1) * STAGE;
+    // ---- block k3(kt-1): completes the reads of stage kt-1, then the barrier that publishes stage kt
+    lds_wait6(a1, b1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    { const unsigned aa = a_base + so + koff[0], ba = b_base + so + koff[0]; BLOCK(a1, b1, a0, b0, aa, ba, true, kt + 1, 0, (DMA ? QD3 : 0), c3) }
+    lds_wait6(a0, b0);
+    { const unsigned aa = a_base + so + koff[1], ba = b_base + so + koff[1]; BLOCK(a0, b0, a1, b1, aa, ba, true, kt + 1, QO0, (DMA ? QD0 : 0), c0) }
+    lds_wait6(a1, b1);
+    { const unsigned aa = a_base + so + koff[2], ba = b_base + so + koff[2]; BLOCK(a1, b1, a0, b0, aa, ba, true, kt + 1, QO1, (DMA ? QD1 : 0), true) }
+    lds_wait6(a0, b0);
+    { const unsigned aa = a_base + so + koff[3], ba = b_base + so + koff[3]; BLOCK(a0, b0, a1, b1, aa, ba, true, 0, 0, 0, true) }
+  };
+  for (int kt = 1; kt < nk - 1; ++kt) stage(std::true_type{}, kt);
+  stage(std::false_type{}, nk - 1);
+  lds_wait6(a1, b1);
+  { BLOCK(a1, b1, a0, b0, a_base, b_base, false, 0, 0, 0, true) }
+#undef BLOCK
+#undef SB
+#undef MFQ
+#undef RDQ
+
+  if (g.out_f32) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int m = tm * BM + wm * 128 + mi * 32 + fr;
+      if (m >= g.M) continue;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4;
+          if (n >= g.N) continue;
+          store4<ACT>(g, m, n, f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]});
+        }
+    }
+    return;
+  }
+  __builtin_amdgcn_s_barrier();
+  char* reg = smem + wave * 16384;
+  {
+    float bias_v[2][4][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = min(tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4, g.N - 4);
+        uint2 bb = make_uint2(0, 0);
+        if (g.bias) bb = *reinterpret_cast<const uint2*>(g.bias + n);
+        bias_v[ni][q][0] = bflo(bb.x); bias_v[ni][q][1] = bfhi(bb.x); bias_v[ni][q][2] = bflo(bb.y); bias_v[ni][q][3] = bfhi(bb.y);
+      }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int row = mi * 32 + fr;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[i] = acc[mi][ni][4 * q + i] * g.alpha + bias_v[ni][q][i];
+            if (ACT) v[i] = apply_act(v[i], ACT);
+          }
+          const int u = ni * 8 + q * 2 + fh;
+          *reinterpret_cast<uint2*>(reg + row * 128 + ((u ^ ((row & 7) << 1)) << 3)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        }
+    }
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   {
     const int rsub = lane >> 3, c = lane & 7;
@@ -684,7 +894,14 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   if (use256) {
     g.tilesM = cdiv(M, 256); g.tilesN = cdiv(N, 256);
     const dim3 grid(g.tilesM * g.tilesN), blk(512);
-    if (g_gemm_allow_256 == 1) {
+    if (g_gemm_allow_256 >= 2 && g_gemm_allow_256 != 4 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128) {
+      switch (act) {
+        case 0: hipLaunchKernelGGL((gemm_nt_256q_kernel<0>), grid, blk, 0, s, g); break;
+        case 1: hipLaunchKernelGGL((gemm_nt_256q_kernel<1>), grid, blk, 0, s, g); break;
+        case 2: hipLaunchKernelGGL((gemm_nt_256q_kernel<2>), grid, blk, 0, s, g); break;
+        default: hipLaunchKernelGGL((gemm_nt_256q_kernel<3>), grid, blk, 0, s, g); break;
+      }
+    } else if (g_gemm_allow_256 == 1) {
       switch (act) {
         case 0: hipLaunchKernelGGL((gemm_nt_256_kernel<0>), grid, blk, 0, s, g); break;
         case 1: hipLaunchKernelGGL((gemm_nt_256_kernel<1>), grid, blk, 0, s, g); break;
