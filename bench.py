@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--caption-tokens", type=int, default=128)
     ap.add_argument("--llama-layers", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-policy", type=int, default=None, help="kernel A/B tests only: lhrs_gemm_set_policy value")
     ap.add_argument("--stage", type=int, default=1, choices=[1, 2, 3],
                     help="1: projector-only + Adan (the headline metric, BASELINE configs[1..2]); 3: LoRA r=8 on q,k,v,o + AdamW, projector "
                          "frozen (BASELINE configs[3]); 2: LoRA r=128 on every linear + projector, AdamW (Config/multi_modal_stage2.yaml)")
@@ -129,6 +130,8 @@ def main():
     from lhrs_bot_amd.unibind import UniBind
 
     lib = _lib.load()
+    if a.gemm_policy is not None:
+        lib.lhrs_gemm_set_policy(a.gemm_policy)
     B, T = a.micro_batch, a.caption_tokens + 2
     S = T - 1 + 144
     model = UniBind(("rgb", "text"), None, device=dev, llama_layers=a.llama_layers).init_random(seed=0)  # same weights on every rank
@@ -197,7 +200,7 @@ def main():
                        "grad_allreduce": a.comm_dtype if world > 1 else "none"},
             "loss": round(final_loss, 4),
             "step_mfma_frac": round(sps / world * f_alg(S) / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 and a.stage == 1 else None,
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_256q_kernel (256x256 tile, BK=64 double-buffered LDS stages via global_load_lds DMA, v_mfma_f32_32x32x16_bf16)", "achieved": round(ach, 1),
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_256r_kernel (256x256 tile, 16 waves, BK=64 double-buffered LDS stages via global_load_lds DMA, v_mfma_f32_32x32x16_bf16)", "achieved": round(ach, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "launches_timed": int(n_samp), "avg_launch_us": round(1e3 * ms / max(n_samp, 1), 2),
                          "gemm_flops_share_of_step": round(prof[4] / a.steps / (B * f_alg(S)), 3) if scale_layers == 1.0 else None},

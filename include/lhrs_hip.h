@@ -46,8 +46,8 @@ int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, i
 int lhrs_gemm_bf16_nt_lora(const void* A, int lda, const void* B, int ldb, const void* A2, int lda2, const void* B2, int ldb2,
                            int K2, void* C, int ldc, int M, int N, int K, const void* bias, const void* residual, int ldr,
                            int out_f32, int accumulate, float alpha, void* stream);
-/* 256x256-tile kernel choice (tuning / A-B tests): 0 never, 1 plain 4-stage ring, 2 default (BK=64 two-buffer kernel when K % 64 == 0,
- * else the BK=32 ring), 4 always the BK=32 ring */
+/* 256x256-tile kernel choice (tuning / A-B tests): 0 never, 1 plain 4-stage ring, 2 default (16-wave BK=64 two-buffer kernel
+ * when K % 64 == 0, else the BK=32 ring), 3 the 8-wave BK=64 kernel, 4 always the BK=32 ring */
 int lhrs_gemm_set_policy(int allow_256);
 int lhrs_gemm_profile_enable(int max_samples);
 int lhrs_gemm_profile_read(double* out5_host);

@@ -765,6 +765,191 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256q_kernel(GemmArgs g) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 256x256 "r" variant: the q kernel's stage structure with SIXTEEN waves (4x4, 64x64 per wave, 4 waves per SIMD at <=128 VGPRs):
+// when a wave sits in a DMA issue or at the barrier three others can feed the SIMD's MFMA pipe instead of one.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_wait4(bf16x8 (&a)[2], bf16x8 (&b)[2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(a[0]), "+v"(a[1]));
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int ACT>
+__global__ __launch_bounds__(1024, 1) void gemm_nt_256r_kernel(GemmArgs g) {
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int A_BYTES = BM * BK * 2, STAGE = A_BYTES + BN * BK * 2;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  int tm, tn;
+  tile_coords(g, tm, tn);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // DMA: 64 pieces of 1 KiB per stage; wave w issues #4w..4w+3 (waves 0-7: A, 8-15: B)
+  const bool isA = wave < 8;
+  const char* base1 = reinterpret_cast<const char*>(isA ? g.A : g.B);
+  const char* base2 = reinterpret_cast<const char*>(isA ? g.A2 : g.B2);
+  const long ld1 = isA ? g.lda : g.ldb, ld2 = isA ? g.lda2 : g.ldb2;
+  const int row0 = isA ? tm * BM : tn * BN, rmax = (isA ? g.M : g.N) - 1;
+  unsigned off1[4], off2[4];
+  const int nk1 = g.K / BK;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ridx = (wave & 7) * 4 + j;
+    const int lchunk = (lane & 7) ^ ((((j & 1) << 2) + (lane >> 4)) & 7);
+    const int row = min(row0 + ridx * 8 + (lane >> 3), rmax);
+    off1[j] = (unsigned)(((long)row * ld1 + lchunk * 8) * 2);
+    off2[j] = g.K2 > 0 ? (unsigned)(((long)row * ld2 + lchunk * 8) * 2) : 0u;
+  }
+  const int dst0 = (isA ? 0 : A_BYTES) + (wave & 7) * 4096;
+  auto issue1 = [&](int kt, int j) {
+    const char* p = kt < nk1 ? base1 + (long)kt * (BK * 2) + off1[j] : base2 + (long)(kt - nk1) * (BK * 2) + off2[j];
+    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + (kt & 1) * STAGE + dst0 + j * 1024), 16, 0, 0);
+  };
+
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int sw = (fr >> 1) & 7;
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+  const unsigned a_base = lds0 + (wm * 64 + fr) * 128;
+  const unsigned b_base = lds0 + A_BYTES + (wn * 64 + fr) * 128;
+  unsigned koff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) koff[kk] = ((kk * 2 + fh) ^ sw) * 16;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  bf16x8 a0[2], b0[2], a1[2], b1[2];
+#define RDQ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+#define MFQ(A_, B_, mi, ni) \
+  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B_[ni], A_[mi], acc[mi][ni], 0, 0, 0); __builtin_amdgcn_sched_barrier(0);
+#define SB __builtin_amdgcn_sched_barrier(0);
+  // one block: 4 MFMAs on (Ac, Bc); behind each: one fragment read of the next block and (NDMA > i) one DMA piece of stage kd
+#define BLOCK(Ac, Bc, An, Bn, aa, ba, RD, kd, d0, NDMA)                                  \
+  MFQ(Ac, Bc, 0, 0) if (RD) RDQ(Bn[0], ba, 0);    if (NDMA > 0) issue1(kd, d0);     SB     \
+  MFQ(Ac, Bc, 0, 1) if (RD) RDQ(Bn[1], ba, 4096); if (NDMA > 1) issue1(kd, d0 + 1); SB     \
+  MFQ(Ac, Bc, 1, 0) if (RD) RDQ(An[0], aa, 0);    if (NDMA > 2) issue1(kd, d0 + 2); SB     \
+  MFQ(Ac, Bc, 1, 1) if (RD) RDQ(An[1], aa, 4096); if (NDMA > 3) issue1(kd, d0 + 3); SB
+
+  const int nk = (g.K + g.K2) / BK;  // >= 2 (host guarantees)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) issue1(0, j);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) issue1(1, j);
+  {
+    const unsigned aa = a_base + koff[0], ba = b_base + koff[0];
+    RDQ(b0[0], ba, 0); RDQ(b0[1], ba, 4096); RDQ(a0[0], aa, 0); RDQ(a0[1], aa, 4096);
+  }
+  lds_wait4(a0, b0);
+  { const unsigned aa = a_base + koff[1], ba = b_base + koff[1]; BLOCK(a0, b0, a1, b1, aa, ba, true, 0, 0, 0) }
+  lds_wait4(a1, b1);
+  { const unsigned aa = a_base + koff[2], ba = b_base + koff[2]; BLOCK(a1, b1, a0, b0, aa, ba, true, 0, 0, 0) }
+  lds_wait4(a0, b0);
+  { const unsigned aa = a_base + koff[3], ba = b_base + koff[3]; BLOCK(a0, b0, a1, b1, aa, ba, true, 0, 0, 0) }
+
+  auto stage = [&](auto dma_c, int kt) {
+    constexpr bool DMA = decltype(dma_c)::value;
+    const unsigned so = (kt & 1) * STAGE;
+    lds_wait4(a1, b1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    { const unsigned aa = a_base + so + koff[0], ba = b_base + so + koff[0]; BLOCK(a1, b1, a0, b0, aa, ba, true, kt + 1, 0, (DMA ? 4 : 0)) }
+    lds_wait4(a0, b0);
+    { const unsigned aa = a_base + so + koff[1], ba = b_base + so + koff[1]; BLOCK(a0, b0, a1, b1, aa, ba, true, 0, 0, 0) }
+    lds_wait4(a1, b1);
+    { const unsigned aa = a_base + so + koff[2], ba = b_base + so + koff[2]; BLOCK(a1, b1, a0, b0, aa, ba, true, 0, 0, 0) }
+    lds_wait4(a0, b0);
+    { const unsigned aa = a_base + so + koff[3], ba = b_base + so + koff[3]; BLOCK(a0, b0, a1, b1, aa, ba, true, 0, 0, 0) }
+  };
+  for (int kt = 1; kt < nk - 1; ++kt) stage(std::true_type{}, kt);
+  stage(std::false_type{}, nk - 1);
+  lds_wait4(a1, b1);
+  { BLOCK(a1, b1, a0, b0, a_base, b_base, false, 0, 0, 0) }
+#undef BLOCK
+#undef SB
+#undef MFQ
+#undef RDQ
+
+  if (g.out_f32) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int m = tm * BM + wm * 64 + mi * 32 + fr;
+      if (m >= g.M) continue;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4;
+          if (n >= g.N) continue;
+          store4<ACT>(g, m, n, f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]});
+        }
+    }
+    return;
+  }
+  __builtin_amdgcn_s_barrier();
+  char* reg = smem + wave * 8192;  // [64 rows][64 cols] bf16, wave private
+  {
+    float bias_v[2][4][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = min(tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4, g.N - 4);
+        uint2 bb = make_uint2(0, 0);
+        if (g.bias) bb = *reinterpret_cast<const uint2*>(g.bias + n);
+        bias_v[ni][q][0] = bflo(bb.x); bias_v[ni][q][1] = bfhi(bb.x); bias_v[ni][q][2] = bflo(bb.y); bias_v[ni][q][3] = bfhi(bb.y);
+      }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int row = mi * 32 + fr;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[i] = acc[mi][ni][4 * q + i] * g.alpha + bias_v[ni][q][i];
+            if (ACT) v[i] = apply_act(v[i], ACT);
+          }
+          const int u = ni * 8 + q * 2 + fh;
+          *reinterpret_cast<uint2*>(reg + row * 128 + ((u ^ ((row & 7) << 1)) << 3)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  {
+    const int rsub = lane >> 3, c = lane & 7;
+    const int n = tn * BN + wn * 64 + c * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = i * 8 + rsub;
+      const int m = tm * BM + wm * 64 + row;
+      uint4 val = *reinterpret_cast<const uint4*>(reg + row * 128 + ((c ^ (row & 7)) << 4));
+      if (m < g.M && n < g.N) {
+        if (g.res) {
+          const uint4 r = *reinterpret_cast<const uint4*>(g.res + (long)m * g.ldr + n);
+          val.x = pack2bf(bflo(val.x) + bflo(r.x), bfhi(val.x) + bfhi(r.x));
+          val.y = pack2bf(bflo(val.y) + bflo(r.y), bfhi(val.y) + bfhi(r.y));
+          val.z = pack2bf(bflo(val.z) + bflo(r.z), bfhi(val.z) + bfhi(r.z));
+          val.w = pack2bf(bflo(val.w) + bflo(r.w), bfhi(val.w) + bfhi(r.w));
+        }
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n) = val;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // ---- optional live timing of the GEMM launches (bench.py roofline leg) -----------------------------------
@@ -894,7 +1079,15 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   if (use256) {
     g.tilesM = cdiv(M, 256); g.tilesN = cdiv(N, 256);
     const dim3 grid(g.tilesM * g.tilesN), blk(512);
-    if (g_gemm_allow_256 >= 2 && g_gemm_allow_256 != 4 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128) {
+    if ((g_gemm_allow_256 == 2 || g_gemm_allow_256 == 5) && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128) {
+      const dim3 blk16(1024);
+      switch (act) {
+        case 0: hipLaunchKernelGGL((gemm_nt_256r_kernel<0>), grid, blk16, 0, s, g); break;
+        case 1: hipLaunchKernelGGL((gemm_nt_256r_kernel<1>), grid, blk16, 0, s, g); break;
+        case 2: hipLaunchKernelGGL((gemm_nt_256r_kernel<2>), grid, blk16, 0, s, g); break;
+        default: hipLaunchKernelGGL((gemm_nt_256r_kernel<3>), grid, blk16, 0, s, g); break;
+      }
+    } else if (g_gemm_allow_256 == 3 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128) {
       switch (act) {
         case 0: hipLaunchKernelGGL((gemm_nt_256q_kernel<0>), grid, blk, 0, s, g); break;
         case 1: hipLaunchKernelGGL((gemm_nt_256q_kernel<1>), grid, blk, 0, s, g); break;

@@ -9,7 +9,7 @@ lib = _lib.load()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 M = B * 273
 shapes = [(M, 12288, 4096), (M, 4096, 4096), (M, 22016, 4096), (M, 4096, 11008), (M, 11008, 4096), (M, 4096, 22016), (M, 4096, 12288)]
-for pol in (4, 2, 4, 2):
+for pol in (3, 2, 3, 2):
     lib.lhrs_gemm_set_policy(pol)
     tot_t = tot_f = 0
     for (m, n, k) in shapes:
@@ -20,7 +20,7 @@ for pol in (4, 2, 4, 2):
             hk.gemm_nt(a, b, out=c)
         torch.cuda.synchronize()
         if pol == 2 and (m, n, k) == shapes[0]:
-            lib.lhrs_gemm_set_policy(4)
+            lib.lhrs_gemm_set_policy(1)
             ref = hk.gemm_nt(a, b)
             lib.lhrs_gemm_set_policy(2)
             print("policy 3 vs 2 max|diff| =", (ref.float() - c.float()).abs().max().item())
