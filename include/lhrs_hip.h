@@ -84,6 +84,12 @@ int lhrs_seq_transpose(const void* in, long ld_in, void* out, int cols, int LT, 
 int lhrs_attn_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, float* lse,
                   const int* desc, int nseq, int H, int D, int max_q, int max_kv, int LTq, int causal, float scale,
                   void* stream);
+/* lhrs_attn_fwd with an HF attention_mask over the keys (batched evaluation with LEFT-padded prompts: DataCollatorForVGSupervisedDataset,
+ * lhrs/Dataset/cap_dataset.py:813-854 -> main_vqa.py:205-214 -> HF _prepare_4d_causal_attention_mask): key j of sequence s is
+ * visible iff key_mask[s * ld_mask + j] != 0, AND the causal rule, AND j < kv_len. */
+int lhrs_attn_fwd_kmask(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
+                        float* lse, const int* desc, int nseq, int H, int D, int max_q, int max_kv, int LTq,
+                        int causal, float scale, const unsigned char* key_mask, long ld_mask, void* stream);
 int lhrs_attn_delta(const void* o, long ldo, const void* dout, long ld_do, float* delta, const int* desc, int nseq, int H,
                     int D, int max_q, int LTq, void* stream);
 int lhrs_attn_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout,

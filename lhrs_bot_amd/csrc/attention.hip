@@ -41,6 +41,8 @@ struct AttnArgs {
   const int* desc;    // [nseq][8]
   int H;
   float scale;
+  const unsigned char* kmask;  // optional key-visibility bytes [seq][ld_kmask] (HF attention_mask semantics), tiled forward only
+  long ld_kmask;
 };
 
 constexpr float NEG_INF = -__builtin_huge_valf();
@@ -166,6 +168,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
   for (int i = 0; i < DB; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const unsigned char* km = a.kmask ? a.kmask + (long)seq * a.ld_kmask : nullptr;
   int kv_end = kv_len;
   if (CAUSAL) kv_end = max(0, min(kv_len, q0 + 64 + coff));
   const int ntiles = (kv_end + 63) >> 6;
@@ -200,7 +203,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = j * 64 + nb * 16 + fg * 4 + r;
-        const bool ok = key < kv_len && (!CAUSAL || key <= qrow + coff);
+        bool ok = key < kv_len && (!CAUSAL || key <= qrow + coff);
+        if (km != nullptr && ok) ok = km[key] != 0;
         s[nb][r] = ok ? s[nb][r] * a.scale : NEG_INF;
         mx = fmaxf(mx, s[nb][r]);
       }
@@ -818,10 +822,12 @@ extern "C" int lhrs_seq_transpose(const void* in, long ld_in, void* out, int col
   return 0;
 }
 
-extern "C" int lhrs_attn_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
-                             float* lse, const int* desc, int nseq, int H, int D, int max_q, int max_kv, int LTq,
-                             int causal, float scale, void* stream) {
+static int attn_fwd_impl(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
+                         float* lse, const int* desc, int nseq, int H, int D, int max_q, int max_kv, int LTq,
+                         int causal, float scale, const unsigned char* key_mask, long ld_mask, void* stream) {
   AttnArgs a; memset(&a, 0, sizeof(a));
+  a.kmask = key_mask; a.ld_kmask = ld_mask;
+  if (key_mask != nullptr) max_kv = 1 << 30;  // the mask lives in the tiled kernel only
   a.q = (const bf16_t*)q; a.ldq = ldq; a.k = (const bf16_t*)k; a.ldk = ldk; a.v = (const bf16_t*)v; a.ldv = ldv;
   a.o = (bf16_t*)o; a.ldo = ldo; a.lse = lse; a.desc = desc; a.H = H; a.LTq = LTq; a.scale = scale;
   if (check_common(a, D, nseq, "attn_fwd")) return -1;
@@ -848,6 +854,21 @@ extern "C" int lhrs_attn_fwd(const void* q, long ldq, const void* k, long ldk, c
   }
   LHRS_CHECK_LAUNCH("attn_fwd");
   return 0;
+}
+
+extern "C" int lhrs_attn_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
+                             float* lse, const int* desc, int nseq, int H, int D, int max_q, int max_kv, int LTq,
+                             int causal, float scale, void* stream) {
+  return attn_fwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, lse, desc, nseq, H, D, max_q, max_kv, LTq, causal, scale, nullptr, 0, stream);
+}
+
+// forward with an HF-style attention_mask: key j of sequence s is visible iff key_mask[s * ld_mask + j] != 0 (AND causal, AND
+// j < kv_len).  A query row with no visible key returns 0 (HF would return the mean of V: such rows are pad positions).
+extern "C" int lhrs_attn_fwd_kmask(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
+                                   float* lse, const int* desc, int nseq, int H, int D, int max_q, int max_kv, int LTq,
+                                   int causal, float scale, const unsigned char* key_mask, long ld_mask, void* stream) {
+  LHRS_REQUIRE(key_mask != nullptr && ld_mask > 0, "attn_fwd_kmask: key_mask=%p ld_mask=%ld", (const void*)key_mask, ld_mask);
+  return attn_fwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, lse, desc, nseq, H, D, max_q, max_kv, LTq, causal, scale, key_mask, ld_mask, stream);
 }
 
 extern "C" int lhrs_attn_delta(const void* o, long ldo, const void* dout, long ld_do, float* delta, const int* desc,

@@ -159,10 +159,17 @@ def seq_transpose(x, cols, LT, desc, nseq, which: str):
     return out
 
 
-def attn_fwd(q, k, v, o, lse, desc, nseq, H, D, max_q, max_kv, LTq, causal, scale):
-    st = _L().lhrs_attn_fwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), o.data_ptr(),
-                            o.stride(0), _p(lse), desc.data_ptr(), nseq, H, D, max_q, max_kv, LTq, int(causal), float(scale),
-                            _stream())
+def attn_fwd(q, k, v, o, lse, desc, nseq, H, D, max_q, max_kv, LTq, causal, scale, key_mask=None):
+    """key_mask: optional uint8 [nseq, >= kv_len] HF-style attention_mask over the keys (left-padded batched generate)."""
+    if key_mask is None:
+        st = _L().lhrs_attn_fwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), o.data_ptr(),
+                                o.stride(0), _p(lse), desc.data_ptr(), nseq, H, D, max_q, max_kv, LTq, int(causal), float(scale),
+                                _stream())
+    else:
+        assert key_mask.dtype == torch.uint8 and key_mask.dim() == 2 and key_mask.shape[0] == nseq and key_mask.stride(1) == 1
+        st = _L().lhrs_attn_fwd_kmask(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), o.data_ptr(),
+                                      o.stride(0), _p(lse), desc.data_ptr(), nseq, H, D, max_q, max_kv, LTq, int(causal),
+                                      float(scale), key_mask.data_ptr(), key_mask.stride(0), _stream())
     _lib.check(st, "attn_fwd")
 
 

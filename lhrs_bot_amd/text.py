@@ -317,7 +317,7 @@ class TextModal:
     __call__ = decode
 
     # ------------------------------------------------------------------ generate (KV cache)
-    def _layer_step(self, L, x, B, S_new, ctx, cache, desc, max_ctx):
+    def _layer_step(self, L, x, B, S_new, ctx, cache, desc, max_ctx, kmask=None):
         """One decoder layer over S_new new positions per sequence with `ctx` cached positions (prefill: ctx = 0)."""
         d, H, hd, ff = self.d, self.heads, self.hd, self.ff
         M = x.shape[0]
@@ -331,7 +331,7 @@ class TextModal:
             hk.copy_2d(kc.data_ptr() + (b * max_ctx + ctx) * row_b, row_b, src + row_b, 3 * row_b, row_b, S_new)
             hk.copy_2d(vc.data_ptr() + (b * max_ctx + ctx) * row_b, row_b, src + 2 * row_b, 3 * row_b, row_b, S_new)
         o = torch.empty((M, d), device=self.device, dtype=torch.bfloat16)
-        hk.attn_fwd(qkv[:, :d], kc, vc, o, None, desc, B, H, hd, S_new, 1 << 30, hk.pad64(S_new), True, 1.0 / math.sqrt(hd))
+        hk.attn_fwd(qkv[:, :d], kc, vc, o, None, desc, B, H, hd, S_new, 1 << 30, hk.pad64(S_new), True, 1.0 / math.sqrt(hd), key_mask=kmask)
         x = hk.gemm_nt(o, L["o_w"], residual=x)
         h = hk.rmsnorm_fwd(x, L["ln2_w"], self.eps, out=h)
         act = hk.swiglu_fwd(hk.gemm_nt(h, L["gu_w"]), ff)
@@ -344,7 +344,7 @@ class TextModal:
                 L[k + "8"], L[k + "8s"] = hk.quant_fp8_rows(L[k])
         self.p["lm_head8"], self.p["lm_head8s"] = hk.quant_fp8_rows(self.p["lm_head"])
 
-    def _decode_session(self, B, max_ctx, caches, max_new, weights="bf16"):
+    def _decode_session(self, B, max_ctx, caches, max_new, weights="bf16", kmask=None):
         """Static buffers + one captured hipGraph for the single-token step (batch <= 8): embedding gather, 32 x [RMSNorm,
         QKV GEMV, RoPE, KV append, attention over the cache, O GEMV + residual, RMSNorm, gate|up GEMV, SwiGLU, down GEMV +
         residual], final norm, lm_head GEMV -> fp32 logits.  Context length / positions live on the device
@@ -381,7 +381,7 @@ class TextModal:
                 w, sc = W(L, "qkv_w")
                 hk.gemv_fused(w, x, s.qkv, d, wscale=sc, prologue=hk.PRO_RMSNORM, norm_w=L["ln1_w"], eps=self.eps)
                 hk.rope_kv_append(s.qkv, kc, vc, self.cos, self.sin, s.pos, B, H, hd, max_ctx)
-                hk.attn_fwd(s.qkv[:, :d], kc, vc, s.o, None, s.desc, B, H, hd, 1, 1 << 30, 64, True, scale)
+                hk.attn_fwd(s.qkv[:, :d], kc, vc, s.o, None, s.desc, B, H, hd, 1, 1 << 30, 64, True, scale, key_mask=kmask)
                 w, sc = W(L, "o_w")
                 hk.gemv_fused(w, s.o, x2, d, wscale=sc, residual=x)
                 w, sc = W(L, "gu_w")
@@ -407,10 +407,15 @@ class TextModal:
         the host never synchronises inside the loop."""
         embeds, _, mask, _ = self.prepare_inputs_for_multimodal(input_ids, attention_mask, None, image_embedding)
         B, S0, d = embeds.shape
-        if mask is not None and not bool(mask.bool().all()):
-            raise NotImplementedError("padded prompts in generate (batched eval with left padding) - SURVEY.md §8 f-3")
         max_ctx = S0 + max_new_tokens
         dev = self.device
+        kmask = None
+        if mask is not None and not bool(mask.bool().all()):
+            # batched evaluation with LEFT-padded prompts (DataCollatorForVGSupervisedDataset -> main_vqa.py:205-214): HF keeps
+            # position_ids = arange (CustomLlamaForCausalLM.prepare_inputs_for_generation passes none) and hides the keys whose
+            # (spliced) attention_mask is 0; every generated position is visible.
+            kmask = torch.ones((B, max_ctx), device=dev, dtype=torch.uint8)
+            kmask[:, :S0] = mask.to(device=dev, dtype=torch.uint8)
         caches = [(torch.empty((B * max_ctx, d), device=dev, dtype=torch.bfloat16), torch.empty((B * max_ctx, d), device=dev, dtype=torch.bfloat16))
                   for _ in range(len(self.p["layers"]))]
 
@@ -433,7 +438,7 @@ class TextModal:
         desc = hk.make_desc([(b * S0, S0, b * max_ctx, S0, S0, 0) for b in range(B)], dev)
         x = embeds.reshape(B * S0, d)
         for L, cache in zip(self.p["layers"], caches):
-            x = self._layer_step(L, x, B, S0, 0, cache, desc, max_ctx)
+            x = self._layer_step(L, x, B, S0, 0, cache, desc, max_ctx, kmask)
         hn = hk.rmsnorm_fwd(x.view(B, S0, d)[:, -1].contiguous(), self.p["norm_w"], self.eps)
         logits = hk.gemm_nt(hn, self.p["lm_head"], out_f32=True)  # [B, V] fp32 (HF: logits.float())
         all_logits = [logits.clone()] if return_logits else []
@@ -454,7 +459,7 @@ class TextModal:
 
         n_done = 1
         if B <= 8:
-            s = self._decode_session(B, max_ctx, caches, max_new_tokens, weights)
+            s = self._decode_session(B, max_ctx, caches, max_new_tokens, weights, kmask)
             s.state[0], s.state[1] = S0, 0
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
@@ -496,7 +501,7 @@ class TextModal:
                 x = hk.gather_rows(self.p["embed"], out_ids[-1].clamp(0, self.vocab - 1).to(torch.int32))
                 desc = hk.make_desc([(b, 1, b * max_ctx, ctx + 1, ctx + 1, ctx) for b in range(B)], dev)
                 for L, cache in zip(self.p["layers"], caches):
-                    x = self._layer_step(L, x, B, 1, ctx, cache, desc, max_ctx)
+                    x = self._layer_step(L, x, B, 1, ctx, cache, desc, max_ctx, kmask)
                 logits = hk.gemm_nt(hk.rmsnorm_fwd(x, self.p["norm_w"], self.eps), self.p["lm_head"], out_f32=True)
                 if return_logits:
                     all_logits.append(logits.clone())

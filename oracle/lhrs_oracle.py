@@ -242,23 +242,31 @@ def unibind_forward(P: Dict, batch: Dict, collect: Optional[Dict] = None) -> tor
 
 # ------------------------------------------------------------------------------------------------- generate (greedy)
 @torch.no_grad()
-def generate_logits(P: Dict, rgb: torch.Tensor, input_ids: torch.Tensor, forced_tokens: torch.Tensor) -> torch.Tensor:
+def generate_logits(P: Dict, rgb: torch.Tensor, input_ids: torch.Tensor, forced_tokens: torch.Tensor,
+                    attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """UniBind.generate / TextModal.generate (lhrs/models/UniBind.py:214-242, lhrs/models/text_modal.py:528-627) restated
     WITHOUT a KV cache: for step t the full sequence [spliced prompt | forced_tokens[:, :t]] is re-run and the logits of the
-    last position are returned -> [B, n_new, V].  Greedy decoding = argmax of these logits (HF do_sample=False)."""
+    last position are returned -> [B, n_new, V].  Greedy decoding = argmax of these logits (HF do_sample=False).
+    attention_mask (batched evaluation, left-padded prompts: main_vqa.py:205-214) goes through the splice's mask rule and hides
+    keys; positions stay arange(S) because CustomLlamaForCausalLM.prepare_inputs_for_generation (text_modal.py:36-60) passes no
+    position_ids; generated positions are visible (HF generate appends ones)."""
     img = pooler_forward(P["pooler"], vit_forward(P["vit"], rgb))
-    src, _, _ = splice(input_ids, None, None, img.shape[1])
+    src, _, mask = splice(input_ids, None, attention_mask, img.shape[1])
     B, S0 = src.shape
     emb = P["llama"]["embed"]
     tok = emb[torch.gather(input_ids.clamp(min=0), 1, src.clamp(min=0))]
     img_rows = img[torch.arange(B)[:, None], (-src - 1).clamp(0, img.shape[1] - 1)]
     embeds = torch.where((src < 0)[..., None], img_rows, tok)
+    if attention_mask is None:
+        mask = None
     out = []
     for t in range(forced_tokens.shape[1] + 1):
         if t > 0:
             embeds = torch.cat([embeds, emb[forced_tokens[:, t - 1]][:, None]], 1)
+            if mask is not None:
+                mask = torch.cat([mask, torch.ones((B, 1), dtype=mask.dtype)], 1)
         if t == forced_tokens.shape[1]:
             break
-        h = llama_hidden(P["llama"], embeds, None)
+        h = llama_hidden(P["llama"], embeds, mask)
         out.append(F.linear(h[:, -1], P["llama"]["lm_head"]).float())
     return torch.stack(out, 1)

@@ -110,3 +110,55 @@ def test_fp8_weight_decode_and_fused_prologues():
     _, lg_f8 = model.generate(ids, images=rgb, do_sample=False, max_new_tokens=5, return_logits=True, weights="fp8")
     assert rel(lg_f8[:, 0], lg_bf[:, 0]) == 0.0        # the prefill is bf16 in both
     assert rel(lg_f8[:, 1:2], lg_bf[:, 1:2]) < 1e-1    # first decoded step: e4m3 weight error only (same token fed; random weights)
+
+
+@pytest.mark.timeout(900)
+def test_batched_left_padded_generate():
+    """§8 f-3 (main_vqa.py:205-214): LEFT-padded prompts + attention_mask; the spliced mask hides keys inside the kernels
+    (lhrs_attn_fwd_kmask) in the prefill and in every cached step, graph-captured or eager."""
+    import os
+    import numpy as np
+    Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "batch_generate.npz"))
+    P = {"vit": OP.make_vit_params(seed=2), "pooler": OP.make_pooler_params(seed=1), "llama": OP.make_llama_params(seed=3, layers=2)}
+    model = UniBind(("rgb", "text"), None, device=DEV, llama_layers=2).load_params(P).eval()
+    rgb = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(int(Z["rgb_seed"])))
+    ids, mask = torch.from_numpy(Z["input_ids"]), torch.from_numpy(Z["attention_mask"])
+    NEW = 5
+    new_ids, logits = model.generate(ids, images=rgb, attention_mask=mask, do_sample=False, max_new_tokens=NEW, return_logits=True)
+    assert new_ids.shape == (3, NEW) and torch.equal(new_ids, logits.argmax(-1))
+    # step 0 (the prefill) against the REFERENCE's logits, later steps against the oracle teacher-forced with the engine's tokens
+    cols = torch.from_numpy(Z["logits_cols"])
+    assert rel(logits[:, 0].cpu()[:, cols], torch.from_numpy(Z["logits"])[:, 0]) < 3e-2
+    want = O.generate_logits(P, rgb, ids, new_ids.cpu(), attention_mask=mask)
+    assert rel(logits, want) < 3e-2
+    picked = want.gather(-1, new_ids.cpu()[..., None]).squeeze(-1)
+    assert torch.all(want.max(-1).values - picked < 0.15 * want.std(-1))
+    # the mask matters: without it the padded rows change, the unpadded row 0 does not
+    _, lg_nomask = model.generate(ids, images=rgb, attention_mask=None, do_sample=False, max_new_tokens=1, return_logits=True)
+    assert rel(lg_nomask[0], logits[0, :1]) < 1e-6 and rel(lg_nomask[2], logits[2, :1]) > 1e-3
+    # eager launches == replayed graph, bit for bit, with the mask in place
+    b_ids, b_lg = model.generate(ids, images=rgb, attention_mask=mask, do_sample=False, max_new_tokens=NEW, return_logits=True, use_graph=False)
+    assert torch.equal(b_ids, new_ids) and torch.equal(b_lg, logits)
+
+
+def test_attention_key_mask_kernel():
+    import math
+    g = torch.Generator().manual_seed(9)
+    H, D, S = 4, 128, 150
+    for nq in (S, 1):
+        q = torch.randn(2 * nq, H * D, generator=g).to(DEV, torch.bfloat16)
+        k = torch.randn(2 * S, H * D, generator=g).to(DEV, torch.bfloat16)
+        v = torch.randn(2 * S, H * D, generator=g).to(DEV, torch.bfloat16)
+        km = (torch.rand(2, S, generator=g) > 0.3).to(torch.uint8)
+        km[:, 0] = 1
+        o = torch.empty_like(q)
+        coff = S - nq
+        desc = hk.make_desc([(b * nq, nq, b * S, S, S, coff) for b in range(2)], DEV)
+        hk.attn_fwd(q, k, v, o, None, desc, 2, H, D, nq, S, hk.pad64(nq), True, 1 / math.sqrt(D), key_mask=km.to(DEV))
+        qf, kf, vf = (t.float().cpu().view(2, -1, H, D).transpose(1, 2) for t in (q, k, v))
+        bias = torch.zeros(2, 1, nq, S)
+        bias.masked_fill_(~km.bool()[:, None, None, :], float("-inf"))
+        causal = torch.arange(S)[None, :] > (torch.arange(nq)[:, None] + coff)
+        bias.masked_fill_(causal[None, None], float("-inf"))
+        ref = (torch.softmax(qf @ kf.transpose(-1, -2) / math.sqrt(D) + bias, -1) @ vf).transpose(1, 2).reshape(2 * nq, H * D)
+        assert rel(o, ref) < 1e-2

@@ -121,3 +121,22 @@ def test_adamw_restatement_matches_torch():
         opt.step()
         adamw_step_ref(st, grad, step, lr=1e-3, wd=0.1)
         assert (w.detach() - st["p"]).abs().max() < 1e-12
+
+
+def test_batched_left_padded_generate_matches_reference():
+    """§8 f-3: left-padded prompts + attention_mask through splice mask rule -> masked causal LLaMA, teacher-forced steps."""
+    Z = np.load(os.path.join(G, "batch_generate.npz"))
+    P = {"vit": OP.make_vit_params(seed=2), "pooler": OP.make_pooler_params(seed=1),
+         "llama": OP.make_llama_params(seed=3, layers=int(Z["n_llama_layers"]))}
+    rgb = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(int(Z["rgb_seed"])))
+    assert abs(rgb.double().sum().item() - float(Z["rgb_checksum"])) < 1e-6
+    ids, mask = torch.from_numpy(Z["input_ids"]), torch.from_numpy(Z["attention_mask"])
+    _, _, new_mask = O.splice(ids, None, mask, 144)
+    assert np.array_equal(new_mask.numpy(), Z["new_mask"])      # the reference's mask rule on LEFT-padded rows, bit exact
+    got = O.generate_logits(P, rgb, ids, torch.from_numpy(Z["forced_tokens"]), attention_mask=mask)
+    want = torch.from_numpy(Z["logits"])
+    sub = got[:, :, torch.from_numpy(Z["logits_cols"])]
+    assert sub.shape == want.shape
+    assert ((sub - want).norm() / want.norm()).item() < 2e-4
+    clear = torch.from_numpy(Z["top2_margin"]) > 1e-3
+    assert torch.equal(got.argmax(-1)[clear], torch.from_numpy(Z["argmax"])[clear])
