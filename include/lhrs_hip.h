@@ -168,6 +168,14 @@ int lhrs_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_
                     int step, float lr, float beta1, float beta2, float eps, float weight_decay, const float* gnorm_sq,
                     float max_norm, float grad_scale, void* stream);
 
+/* ---- data boundary: the image transform of the reference -------------------------------------------
+ * CLIPImageProcessor.preprocess as built by build_vlp_transform (lhrs/Dataset/build_transform.py:43-45) for one decoded RGB image:
+ * img = uint8 [H][W][3] on the device (row_stride bytes per row) -> out = float32 [3][224][224].  Bit-exact with Pillow's BICUBIC
+ * resize (short edge -> 224), center crop, /255, CLIP mean/std.  workspace: lhrs_clip_preprocess_workspace(H, W) bytes, caller-owned. */
+long lhrs_clip_preprocess_workspace(int H, int W);
+int lhrs_clip_preprocess(const unsigned char* img, int H, int W, long row_stride, float* out, void* workspace,
+                         long workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ REPO_ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(REPO_ROOT, "include", "lhrs_hip.h")
 LIB_PATH = os.environ.get("LHRS_HIP_LIB") or os.path.join(_HERE, "csrc", "liblhrs_hip.so")  # override: kernel experiments only
 
-_PROTO = re.compile(r"^\s*(const\s+char\s*\*|int|void)\s+(lhrs_\w+)\s*\(([^;{]*)\)\s*;", re.M | re.S)
+_PROTO = re.compile(r"^\s*(const\s+char\s*\*|int|long|void)\s+(lhrs_\w+)\s*\(([^;{]*)\)\s*;", re.M | re.S)
 
 
 def _strip_comments(text: str) -> str:
@@ -46,7 +46,7 @@ def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:
     for ret, name, params in _PROTO.findall(text):
         params = " ".join(params.split())
         args = [] if params in ("", "void") else [_ctype_of(p) for p in params.split(",")]
-        restype = ctypes.c_char_p if "char" in ret else (None if ret.strip() == "void" else ctypes.c_int)
+        restype = ctypes.c_char_p if "char" in ret else (None if ret.strip() == "void" else (ctypes.c_long if ret.strip() == "long" else ctypes.c_int))
         out[name] = (restype, args)
     return out
 

@@ -74,3 +74,43 @@ class DataCollatorForSupervisedDataset:
         if "valid_image" in instances[0]:
             batch["valid_image"] = torch.tensor([inst["valid_image"] for inst in instances])
         return batch
+
+
+class CLIPImageProcessorHIP:
+    """Drop-in for the transform `build_vlp_transform` returns for the ViT arch (lhrs/Dataset/build_transform.py:43-45, HF
+    `CLIPImageProcessor`): `.preprocess(images, return_tensors="pt")["pixel_values"]` -> float32 [B, 3, 224, 224] ON THE DEVICE,
+    bit-exact with the PIL pipeline (resize short edge 224 BICUBIC, center crop, /255, CLIP mean/std) but computed by
+    `lhrs_clip_preprocess`: the DataLoader only has to decode and ship uint8 pixels.  Accepts PIL images, uint8 HWC numpy
+    arrays or uint8 HWC tensors (host or device)."""
+
+    crop_size = {"height": 224, "width": 224}
+    image_mean = (0.48145466, 0.4578275, 0.40821073)
+    image_std = (0.26862954, 0.26130258, 0.27577711)
+
+    def __init__(self, device="cuda"):
+        from . import _lib
+        _lib.load()
+        self.device = torch.device(device)
+
+    def _to_u8(self, im) -> torch.Tensor:
+        if isinstance(im, torch.Tensor):
+            t = im
+        else:
+            import numpy as np
+            if hasattr(im, "convert"):  # PIL: do_convert_rgb
+                im = np.asarray(im.convert("RGB"))
+            t = torch.from_numpy(np.ascontiguousarray(im))
+        if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
+            raise ValueError(f"expected a uint8 [H, W, 3] image, got {tuple(t.shape)} {t.dtype}")
+        return t.to(self.device).contiguous()
+
+    def preprocess(self, images, return_tensors="pt", **_kw) -> Dict[str, torch.Tensor]:
+        from . import kernels as hk
+        if not isinstance(images, (list, tuple)):
+            images = [images]
+        out = torch.empty((len(images), 3, 224, 224), device=self.device, dtype=torch.float32)
+        for b, im in enumerate(images):
+            hk.clip_preprocess(self._to_u8(im), out=out[b])
+        return {"pixel_values": out}
+
+    __call__ = preprocess

@@ -439,3 +439,19 @@ def adamw_step(p, g, m, v, shadow, step, lr, betas=(0.9, 0.95), eps=1e-8, wd=0.0
     st = _L().lhrs_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(shadow), p.numel(), step, lr, betas[0],
                               betas[1], eps, wd, _p(gnorm_sq), max_norm, grad_scale, _stream())
     _lib.check(st, "adamw_step")
+
+
+# --------------------------------------------------------------------------------------------- data boundary (images)
+def clip_preprocess(img_u8: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """uint8 [H, W, 3] device tensor -> float32 [3, 224, 224] pixel_values, bit-exact with CLIPImageProcessor (lhrs_clip_preprocess)."""
+    assert img_u8.dtype == torch.uint8 and img_u8.dim() == 3 and img_u8.shape[2] == 3 and img_u8.is_cuda and img_u8.stride(2) == 1 \
+        and img_u8.stride(1) == 3, "clip_preprocess: uint8 [H, W, 3] device tensor with packed pixels"
+    H, W = int(img_u8.shape[0]), int(img_u8.shape[1])
+    if out is None:
+        out = torch.empty((3, 224, 224), device=img_u8.device, dtype=torch.float32)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == 3 * 224 * 224
+    nbytes = _L().lhrs_clip_preprocess_workspace(H, W)
+    ws = torch.empty(nbytes, device=img_u8.device, dtype=torch.uint8)
+    st = _L().lhrs_clip_preprocess(img_u8.data_ptr(), H, W, img_u8.stride(0), out.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    _lib.check(st, "clip_preprocess")
+    return out

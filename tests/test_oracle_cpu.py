@@ -140,3 +140,17 @@ def test_batched_left_padded_generate_matches_reference():
     assert ((sub - want).norm() / want.norm()).item() < 2e-4
     clear = torch.from_numpy(Z["top2_margin"]) > 1e-3
     assert torch.equal(got.argmax(-1)[clear], torch.from_numpy(Z["argmax"])[clear])
+
+
+def test_clip_image_preprocess_bit_exact_against_pillow_and_hf():
+    """§8 f-2: Pillow BICUBIC resize (8-bit, two passes) + HF CLIPImageProcessor arithmetic, uint8 and float32 bit-exact."""
+    import hashlib
+    from image_cases import CASES, make_image
+    from oracle import image_oracle as IO
+    Z = np.load(os.path.join(G, "clip_preprocess.npz"))
+    assert [tuple(c) for c in Z["cases"]] == CASES
+    for i, (h, w) in enumerate(CASES):
+        crop, pv = IO.clip_preprocess(make_image(100 + i, h, w))
+        assert np.array_equal(crop[::9, ::9], Z[f"u8_sample_{i}"]) and np.array_equal(pv[:, ::9, ::9], Z[f"f32_sample_{i}"])
+        assert hashlib.sha256(np.ascontiguousarray(crop).tobytes()).hexdigest() == str(Z[f"u8_sha_{i}"])
+        assert hashlib.sha256(np.ascontiguousarray(pv).tobytes()).hexdigest() == str(Z[f"f32_sha_{i}"])
