@@ -79,5 +79,31 @@ coll = cd.DataCollatorForSupervisedDataset(tokenizer=tok)
 inst = [{"text": {"input_ids": pp["input_ids"][i], "labels": pp["labels"][i]}, "rgb": torch.full((3, 2, 2), float(i)), "valid_image": i % 2 == 0} for i in range(3)]
 b = coll(inst)
 out["coll"] = {k: v.tolist() for k, v in b.items()}
+# ---- stages 2/3: llava_llama_2 conversations (preprocess_multimodal + preprocess_llama_2) and the evaluation collator
+cd.conversation_lib.default_conversation = cd.conversation_lib.conv_templates["llava_llama_2"]
+ToyTok.model_max_length = 512
+l2_cases = [
+    [{"Question": "What is in the picture? <image>", "Answer": "an airport with two runways"}],
+    [{"Question": "<image>\nDescribe it.", "Answer": "dense forest"}, {"Question": "How many roads?", "Answer": "two roads cross"}],
+    [{"Question": "no picture here", "Answer": "ok"}],
+]
+out["l2_sources"] = l2_cases
+out["l2"] = []
+for src in l2_cases:
+    s2 = cd.preprocess_multimodal(copy.deepcopy(src), tune_im_start=False)
+    r = cd.preprocess(copy.deepcopy(s2), tok, has_image=True)
+    conv = cd.conversation_lib.default_conversation.copy()
+    for s in s2:
+        for j, k in enumerate(s):
+            conv.append_message(conv.roles[j % 2], s[k])
+    out["l2"].append({"mm": s2, "prompt": conv.get_prompt(), "ids": r["input_ids"].tolist(), "labels": r["labels"].tolist()})
+ToyTok.model_max_length = 40     # shorter than the 2-turn sample: the "cur_len < model_max_length" guard is skipped
+r = cd.preprocess(copy.deepcopy(out["l2"][1]["mm"]), tok, has_image=True)
+out["l2_short_ctx"] = {"ids": r["input_ids"].tolist(), "labels": r["labels"].tolist()}
+ToyTok.model_max_length = 24
+vg = cd.DataCollatorForVGSupervisedDataset(tokenizer=tok)
+inst = [(torch.full((3, 2, 2), float(i)), list(range(5, 5 + n)), "t%d" % i, "f%d.png" % i) for i, n in enumerate([4, 9, 30])]
+images, ids, targets, names, mask = vg(inst)
+out["vg"] = {"ids": ids.tolist(), "mask": mask.tolist(), "targets": targets, "names": names, "images_shape": list(images.shape)}
 json.dump(out, open(os.path.join(HERE, "data_boundary.json"), "w"))
 print("data golden:", [len(x) for x in out["tit"]], [len(x) for x in out["pp_ids"]], list(b.keys()), b["input_ids"].shape)

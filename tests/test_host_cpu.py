@@ -183,3 +183,21 @@ def test_data_boundary_matches_reference_functions():
             for i in range(3)]
     b = D.DataCollatorForSupervisedDataset(tok)(inst)
     assert {k: v.tolist() for k, v in b.items()} == z["coll"]   # incl. truncation at model_max_length = 24
+    # stages 2/3: <image> hoisting, the llava_llama_2 prompt, label masking (one conversation per call; blanking rule)
+    ToyTok.model_max_length = 512
+    for src, want in zip(z["l2_sources"], z["l2"]):
+        mm = D.preprocess_multimodal(copy.deepcopy(src), tune_im_start=False)
+        assert mm == want["mm"]
+        msgs = [[D.LLAMA_2_ROLES[j % 2], s[k]] for s in mm for j, k in enumerate(s)]
+        assert D.llama_2_prompt(msgs) == want["prompt"]
+        r = D.preprocess(copy.deepcopy(mm), tok, has_image=True, sep_style="llama_2")
+        assert r["input_ids"].tolist() == want["ids"] and r["labels"].tolist() == want["labels"]
+    ToyTok.model_max_length = 40
+    r = D.preprocess(copy.deepcopy(z["l2"][1]["mm"]), tok, has_image=True)
+    assert r["input_ids"].tolist() == z["l2_short_ctx"]["ids"] and r["labels"].tolist() == z["l2_short_ctx"]["labels"]
+    # evaluation collator: LEFT padding, truncation, mask
+    ToyTok.model_max_length = 24
+    inst = [(torch.full((3, 2, 2), float(i)), list(range(5, 5 + n)), "t%d" % i, "f%d.png" % i) for i, n in enumerate([4, 9, 30])]
+    images, ids, targets, names, mask = D.DataCollatorForVGSupervisedDataset(tok)(inst)
+    assert ids.tolist() == z["vg"]["ids"] and mask.tolist() == z["vg"]["mask"] and targets == z["vg"]["targets"]
+    assert names == z["vg"]["names"] and list(images.shape) == z["vg"]["images_shape"]
