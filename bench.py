@@ -90,6 +90,49 @@ def cpu_baseline(S: int, budget_s: float = 25.0):
                        f"+ 1 of 32 LLaMA-7B layers fwd+dX-bwd {t_layer:.2f}s, extrapolated x32 (oracle/lhrs_oracle.py, fp32 torch CPU)")}
 
 
+
+class _SmiSampler:
+    """Background rocm-smi sampling (shader clock, package power) during the timed region, rank 0 only.  Evidence for the DVFS
+    ceiling the MFMA-bound step runs under (MI355X caps at 1400 W: random-valued bf16 operands pull sclk from 2.4 GHz to ~1.7 GHz);
+    best effort - any failure just leaves the fields null."""
+
+    def __init__(self):
+        import threading
+        self.samples, self._stop = [], False
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self._stop:
+            try:
+                o = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5).stdout
+                c = re.search(r'"sclk clock speed:"\s*:\s*"\((\d+)Mhz\)"', o)
+                p = re.search(r'Graphics Package Power \(W\)"\s*:\s*"([\d.]+)"', o)
+                if c:
+                    self.samples.append((int(c.group(1)), float(p.group(1)) if p else None))
+            except Exception:  # noqa: BLE001
+                return
+            time.sleep(0.1)
+
+    def start(self):
+        try:
+            self._th.start()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def stop(self):
+        self._stop = True
+        try:
+            self._th.join(timeout=6)
+        except Exception:  # noqa: BLE001
+            pass
+        s = self.samples[1:] if len(self.samples) > 2 else self.samples
+        if not s:
+            return None, None
+        pw = [p for _, p in s if p is not None]
+        return sum(c for c, _ in s) / len(s), (sum(pw) / len(pw) if pw else None)
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,6 +205,9 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    smi = _SmiSampler() if rank == 0 else None
+    if smi is not None:
+        smi.start()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
@@ -169,6 +215,7 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    sclk, watts = smi.stop() if smi is not None else (None, None)
     prof = (ctypes.c_double * 5)()
     _lib.check(lib.lhrs_gemm_profile_read(ctypes.addressof(prof)), "gemm_profile_read")
     lib.lhrs_gemm_profile_enable(0)
@@ -203,6 +250,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_256r_kernel (256x256 tile, 16 waves, BK=64 double-buffered LDS stages via global_load_lds DMA, v_mfma_f32_32x32x16_bf16)", "achieved": round(ach, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "launches_timed": int(n_samp), "avg_launch_us": round(1e3 * ms / max(n_samp, 1), 2),
+                         "sclk_mhz_during_timed_region": round(sclk) if sclk else None, "package_power_w": round(watts) if watts else None,
+                         "frac_of_peak_at_measured_clock": round(ach / (PEAK_BF16_TFLOPS * sclk / 2400.0), 4) if sclk else None,
                          "gemm_flops_share_of_step": round(prof[4] / a.steps / (B * f_alg(S)), 3) if scale_layers == 1.0 else None},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -134,13 +134,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
   }
 }
 
-__global__ void layernorm_bwd_finalize(const float* __restrict__ partial, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int nblk, int cols, int accumulate) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= cols) return;
+// 32 columns x 8 row-slices per block: slice sl folds partial blocks sl, sl+8, ... and the slices are added in a fixed order
+__global__ __launch_bounds__(256) void layernorm_bwd_finalize(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int nblk, int cols, int accumulate) {
+  __shared__ float red[2][8][32];
+  const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + c;
   float a = 0.f, b = 0.f;
-  for (int k = 0; k < nblk; ++k) { a += partial[((long)k * 2) * cols + j]; b += partial[((long)k * 2 + 1) * cols + j]; }
-  if (accumulate) { dgamma[j] += a; dbeta[j] += b; } else { dgamma[j] = a; dbeta[j] = b; }
+  if (j < cols)
+    for (int k = sl; k < nblk; k += 8) { a += partial[((long)k * 2) * cols + j]; b += partial[((long)k * 2 + 1) * cols + j]; }
+  red[0][sl][c] = a; red[1][sl][c] = b;
+  __syncthreads();
+  if (sl == 0 && j < cols) {
+    a = 0.f; b = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a += red[0][i][c]; b += red[1][i][c]; }
+    if (accumulate) { dgamma[j] += a; dbeta[j] += b; } else { dgamma[j] = a; dbeta[j] = b; }
+  }
 }
 
 // ---------------------------------------------------------------- RMSNorm
@@ -271,7 +281,7 @@ extern "C" int lhrs_layernorm_bwd(const void* dy, long ld_dy, const void* x, lon
   }
   LHRS_CHECK_LAUNCH("layernorm_bwd");
   if (dgamma) {
-    hipLaunchKernelGGL(layernorm_bwd_finalize, dim3(cdiv(cols, 256)), dim3(256), 0, s, part, dgamma, dbeta, nblk, cols,
+    hipLaunchKernelGGL(layernorm_bwd_finalize, dim3(cdiv(cols, 32)), dim3(256), 0, s, part, dgamma, dbeta, nblk, cols,
                        accumulate);
     LHRS_CHECK_LAUNCH("layernorm_bwd_finalize");
   }
