@@ -48,6 +48,15 @@ int lhrs_gemm_bf16_nt_lora(const void* A, int lda, const void* B, int ldb, const
                            int out_f32, int accumulate, float alpha, void* stream);
 /* 256x256-tile kernel choice (tuning / A-B tests): 0 never, 1 plain 4-stage ring, 2 default (16-wave BK=64 two-buffer kernel
  * when K % 64 == 0, else the BK=32 ring), 3 the 8-wave BK=64 kernel, 4 always the BK=32 ring */
+/* LLaMA MLP with SwiGLU fused into the GEMM epilogues (HF LlamaMLP.forward: down(silu(gate(x)) * up(x)); text_modal.py:258-294).
+ * fwd: gu[M, 2*ff] = X.Wgu^T (+ A2.B2^T), act[M, ff] = silu(gate) * up.  bwd: dgu[M, 2*ff] = swiglu'(gu) * (dY.WdT^T (+ A2.B2^T)),
+ * dgu may alias gu; dact_scratch [M, ff] is only touched by the unfused fallback (may be NULL when lhrs_gemm_swiglu_fusable() == 1).
+ * Bit-identical to GEMM + lhrs_swiglu_fwd / lhrs_swiglu_bwd. */
+int lhrs_gemm_swiglu_fusable(int M, int ff, int K_fwd, int K_bwd, int K2);
+int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int ldw, const void* A2, int lda2, const void* B2, int ldb2,
+                         int K2, void* gu, int ld_gu, void* act, int ld_act, int M, int ff, int K, void* stream);
+int lhrs_gemm_swiglu_bwd(const void* dY, int ldy, const void* WdT, int ldw, const void* A2, int lda2, const void* B2, int ldb2,
+                         int K2, const void* gu, void* dgu, int ld_gu, void* dact_scratch, int M, int ff, int K, void* stream);
 int lhrs_gemm_set_policy(int allow_256);
 int lhrs_gemm_profile_enable(int max_samples);
 int lhrs_gemm_profile_read(double* out5_host);

@@ -97,6 +97,13 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
+__device__ __forceinline__ void unpack8(const uint4& u, float (&v)[8]) {
+  v[0] = bflo(u.x); v[1] = bfhi(u.x); v[2] = bflo(u.y); v[3] = bfhi(u.y);
+  v[4] = bflo(u.z); v[5] = bfhi(u.z); v[6] = bflo(u.w); v[7] = bfhi(u.w);
+}
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+  return make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+}
 __device__ __forceinline__ float silu(float x) { return x / (1.f + __expf(-x)); }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

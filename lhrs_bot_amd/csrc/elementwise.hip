@@ -9,13 +9,6 @@
 
 namespace {
 
-__device__ __forceinline__ void unpack8(const uint4& u, float (&v)[8]) {
-  v[0] = bflo(u.x); v[1] = bfhi(u.x); v[2] = bflo(u.y); v[3] = bfhi(u.y);
-  v[4] = bflo(u.z); v[5] = bfhi(u.z); v[6] = bflo(u.w); v[7] = bfhi(u.w);
-}
-__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
-  return make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-}
 
 // ---- im2col for the 14x14/stride-14 patch conv.  out[(b*GP*GP + py*GP + px)][k], k = c*P*P + i*P + j, zero for k >= 3*P*P
 __global__ void patchify_kernel(const float* __restrict__ rgb, bf16_t* __restrict__ out, int B, int img, int P, int KP) {

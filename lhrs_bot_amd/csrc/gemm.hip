@@ -41,6 +41,14 @@ struct GemmArgs {
   const bf16_t* A2;
   const bf16_t* B2;
   int lda2, ldb2, K2;
+  // fused SwiGLU epilogues of the 16-wave 256x256 kernel (LLaMA MLP, HF LlamaMLP: down(silu(gate(x)) * up(x))):
+  //   epi 1: B = [gate; up] weight [2*ff, K]; tile tn holds gate AND up of columns [tn*128, +128) (wave wn: 32 gate + 32 up);
+  //          C = gate|up [M, 2*ff] in the usual layout, aux_out = silu(gate) * up [M, ff]
+  //   epi 2: A.B^T = d_act [M, ff]; aux = gate|up [M, 2*ff]; C = d(gate|up) [M, 2*ff] (may alias aux)
+  int epi, ff;
+  const bf16_t* aux;
+  bf16_t* aux_out;
+  long ld_aux;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -775,7 +783,7 @@ __device__ __forceinline__ void lds_wait4(bf16x8 (&a)[2], bf16x8 (&b)[2]) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int ACT>
+template <int ACT, int EPI = 0>
 __global__ __launch_bounds__(1024, 1) void gemm_nt_256r_kernel(GemmArgs g) {
   constexpr int BM = 256, BN = 256, BK = 64;
   constexpr int A_BYTES = BM * BK * 2, STAGE = A_BYTES + BN * BK * 2;
@@ -799,7 +807,11 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256r_kernel(GemmArgs g) {
   for (int j = 0; j < 4; ++j) {
     const int ridx = (wave & 7) * 4 + j;
     const int lchunk = (lane & 7) ^ ((((j & 1) << 2) + (lane >> 4)) & 7);
-    const int row = min(row0 + ridx * 8 + (lane >> 3), rmax);
+    int row = min(row0 + ridx * 8 + (lane >> 3), rmax);
+    if (EPI == 1 && !isA) {  // B tile row r = 64*wn + 32*half + i  <-  weight row half*ff + tn*128 + wn*32 + i
+      const int r = ridx * 8 + (lane >> 3);
+      row = ((r >> 5) & 1) * g.ff + tn * 128 + (r >> 6) * 32 + (r & 31);
+    }
     off1[j] = (unsigned)(((long)row * ld1 + lchunk * 8) * 2);
     off2[j] = g.K2 > 0 ? (unsigned)(((long)row * ld2 + lchunk * 8) * 2) : 0u;
   }
@@ -906,7 +918,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256r_kernel(GemmArgs g) {
       for (int q = 0; q < 4; ++q) {
         const int n = min(tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4, g.N - 4);
         uint2 bb = make_uint2(0, 0);
-        if (g.bias) bb = *reinterpret_cast<const uint2*>(g.bias + n);
+        if (EPI == 0 && g.bias) bb = *reinterpret_cast<const uint2*>(g.bias + n);
         bias_v[ni][q][0] = bflo(bb.x); bias_v[ni][q][1] = bfhi(bb.x); bias_v[ni][q][2] = bflo(bb.y); bias_v[ni][q][3] = bfhi(bb.y);
       }
 #pragma unroll
@@ -930,14 +942,32 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256r_kernel(GemmArgs g) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   {
     const int rsub = lane >> 3, c = lane & 7;
-    const int n = tn * BN + wn * 64 + c * 8;
+    // EPI 1: chunks 0-3 are gate columns, 4-7 the matching up columns of the [M, 2*ff] output
+    const int n = EPI == 1 ? (c < 4 ? 0 : g.ff) + tn * 128 + wn * 32 + (c & 3) * 8 : tn * BN + wn * 64 + c * 8;
+    const int nlim = EPI == 2 ? g.ff : g.N;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int row = i * 8 + rsub;
       const int m = tm * BM + wm * 64 + row;
       uint4 val = *reinterpret_cast<const uint4*>(reg + row * 128 + ((c ^ (row & 7)) << 4));
-      if (m < g.M && n < g.N) {
-        if (g.res) {
+      if (m < g.M && n < nlim) {
+        if (EPI == 2) {  // val = d_act (bf16-rounded like the unfused path): d(gate), d(up) from the saved gate|up
+          const uint4 gq = *reinterpret_cast<const uint4*>(g.aux + (long)m * g.ld_aux + n);
+          const uint4 uq = *reinterpret_cast<const uint4*>(g.aux + (long)m * g.ld_aux + g.ff + n);
+          float d[8], gg[8], uu[8], dg[8], du[8];
+          unpack8(val, d); unpack8(gq, gg); unpack8(uq, uu);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float sg = 1.f / (1.f + __expf(-gg[e]));
+            du[e] = d[e] * gg[e] * sg;
+            dg[e] = d[e] * uu[e] * sg * (1.f + gg[e] * (1.f - sg));
+          }
+          bf16_t* out = reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n;
+          *reinterpret_cast<uint4*>(out) = pack8(dg);
+          *reinterpret_cast<uint4*>(out + g.ff) = pack8(du);
+          continue;
+        }
+        if (EPI == 0 && g.res) {
           const uint4 r = *reinterpret_cast<const uint4*>(g.res + (long)m * g.ldr + n);
           val.x = pack2bf(bflo(val.x) + bflo(r.x), bfhi(val.x) + bfhi(r.x));
           val.y = pack2bf(bflo(val.y) + bflo(r.y), bfhi(val.y) + bfhi(r.y));
@@ -946,6 +976,34 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256r_kernel(GemmArgs g) {
         }
         *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n) = val;
       }
+    }
+  }
+  if (EPI == 1) {
+    // second pass: act = silu(gate) * up on the bf16-rounded gate / up (what the unfused kernel reads back), staged [64][32]
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int row = mi * 32 + fr;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float gv = bf2f(f2bf(acc[mi][0][4 * q + i] * g.alpha)), uv = bf2f(f2bf(acc[mi][1][4 * q + i] * g.alpha));
+          v[i] = silu(gv) * uv;
+        }
+        const int u = q * 2 + fh;  // 8-byte unit 0..7 of the 64-byte row
+        *reinterpret_cast<uint2*>(reg + row * 64 + ((u ^ ((row & 3) << 1)) << 3)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int rsub = lane >> 2, c = lane & 3;
+    const int n = tn * 128 + wn * 32 + c * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 16 + rsub;
+      const int m = tm * BM + wm * 64 + row;
+      const uint4 val = *reinterpret_cast<const uint4*>(reg + row * 64 + ((c ^ (row & 3)) << 4));
+      if (m < g.M) *reinterpret_cast<uint4*>(g.aux_out + (long)m * g.ld_aux + n) = val;
     }
   }
 }
@@ -1036,6 +1094,7 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   LHRS_REQUIRE(!accumulate || out_f32, "gemm: accumulate needs f32 output");
   LHRS_REQUIRE(act >= 0 && act <= 3, "gemm: unknown activation %d", act);
   GemmArgs g;
+  g.epi = 0; g.ff = 0; g.aux = nullptr; g.aux_out = nullptr; g.ld_aux = 0;
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C;
   g.bias = (const bf16_t*)bias; g.res = (const bf16_t*)residual;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
@@ -1115,5 +1174,80 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
 #undef LAUNCH_TILE
   if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], s);
   LHRS_CHECK_LAUNCH("gemm_bf16_nt");
+  return 0;
+}
+
+
+// ---- LLaMA MLP with the SwiGLU fused into the GEMM epilogues (HF LlamaMLP, reached from lhrs/models/text_modal.py:258-294) ----------
+// forward : gu[M, 2*ff] = x W_gu^T (+ LoRA pair), act[M, ff] = silu(gu[:, :ff]) * gu[:, ff:]     - one launch instead of GEMM + swiglu_fwd
+// backward: dgu[M, 2*ff] = swiglu'(gu) * (dy W_down) (+ LoRA pair); dgu may alias gu             - one launch instead of GEMM + swiglu_bwd
+// Results are bit-identical to the unfused sequence (the epilogue rounds gate / up / d_act to bf16 exactly where the unfused path
+// stores them).  Shapes the 16-wave 256x256 kernel does not take (K % 64, < 160 tiles, ff % 128) fall back to the unfused sequence.
+extern "C" int lhrs_swiglu_fwd(const void* gate_up, void* act, long rows, int F, void* stream);
+extern "C" int lhrs_swiglu_bwd(const void* dact, const void* gate_up, void* dgate_up, long rows, int F, void* stream);
+
+static bool swiglu_fusable(long tiles, int ff, int K, int K2, int lda, int ldb) {
+  return (g_gemm_allow_256 == 2 || g_gemm_allow_256 == 5) && ff % 256 == 0 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128 && tiles >= 160 &&
+         lda % 8 == 0 && ldb % 8 == 0;
+}
+// 1 when lhrs_gemm_swiglu_fwd / _bwd will take the fused kernel for this problem (dense operands), else 0 (they fall back)
+extern "C" int lhrs_gemm_swiglu_fusable(int M, int ff, int K_fwd, int K_bwd, int K2) {
+  const long tf = (long)cdiv(M, 256) * (ff / 128), tb = (long)cdiv(M, 256) * cdiv(ff, 256);
+  return swiglu_fusable(tf, ff, K_fwd, K2, 8, 8) && swiglu_fusable(tb, ff, K_bwd, K2, 8, 8);
+}
+
+static void prof_begin(int M, int N, int K, hipStream_t s, int& slot) {
+  slot = -1;
+  if (!g_prof.on) return;
+  g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * K;
+  if (g_prof.used < g_prof.cap) {
+    slot = g_prof.used++;
+    g_prof.flops[slot] = 2.0 * M * N * K;
+    (void)hipEventRecord(g_prof.ev[2 * slot], s);
+  }
+}
+
+extern "C" int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int ldw, const void* A2, int lda2, const void* B2, int ldb2,
+                                    int K2, void* gu, int ld_gu, void* act, int ld_act, int M, int ff, int K, void* stream) {
+  LHRS_REQUIRE(M > 0 && ff > 0 && K > 0 && ff % 8 == 0 && ld_gu >= 2 * ff && ld_act >= ff && ld_gu % 8 == 0 && ld_act % 8 == 0,
+               "gemm_swiglu_fwd: M=%d ff=%d K=%d ld_gu=%d ld_act=%d", M, ff, K, ld_gu, ld_act);
+  if (!swiglu_fusable((long)cdiv(M, 256) * (ff / 128), ff, K, K2, ldx, ldw)) {
+    if (gemm_launch(X, ldx, Wgu, ldw, gu, ld_gu, M, 2 * ff, K, nullptr, nullptr, 0, 0, 0, 0, 1.f, A2, lda2, B2, ldb2, K2, stream)) return -1;
+    LHRS_REQUIRE(ld_gu == 2 * ff && ld_act == ff, "gemm_swiglu_fwd: the unfused fallback needs dense gu / act");
+    return lhrs_swiglu_fwd(gu, act, M, ff, stream);
+  }
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  g.A = (const bf16_t*)X; g.B = (const bf16_t*)Wgu; g.C = gu; g.M = M; g.N = 2 * ff; g.K = K; g.lda = ldx; g.ldb = ldw; g.ldc = ld_gu;
+  g.alpha = 1.f; g.A2 = (const bf16_t*)A2; g.B2 = (const bf16_t*)B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
+  g.epi = 1; g.ff = ff; g.aux_out = (bf16_t*)act; g.ld_aux = ld_act;
+  g.tilesM = cdiv(M, 256); g.tilesN = ff / 128;
+  hipStream_t s = (hipStream_t)stream;
+  int slot;
+  prof_begin(M, 2 * ff, K + K2, s, slot);
+  hipLaunchKernelGGL((gemm_nt_256r_kernel<0, 1>), dim3(g.tilesM * g.tilesN), dim3(1024), 0, s, g);
+  if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], s);
+  LHRS_CHECK_LAUNCH("gemm_swiglu_fwd");
+  return 0;
+}
+
+extern "C" int lhrs_gemm_swiglu_bwd(const void* dY, int ldy, const void* WdT, int ldw, const void* A2, int lda2, const void* B2, int ldb2,
+                                    int K2, const void* gu, void* dgu, int ld_gu, void* dact_scratch, int M, int ff, int K, void* stream) {
+  LHRS_REQUIRE(M > 0 && ff > 0 && K > 0 && ff % 8 == 0 && ld_gu >= 2 * ff && ld_gu % 8 == 0, "gemm_swiglu_bwd: M=%d ff=%d K=%d ld_gu=%d", M, ff, K, ld_gu);
+  if (!swiglu_fusable((long)cdiv(M, 256) * cdiv(ff, 256), ff, K, K2, ldy, ldw)) {
+    LHRS_REQUIRE(dact_scratch != nullptr && ld_gu == 2 * ff, "gemm_swiglu_bwd: the unfused fallback needs a [M, ff] scratch and dense gu");
+    if (gemm_launch(dY, ldy, WdT, ldw, dact_scratch, ff, M, ff, K, nullptr, nullptr, 0, 0, 0, 0, 1.f, A2, lda2, B2, ldb2, K2, stream)) return -1;
+    return lhrs_swiglu_bwd(dact_scratch, gu, dgu, M, ff, stream);
+  }
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  g.A = (const bf16_t*)dY; g.B = (const bf16_t*)WdT; g.C = dgu; g.M = M; g.N = ff; g.K = K; g.lda = ldy; g.ldb = ldw; g.ldc = ld_gu;
+  g.alpha = 1.f; g.A2 = (const bf16_t*)A2; g.B2 = (const bf16_t*)B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
+  g.epi = 2; g.ff = ff; g.aux = (const bf16_t*)gu; g.ld_aux = ld_gu;
+  g.tilesM = cdiv(M, 256); g.tilesN = cdiv(ff, 256);
+  hipStream_t s = (hipStream_t)stream;
+  int slot;
+  prof_begin(M, ff, K + K2, s, slot);
+  hipLaunchKernelGGL((gemm_nt_256r_kernel<0, 2>), dim3(g.tilesM * g.tilesN), dim3(1024), 0, s, g);
+  if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], s);
+  LHRS_CHECK_LAUNCH("gemm_swiglu_bwd");
   return 0;
 }

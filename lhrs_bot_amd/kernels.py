@@ -66,6 +66,37 @@ def gemm_nt_lora(a, b, a2, b2, out=None, *, bias=None, residual=None, out_f32=Fa
     return out
 
 
+def gemm_swiglu_fwd(x, w_gu, ff, a2=None, b2=None):
+    """(gu [M, 2ff], act [M, ff]) = LLaMA MLP first half in ONE launch: gu = x @ w_gu^T (+ a2 @ b2^T), act = silu(gate) * up."""
+    M, K = x.shape
+    assert w_gu.shape[0] == 2 * ff
+    gu = torch.empty((M, 2 * ff), device=x.device, dtype=torch.bfloat16)
+    act = torch.empty((M, ff), device=x.device, dtype=torch.bfloat16)
+    K2 = a2.shape[1] if a2 is not None else 0
+    st = _L().lhrs_gemm_swiglu_fwd(x.data_ptr(), x.stride(0), w_gu.data_ptr(), w_gu.stride(0), _p(a2), a2.stride(0) if K2 else 0, _p(b2),
+                                   b2.stride(0) if K2 else 0, K2, gu.data_ptr(), gu.stride(0), act.data_ptr(), act.stride(0), M, ff, K,
+                                   _stream())
+    _lib.check(st, "gemm_swiglu_fwd")
+    return gu, act
+
+
+def gemm_swiglu_bwd(dy, w_down_t, gu, ff, a2=None, b2=None, out=None):
+    """dgu [M, 2ff] = swiglu'(gu) * (dy @ w_down_t^T (+ a2 @ b2^T)) in ONE launch; out defaults to gu (in place)."""
+    M, K = dy.shape
+    assert w_down_t.shape[0] == ff and gu.shape == (M, 2 * ff)
+    dgu = gu if out is None else out
+    K2 = a2.shape[1] if a2 is not None else 0
+    L = _L()
+    scratch = None
+    if not L.lhrs_gemm_swiglu_fusable(M, ff, K, K, K2):
+        scratch = torch.empty((M, ff), device=dy.device, dtype=torch.bfloat16)
+    st = L.lhrs_gemm_swiglu_bwd(dy.data_ptr(), dy.stride(0), w_down_t.data_ptr(), w_down_t.stride(0), _p(a2), a2.stride(0) if K2 else 0,
+                                _p(b2), b2.stride(0) if K2 else 0, K2, gu.data_ptr(), dgu.data_ptr(), gu.stride(0), _p(scratch), M, ff, K,
+                                _stream())
+    _lib.check(st, "gemm_swiglu_bwd")
+    return dgu
+
+
 def gemm_tn_skinny(p, q, out, accumulate=False):
     """out[KP, N] (+)= p[M, KP]^T @ q[M, N]  (fp32 out; p, q token-major bf16, row strides free)."""
     M, KP = p.shape

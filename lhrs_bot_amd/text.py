@@ -229,6 +229,29 @@ class TextModal:
             save["T_" + gname] = T
         return hk.gemm_nt_lora(x, W, T, lo.derived[(li, gname, "Bfull")], residual=residual)
 
+    def _gu_fwd(self, li, h, W, save):
+        """gate|up projection with the SwiGLU in the GEMM epilogue (one launch): -> (gu [M, 2ff], act [M, ff])."""
+        lo = self.lora
+        if lo is None or "gu" not in lo.groups:
+            return hk.gemm_swiglu_fwd(h, W, self.ff)
+        T = hk.gemm_nt(h, lo.view(lo.shadow, li, "gu", "A"), alpha=lo.s)
+        if save is not None:
+            save["T_gu"] = T
+        return hk.gemm_swiglu_fwd(h, W, self.ff, T, lo.derived[(li, "gu", "Bfull")])
+
+    def _down_bwd(self, li, dy, WT, gu, act, T):
+        """dgu (written over gu) = swiglu'(gu) * d_act with d_act = dy W_down (+ LoRA) never leaving the GEMM epilogue."""
+        lo = self.lora
+        if lo is None or "down" not in lo.groups:
+            return hk.gemm_swiglu_bwd(dy, WT, gu, self.ff)
+        G = lo.groups["down"]
+        U = hk.gemm_nt(dy, lo.view(lo.shadow, li, "down", "BD"), alpha=lo.s)
+        dgu = hk.gemm_swiglu_bwd(dy, WT, gu, self.ff, U, lo.derived[(li, "down", "AT")])
+        hk.gemm_tn_skinny(U, act, lo.view(lo.grad, li, "down", "A"))
+        dBD = hk.gemm_tn_skinny(T, dy, lo.view(lo.grad, li, "down", "BD"))
+        hk.blockdiag_mask(dBD, lo.r, G["fout"], G["mask"])
+        return dgu
+
     def _lin_bwd(self, li, gname, dy, WT, x, T):
         """dx = dy W (+ s (dy B) A); adapter gradients dA = (s dy B)^T x, dB^T = (s x A^T)^T dy written into lora.grad."""
         lo = self.lora
@@ -270,8 +293,7 @@ class TextModal:
         hk.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, desc, B, H, hd, S, S, LT, True, 1.0 / math.sqrt(hd))
         x_mid = self._lin(li, "o", o, L["o_w"], residual=x, save=rec)
         h = hk.rmsnorm_fwd(x_mid, L["ln2_w"], self.eps, out=h)
-        gu = self._lin(li, "gu", h, L["gu_w"], save=rec)
-        act = hk.swiglu_fwd(gu, ff)
+        gu, act = self._gu_fwd(li, h, L["gu_w"], rec)
         x_out = self._lin(li, "down", act, L["down_w"], residual=x_mid, save=rec)
         if save is not None:
             rec.update(x_in=x, qkv=qkv, o=o, lse=lse, x_mid=x_mid, gu=gu)
@@ -540,9 +562,8 @@ class TextModal:
             L, s = p["layers"][li], c["layers"][li]
             gu, qkv = s["gu"], s["qkv"]
             act = hk.swiglu_fwd(gu, ff) if lo is not None and "down" in lo.groups else None      # x of the down projection
-            dact = self._lin_bwd(li, "down", dx, L["down_wT"], act, s.get("T_down"))
+            dgu = self._down_bwd(li, dx, L["down_wT"], gu, act, s.get("T_down"))
             h2 = hk.rmsnorm_fwd(s["x_mid"], L["ln2_w"], self.eps) if lo is not None and "gu" in lo.groups else None
-            dgu = hk.swiglu_bwd(dact, gu, ff, out=gu)
             dh = self._lin_bwd(li, "gu", dgu, L["gu_wT"], h2, s.get("T_gu"))
             dx_mid = hk.rmsnorm_bwd(dh, s["x_mid"], L["ln2_w"], None, add=dx, eps=self.eps, out=dh)
             do = self._lin_bwd(li, "o", dx_mid, L["o_wT"], s["o"], s.get("T_o"))

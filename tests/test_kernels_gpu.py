@@ -398,3 +398,28 @@ def test_adan_and_clip_match_restatement():
         hk.adan_step(dp, dg, dm, dv, dn, dpre, shadow, step, 2e-4, wd=0.02, gnorm_sq=gn, max_norm=0.3)
         assert (dp.cpu().double() - state["p"]).abs().max() < 1e-6
     assert torch.equal(shadow, dp.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("M,lora", [(8190, False), (8190, True), (4095, False), (300, True)])
+def test_gemm_fused_swiglu_bit_identical_to_unfused(M, lora):
+    """lhrs_gemm_swiglu_fwd / _bwd == GEMM + swiglu kernels, bit for bit (fused 16-wave kernel at M >= 4095, fallback below)."""
+    g = torch.Generator().manual_seed(M + lora)
+    d, ff, KP = 4096, 11008, 128
+    x = torch.randn(M, d, generator=g).to(DEV, torch.bfloat16)
+    wgu = (torch.randn(2 * ff, d, generator=g) * 0.02).to(DEV, torch.bfloat16)
+    wdT = (torch.randn(ff, d, generator=g) * 0.02).to(DEV, torch.bfloat16)
+    dy = (torch.randn(M, d, generator=g) * 0.1).to(DEV, torch.bfloat16)
+    a2 = b2 = a2b = b2b = None
+    if lora:
+        a2 = (torch.randn(M, KP, generator=g) * 0.1).to(DEV, torch.bfloat16)
+        b2 = (torch.randn(2 * ff, KP, generator=g) * 0.05).to(DEV, torch.bfloat16)
+        a2b = (torch.randn(M, KP, generator=g) * 0.1).to(DEV, torch.bfloat16)
+        b2b = (torch.randn(ff, KP, generator=g) * 0.05).to(DEV, torch.bfloat16)
+    gu, act = hk.gemm_swiglu_fwd(x, wgu, ff, a2, b2)
+    gu_ref = hk.gemm_nt_lora(x, wgu, a2, b2) if lora else hk.gemm_nt(x, wgu)
+    act_ref = hk.swiglu_fwd(gu_ref, ff)
+    assert torch.equal(gu, gu_ref) and torch.equal(act, act_ref)
+    dact_ref = hk.gemm_nt_lora(dy, wdT, a2b, b2b) if lora else hk.gemm_nt(dy, wdT)
+    dgu_ref = hk.swiglu_bwd(dact_ref, gu_ref, ff)
+    dgu = hk.gemm_swiglu_bwd(dy, wdT, gu, ff, a2b, b2b)          # in place over gu
+    assert dgu.data_ptr() == gu.data_ptr() and torch.equal(dgu, dgu_ref)
