@@ -433,9 +433,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256p_kernel(GemmArgs g) {
   MF(A_, B_, 0, 0) MF(A_, B_, 0, 1) MF(A_, B_, 1, 0) MF(A_, B_, 1, 1) MF(A_, B_, 2, 0) MF(A_, B_, 2, 1) MF(A_, B_, 3, 0) MF(A_, B_, 3, 1)
 
   const int nk = (g.K + g.K2) / BK;  // >= 3 (host guarantees)
-#ifdef LHRS_GEMM_PRIO
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
   for (int s = 0; s < NS - 2; ++s)
 #pragma unroll
