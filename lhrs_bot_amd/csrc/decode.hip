@@ -16,7 +16,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 // PRO: what the block does to the activation rows while staging them in LDS (every block redoes it: 8-22 KB from L2)
 //   0 plain copy            1 RMSNorm (HF LlamaRMSNorm: w * bf16(x * rsqrt(mean x^2 + eps)))       2 SwiGLU: silu(x[k]) * x[K + k]
 // FP8: W is OCP e4m3 with one fp32 scale per output row (the 6.7 GB / token weight stream of SURVEY.md §8d)
-template <int NB, int PRO, bool FP8>
+template <int NB, int PRO, bool FP8, int RPW = 4, int KU = 1>
 __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, long ldw, const float* __restrict__ wscale,
                                                    const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ norm_w, float eps,
                                                    const bf16_t* res, long ldr, void* y, long ldy, int N, int K, int out_f32) {
@@ -54,40 +54,49 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
     }
   }
   __syncthreads();
-  const int row0 = blockIdx.x * 16 + wave * 4;  // 4 waves x 4 rows in flight per wave
-  float acc[4][NB];
+  const int row0 = (blockIdx.x * 4 + wave) * RPW;  // 4 waves x RPW rows x KU 16-B loads in flight per lane
+  float acc[RPW][NB];
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int r = 0; r < RPW; ++r)
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
   if (!FP8) {
     const bf16_t* W = reinterpret_cast<const bf16_t*>(Wv);
-    for (int c = lane; c < nch; c += 64) {
-      uint4 w[4];
+    for (int c0 = lane; c0 < nch; c0 += 64 * KU) {
+      uint4 w[KU][RPW];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = min(row0 + r, N - 1);
-        const i32x4 t = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(W + (long)row * ldw + c * 8));
-        w[r] = make_uint4((unsigned)t[0], (unsigned)t[1], (unsigned)t[2], (unsigned)t[3]);
+      for (int u = 0; u < KU; ++u) {
+        const int c = min(c0 + u * 64, nch - 1);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+          const int row = min(row0 + r, N - 1);
+          const i32x4 t = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(W + (long)row * ldw + c * 8));
+          w[u][r] = make_uint4((unsigned)t[0], (unsigned)t[1], (unsigned)t[2], (unsigned)t[3]);
+        }
       }
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const uint4 xv = *reinterpret_cast<const uint4*>(xs + b * K + c * 8);
-        const float x0 = bflo(xv.x), x1 = bfhi(xv.x), x2 = bflo(xv.y), x3 = bfhi(xv.y), x4 = bflo(xv.z), x5 = bfhi(xv.z), x6 = bflo(xv.w),
-                    x7 = bfhi(xv.w);
+      for (int u = 0; u < KU; ++u) {
+        const int c = c0 + u * 64;
+        if (KU > 1 && c >= nch) break;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          acc[r][b] += bflo(w[r].x) * x0 + bfhi(w[r].x) * x1 + bflo(w[r].y) * x2 + bfhi(w[r].y) * x3 + bflo(w[r].z) * x4 +
-                       bfhi(w[r].z) * x5 + bflo(w[r].w) * x6 + bfhi(w[r].w) * x7;
+        for (int b = 0; b < NB; ++b) {
+          const uint4 xv = *reinterpret_cast<const uint4*>(xs + b * K + c * 8);
+          const float x0 = bflo(xv.x), x1 = bfhi(xv.x), x2 = bflo(xv.y), x3 = bfhi(xv.y), x4 = bflo(xv.z), x5 = bfhi(xv.z), x6 = bflo(xv.w),
+                      x7 = bfhi(xv.w);
+#pragma unroll
+          for (int r = 0; r < RPW; ++r)
+            acc[r][b] += bflo(w[u][r].x) * x0 + bfhi(w[u][r].x) * x1 + bflo(w[u][r].y) * x2 + bfhi(w[u][r].y) * x3 + bflo(w[u][r].z) * x4 +
+                         bfhi(w[u][r].z) * x5 + bflo(w[u][r].w) * x6 + bfhi(w[u][r].w) * x7;
+        }
       }
     }
   } else {
     const uint8_t* W = reinterpret_cast<const uint8_t*>(Wv);
     const int nch16 = K / 16;  // 16 fp8 per lane load
     for (int c = lane; c < nch16; c += 64) {
-      i32x4 w[4];
+      i32x4 w[RPW];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < RPW; ++r) {
         const int row = min(row0 + r, N - 1);
         w[r] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(W + (long)row * ldw + c * 16));
       }
@@ -101,7 +110,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
           xf[h * 8 + 4] = bflo(xv.z); xf[h * 8 + 5] = bfhi(xv.z); xf[h * 8 + 6] = bflo(xv.w); xf[h * 8 + 7] = bfhi(xv.w);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < RPW; ++r)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(w[r][j], false);
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
     }
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int r = 0; r < RPW; ++r)
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const float s = wave_sum(acc[r][b]);
@@ -228,6 +237,155 @@ __global__ void decode_emit_kernel(const long* __restrict__ next_ids, int* __res
   if (b == 0) state[1] = t + 1;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// decode_attn_kernel: the whole attention of ONE new token per sequence in a single launch (head_dim 128):
+//   RoPE of the new q / k row (HF rotate_half), append of (rotated k, v) to the cache, attention over the cache.
+//   Latency-bound (ctx * 512 B per head), so the design minimises dependent memory round trips: one 16-wave workgroup per
+//   (sequence, head); a pass covers 512 keys (wave w: keys 32w..32w+31, 16 lanes x 16 B per key row = whole 256-B rows per
+//   wave-instruction) and issues ALL its K and V row loads before anything else; waves keep online-softmax partials
+//   (m, l, o[128]) across passes and merge them through LDS - no global atomics or fences (a cross-workgroup split was tried:
+//   device-scope release/acquire between XCD-private L2s cost more than the serial pass loop).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int DA_WAVES = 16, DA_PASS = DA_WAVES * 32;
+
+__device__ __forceinline__ float group16_sum(float v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(1024) void decode_attn_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* kc, bf16_t* vc,
+                                                           const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                           const int* __restrict__ pos, const unsigned char* __restrict__ kmask,
+                                                           long ld_kmask, bf16_t* __restrict__ out, long ldo, int H, int max_ctx,
+                                                           float scale) {
+  constexpr int D = 128, HALF = 64;
+  __shared__ float part[DA_WAVES][132];
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, grp = lane >> 4;
+  const int d_model = H * D;
+  const long cache_row0 = (long)b * max_ctx;
+  const bf16_t* kbase = kc + cache_row0 * d_model + h * D + l16 * 8;
+  const bf16_t* vbase = vc + cache_row0 * d_model + h * D + l16 * 8;
+  int key0 = wave * 32 + grp;  // this 16-lane group: keys key0, key0+4, ..., key0+28 of the current pass
+  // first pass: every global load is issued up front - none depends on another (any cache row < max_ctx is readable; rows past the
+  // context are discarded below)
+  uint4 kr[8], vr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const long key = min(key0 + i * 4, max_ctx - 1);
+    kr[i] = *reinterpret_cast<const uint4*>(kbase + key * d_model);
+    vr[i] = *reinterpret_cast<const uint4*>(vbase + key * d_model);
+  }
+  const bf16_t* row = qkv + (long)b * ld;
+  const uint4 q_raw = *reinterpret_cast<const uint4*>(row + h * D + l16 * 8);
+  const uint4 k_raw = *reinterpret_cast<const uint4*>(row + d_model + h * D + l16 * 8);
+  const uint4 v_raw = *reinterpret_cast<const uint4*>(row + 2 * d_model + h * D + l16 * 8);
+  const int p = pos[b];  // position of the new token; keys 0..p are visible
+  // ---- rotated q (pre-scaled) and rotated new k for dims [l16*8, +8); the partner half lives in lane l16 ^ 8
+  float q[8], kn[8], vn[8];
+  {
+    float qa[8], ka[8], qb[8], kb[8];
+    unpack8(q_raw, qa); unpack8(k_raw, ka); unpack8(v_raw, vn);
+    const int f0 = (l16 & 7) * 8;
+    const bool hi = l16 >= 8;
+    const float4 c0 = *reinterpret_cast<const float4*>(cos_t + (long)p * HALF + f0), c1 = *reinterpret_cast<const float4*>(cos_t + (long)p * HALF + f0 + 4);
+    const float4 s0 = *reinterpret_cast<const float4*>(sin_t + (long)p * HALF + f0), s1 = *reinterpret_cast<const float4*>(sin_t + (long)p * HALF + f0 + 4);
+    const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      qb[i] = __shfl_xor(qa[i], 8, 64);
+      kb[i] = __shfl_xor(ka[i], 8, 64);
+      // rotate_half: x[d] * cos - x[d+64] * sin (d < 64);  x[d] * cos + x[d-64] * sin (d >= 64); rounded to bf16 like the stored rows
+      q[i] = bf2f(f2bf(hi ? qa[i] * cv[i] + qb[i] * sv[i] : qa[i] * cv[i] - qb[i] * sv[i])) * scale;
+      kn[i] = bf2f(f2bf(hi ? ka[i] * cv[i] + kb[i] * sv[i] : ka[i] * cv[i] - kb[i] * sv[i]));
+    }
+  }
+  float m = -INFINITY, l = 0.f, o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+  for (int base = 0; base <= p; base += DA_PASS) {
+    if (base > 0) {  // later passes (context > 512): same load pattern, issued together at the top of the pass
+      key0 = base + wave * 32 + grp;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const long key = min(key0 + i * 4, max_ctx - 1);
+        kr[i] = *reinterpret_cast<const uint4*>(kbase + key * d_model);
+        vr[i] = *reinterpret_cast<const uint4*>(vbase + key * d_model);
+      }
+    }
+    float sc[8];
+    float mp = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int key = key0 + i * 4;
+      float kv[8];
+      unpack8(kr[i], kv);
+      if (key == p) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kv[e] = kn[e];
+        *reinterpret_cast<uint4*>(kc + (cache_row0 + p) * d_model + h * D + l16 * 8) = pack8(kn);  // append: this group owns the new key
+        *reinterpret_cast<uint4*>(vc + (cache_row0 + p) * d_model + h * D + l16 * 8) = v_raw;
+      }
+      float dot = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dot += q[e] * kv[e];
+      dot = group16_sum(dot);
+      bool ok = key <= p;
+      if (ok && kmask != nullptr) ok = kmask[(long)b * ld_kmask + key] != 0;
+      sc[i] = ok ? dot : -INFINITY;
+      mp = fmaxf(mp, sc[i]);
+    }
+    mp = fmaxf(mp, __shfl_xor(mp, 16, 64));
+    mp = fmaxf(mp, __shfl_xor(mp, 32, 64));
+    const float m_new = fmaxf(m, mp);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __expf(m - m_use);  // 0 on the first contribution (m = -inf)
+    l *= alpha;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] *= alpha;
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (sc[i] == -INFINITY) continue;  // masked / absent key: its (possibly uninitialised) cache row must not touch the sum
+      const float pr = __expf(sc[i] - m_use);
+      float vv[8];
+      unpack8(vr[i], vv);
+      if (key0 + i * 4 == p) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vv[e] = vn[e];
+      }
+      l += pr;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += pr * vv[e];
+    }
+  }
+  // ---- fold the 4 key groups of the wave (each lane group accumulated with the wave-wide max, so plain sums), then the waves
+  l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { o[e] += __shfl_xor(o[e], 16, 64); o[e] += __shfl_xor(o[e], 32, 64); }
+  if (lane < 16) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[wave][2 + l16 * 8 + e] = o[e];
+    if (lane == 0) { part[wave][0] = m; part[wave][1] = l; }
+  }
+  __syncthreads();
+  if (tid < D) {
+    float M = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < DA_WAVES; ++i) M = fmaxf(M, part[i][0]);
+    float L = 0.f, acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < DA_WAVES; ++i) {
+      const float mi = part[i][0];
+      const float w = mi == -INFINITY ? 0.f : __expf(mi - M);
+      L += w * part[i][1];
+      acc += w * part[i][2 + tid];
+    }
+    out[(long)b * ldo + h * D + tid] = f2bf(L > 0.f ? acc / L : 0.f);
+  }
+}
+
 }  // namespace
 
 extern "C" int lhrs_decode_emit(const long* next_ids, int* tok32, long* out_ids, int* state, int B, int max_new, void* stream) {
@@ -238,18 +396,33 @@ extern "C" int lhrs_decode_emit(const long* next_ids, int* tok32, long* out_ids,
 }
 
 // y[B, N] = x[B, K] . W[N, K]^T (+ residual[B, N]);  B <= 8, K % 8 == 0
+static int g_gemv_cfg = 0;  // tuning hook: 0 auto, else RPW * 10 + KU
+extern "C" int lhrs_gemv_set_config(int cfg) { g_gemv_cfg = cfg; return 0; }
+
 template <int PRO, bool FP8>
 static int gemv_chunk(const void* W, long ldw, const float* wscale, const bf16_t* x, long ldx, const bf16_t* norm_w, float eps,
                       const bf16_t* residual, long ldr, void* y, long ldy, int B, int N, int K, int out_f32, hipStream_t s) {
-  const dim3 grid(cdiv(N, 16)), blk(256);
+  const dim3 blk(256);
   const size_t sm = (size_t)B * K * 2;
-#define GEMV_CASE(NB)                                                                                                   \
-  case NB:                                                                                                              \
-    if (sm > 65536) (void)hipFuncSetAttribute((const void*)gemv_kernel<NB, PRO, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-    hipLaunchKernelGGL((gemv_kernel<NB, PRO, FP8>), grid, blk, sm, s, W, ldw, wscale, x, ldx, norm_w, eps, residual, ldr, y, ldy, N, K, out_f32); \
+  int cfg = g_gemv_cfg;
+  if (cfg == 0) cfg = 41;
+#define GEMV_LAUNCH(NB, RPW, KU)                                                                                       \
+  do {                                                                                                                  \
+    if (sm > 65536) (void)hipFuncSetAttribute((const void*)gemv_kernel<NB, PRO, FP8, RPW, KU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+    hipLaunchKernelGGL((gemv_kernel<NB, PRO, FP8, RPW, KU>), dim3(cdiv(N, 4 * RPW)), blk, sm, s, W, ldw, wscale, x, ldx, norm_w, eps, residual, ldr, y, ldy, N, K, out_f32); \
+  } while (0)
+#define GEMV_CASE(NB)                                                             \
+  case NB:                                                                        \
+    if (B == 1 && !FP8 && cfg == 42) GEMV_LAUNCH(1, 4, 2);                        \
+    else if (B == 1 && !FP8 && cfg == 22) GEMV_LAUNCH(1, 2, 2);                   \
+    else if (B == 1 && !FP8 && cfg == 24) GEMV_LAUNCH(1, 2, 4);                   \
+    else if (B == 1 && !FP8 && cfg == 14) GEMV_LAUNCH(1, 1, 4);                   \
+    else if (B == 1 && !FP8 && cfg == 18) GEMV_LAUNCH(1, 1, 8);                   \
+    else GEMV_LAUNCH(NB, 4, 1);                                                   \
     break;
   switch (B) { GEMV_CASE(1) GEMV_CASE(2) GEMV_CASE(3) GEMV_CASE(4) GEMV_CASE(5) GEMV_CASE(6) GEMV_CASE(7) GEMV_CASE(8) }
 #undef GEMV_CASE
+#undef GEMV_LAUNCH
   LHRS_CHECK_LAUNCH("gemv");
   return 0;
 }
@@ -343,5 +516,17 @@ extern "C" int lhrs_graph_launch(void* exec, void* stream) {
 }
 extern "C" int lhrs_graph_destroy(void* exec) {
   if (exec) (void)hipGraphExecDestroy((hipGraphExec_t)exec);
+  return 0;
+}
+
+// One launch per layer and token: RoPE(q, k_new) + KV append + attention over the cache (+ HF attention_mask bytes) -> o [B, H*128].
+extern "C" int lhrs_decode_attn(const void* qkv, long ld, void* kcache, void* vcache, const float* cos_t, const float* sin_t,
+                                const int* pos, const unsigned char* key_mask, long ld_mask, void* out, long ldo, int B, int H, int D,
+                                int max_ctx, float scale, void* stream) {
+  LHRS_REQUIRE(D == 128, "decode_attn: head_dim %d (only 128)", D);
+  LHRS_REQUIRE(B >= 1 && H >= 1 && max_ctx >= 1 && ld % 8 == 0, "decode_attn: B=%d H=%d max_ctx=%d", B, H, max_ctx);
+  hipLaunchKernelGGL(decode_attn_kernel, dim3(H, B), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)qkv, ld, (bf16_t*)kcache,
+                     (bf16_t*)vcache, cos_t, sin_t, pos, key_mask, ld_mask, (bf16_t*)out, ldo, H, max_ctx, scale);
+  LHRS_CHECK_LAUNCH("decode_attn");
   return 0;
 }

@@ -410,6 +410,15 @@ def rope_kv_append(qkv, kc, vc, cos_t, sin_t, pos, B, H, D, max_ctx):
                                         pos.data_ptr(), B, H, D, max_ctx, _stream()), "rope_kv_append")
 
 
+def decode_attn(qkv, kc, vc, cos_t, sin_t, pos, out, B, H, D, max_ctx, scale, key_mask=None):
+    """RoPE(new q, k) + KV append + attention over the cache for one new token per sequence, one launch (lhrs_decode_attn)."""
+    st = _L().lhrs_decode_attn(qkv.data_ptr(), qkv.stride(0), kc.data_ptr(), vc.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), pos.data_ptr(),
+                               _p(key_mask), key_mask.stride(0) if key_mask is not None else 0, out.data_ptr(), out.stride(0), B, H, D,
+                               max_ctx, float(scale), _stream())
+    _lib.check(st, "decode_attn")
+    return out
+
+
 def decode_advance(state, desc, pos, B, max_ctx, inc=1):
     _lib.check(_L().lhrs_decode_advance(state.data_ptr(), desc.data_ptr(), pos.data_ptr(), B, max_ctx, inc, _stream()), "decode_advance")
 

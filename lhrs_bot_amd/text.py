@@ -402,8 +402,11 @@ class TextModal:
             for L, (kc, vc) in zip(self.p["layers"], caches):
                 w, sc = W(L, "qkv_w")
                 hk.gemv_fused(w, x, s.qkv, d, wscale=sc, prologue=hk.PRO_RMSNORM, norm_w=L["ln1_w"], eps=self.eps)
-                hk.rope_kv_append(s.qkv, kc, vc, self.cos, self.sin, s.pos, B, H, hd, max_ctx)
-                hk.attn_fwd(s.qkv[:, :d], kc, vc, s.o, None, s.desc, B, H, hd, 1, 1 << 30, 64, True, scale, key_mask=kmask)
+                if hd == 128:  # RoPE + KV append + attention over the cache in one launch
+                    hk.decode_attn(s.qkv, kc, vc, self.cos, self.sin, s.pos, s.o, B, H, hd, max_ctx, scale, key_mask=kmask)
+                else:
+                    hk.rope_kv_append(s.qkv, kc, vc, self.cos, self.sin, s.pos, B, H, hd, max_ctx)
+                    hk.attn_fwd(s.qkv[:, :d], kc, vc, s.o, None, s.desc, B, H, hd, 1, 1 << 30, 64, True, scale, key_mask=kmask)
                 w, sc = W(L, "o_w")
                 hk.gemv_fused(w, s.o, x2, d, wscale=sc, residual=x)
                 w, sc = W(L, "gu_w")

@@ -162,3 +162,32 @@ def test_attention_key_mask_kernel():
         bias.masked_fill_(causal[None, None], float("-inf"))
         ref = (torch.softmax(qf @ kf.transpose(-1, -2) / math.sqrt(D) + bias, -1) @ vf).transpose(1, 2).reshape(2 * nq, H * D)
         assert rel(o, ref) < 1e-2
+
+
+def test_decode_attn_kernel_matches_rope_append_attention():
+    """lhrs_decode_attn (one launch) == rope_kv_append + tiled attention over the cache, incl. the append side effect, a key mask,
+    contexts that end inside / at the edge of a 512-key pass, and more than one pass."""
+    import math
+    g = torch.Generator().manual_seed(21)
+    B, H, D, max_ctx = 2, 32, 128, 1300
+    d = H * D
+    cos, sin = (t.to(DEV) for t in __import__("oracle.lhrs_oracle", fromlist=["rope_tables"]).rope_tables(max_ctx, D))
+    for ctx, masked in ((0, False), (5, False), (127, True), (300, True), (511, False), (512, True), (640, False), (1299, True)):
+        kc = torch.randn(B * max_ctx, d, generator=g).to(DEV, torch.bfloat16)
+        vc = torch.randn(B * max_ctx, d, generator=g).to(DEV, torch.bfloat16)
+        qkv = torch.randn(B, 3 * d, generator=g).to(DEV, torch.bfloat16)
+        km = None
+        if masked:
+            km = (torch.rand(B, max_ctx, generator=g) > 0.3).to(torch.uint8)
+            km[:, 0] = 1
+            km = km.to(DEV)
+        pos = torch.full((B,), ctx, dtype=torch.int32, device=DEV)
+        kc2, vc2, qkv2 = kc.clone(), vc.clone(), qkv.clone()
+        o = torch.empty(B, d, device=DEV, dtype=torch.bfloat16)
+        hk.decode_attn(qkv, kc, vc, cos, sin, pos, o, B, H, D, max_ctx, 1 / math.sqrt(D), key_mask=km)
+        hk.rope_kv_append(qkv2, kc2, vc2, cos, sin, pos, B, H, D, max_ctx)
+        desc = hk.make_desc([(b, 1, b * max_ctx, ctx + 1, ctx + 1, ctx) for b in range(B)], DEV)
+        o2 = torch.empty_like(o)
+        hk.attn_fwd(qkv2[:, :d], kc2, vc2, o2, None, desc, B, H, D, 1, 1 << 30, 64, True, 1 / math.sqrt(D), key_mask=km)
+        assert torch.equal(kc, kc2) and torch.equal(vc, vc2), ctx      # the appended rows are bit-identical
+        assert rel(o, o2) < 6e-3, (ctx, rel(o, o2))                     # fp32 P.V here vs bf16-rounded P in the MFMA kernel
