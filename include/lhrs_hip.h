@@ -183,9 +183,6 @@ int lhrs_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_
 int lhrs_decode_attn(const void* qkv, long ld, void* kcache, void* vcache, const float* cos_t, const float* sin_t,
                      const int* pos, const unsigned char* key_mask, long ld_mask, void* out, long ldo, int B, int H, int D,
                      int max_ctx, float scale, void* stream);
-/* tuning hook for the decode GEMV launch shape (0 = default) */
-int lhrs_gemv_set_config(int cfg);
-
 /* ---- data boundary: the image transform of the reference -------------------------------------------
  * CLIPImageProcessor.preprocess as built by build_vlp_transform (lhrs/Dataset/build_transform.py:43-45) for one decoded RGB image:
  * img = uint8 [H][W][3] on the device (row_stride bytes per row) -> out = float32 [3][224][224].  Bit-exact with Pillow's BICUBIC

@@ -16,7 +16,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 // PRO: what the block does to the activation rows while staging them in LDS (every block redoes it: 8-22 KB from L2)
 //   0 plain copy            1 RMSNorm (HF LlamaRMSNorm: w * bf16(x * rsqrt(mean x^2 + eps)))       2 SwiGLU: silu(x[k]) * x[K + k]
 // FP8: W is OCP e4m3 with one fp32 scale per output row (the 6.7 GB / token weight stream of SURVEY.md §8d)
-template <int NB, int PRO, bool FP8, int RPW = 4, int KU = 1>
+template <int NB, int PRO, bool FP8, int RPW = 4>
 __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, long ldw, const float* __restrict__ wscale,
                                                    const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ norm_w, float eps,
                                                    const bf16_t* res, long ldr, void* y, long ldy, int N, int K, int out_f32) {
@@ -25,6 +25,17 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);  // [NB][K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nch = K / 8;
+  const int row0 = (blockIdx.x * 4 + wave) * RPW;  // 4 waves x RPW rows per block
+  // the first weight loads are issued BEFORE the activation prologue (which needs two block-wide syncs): HBM latency overlaps it
+  uint4 wcur[RPW];
+  if (!FP8) {
+    const bf16_t* W = reinterpret_cast<const bf16_t*>(Wv);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const i32x4 t = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(W + (long)min(row0 + r, N - 1) * ldw + min(lane, nch - 1) * 8));
+      wcur[r] = make_uint4((unsigned)t[0], (unsigned)t[1], (unsigned)t[2], (unsigned)t[3]);
+    }
+  }
   for (int b = 0; b < NB; ++b) {
     if (PRO == 2) {
       for (int c = tid; c < nch; c += 256) {
@@ -54,7 +65,6 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
     }
   }
   __syncthreads();
-  const int row0 = (blockIdx.x * 4 + wave) * RPW;  // 4 waves x RPW rows x KU 16-B loads in flight per lane
   float acc[RPW][NB];
 #pragma unroll
   for (int r = 0; r < RPW; ++r)
@@ -62,33 +72,26 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
     for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
   if (!FP8) {
     const bf16_t* W = reinterpret_cast<const bf16_t*>(Wv);
-    for (int c0 = lane; c0 < nch; c0 += 64 * KU) {
-      uint4 w[KU][RPW];
+    for (int c = lane; c < nch; c += 64) {  // software pipeline: the loads of chunk c + 64 fly while chunk c is multiplied
+      uint4 wnext[RPW];
+      const int cn = min(c + 64, nch - 1);
 #pragma unroll
-      for (int u = 0; u < KU; ++u) {
-        const int c = min(c0 + u * 64, nch - 1);
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-          const int row = min(row0 + r, N - 1);
-          const i32x4 t = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(W + (long)row * ldw + c * 8));
-          w[u][r] = make_uint4((unsigned)t[0], (unsigned)t[1], (unsigned)t[2], (unsigned)t[3]);
-        }
+      for (int r = 0; r < RPW; ++r) {
+        const i32x4 t = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(W + (long)min(row0 + r, N - 1) * ldw + cn * 8));
+        wnext[r] = make_uint4((unsigned)t[0], (unsigned)t[1], (unsigned)t[2], (unsigned)t[3]);
       }
 #pragma unroll
-      for (int u = 0; u < KU; ++u) {
-        const int c = c0 + u * 64;
-        if (KU > 1 && c >= nch) break;
+      for (int b = 0; b < NB; ++b) {
+        const uint4 xv = *reinterpret_cast<const uint4*>(xs + b * K + c * 8);
+        const float x0 = bflo(xv.x), x1 = bfhi(xv.x), x2 = bflo(xv.y), x3 = bfhi(xv.y), x4 = bflo(xv.z), x5 = bfhi(xv.z), x6 = bflo(xv.w),
+                    x7 = bfhi(xv.w);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const uint4 xv = *reinterpret_cast<const uint4*>(xs + b * K + c * 8);
-          const float x0 = bflo(xv.x), x1 = bfhi(xv.x), x2 = bflo(xv.y), x3 = bfhi(xv.y), x4 = bflo(xv.z), x5 = bfhi(xv.z), x6 = bflo(xv.w),
-                      x7 = bfhi(xv.w);
-#pragma unroll
-          for (int r = 0; r < RPW; ++r)
-            acc[r][b] += bflo(w[u][r].x) * x0 + bfhi(w[u][r].x) * x1 + bflo(w[u][r].y) * x2 + bfhi(w[u][r].y) * x3 + bflo(w[u][r].z) * x4 +
-                         bfhi(w[u][r].z) * x5 + bflo(w[u][r].w) * x6 + bfhi(w[u][r].w) * x7;
-        }
+        for (int r = 0; r < RPW; ++r)
+          acc[r][b] += bflo(wcur[r].x) * x0 + bfhi(wcur[r].x) * x1 + bflo(wcur[r].y) * x2 + bfhi(wcur[r].y) * x3 + bflo(wcur[r].z) * x4 +
+                       bfhi(wcur[r].z) * x5 + bflo(wcur[r].w) * x6 + bfhi(wcur[r].w) * x7;
       }
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) wcur[r] = wnext[r];
     }
   } else {
     const uint8_t* W = reinterpret_cast<const uint8_t*>(Wv);
@@ -396,30 +399,19 @@ extern "C" int lhrs_decode_emit(const long* next_ids, int* tok32, long* out_ids,
 }
 
 // y[B, N] = x[B, K] . W[N, K]^T (+ residual[B, N]);  B <= 8, K % 8 == 0
-static int g_gemv_cfg = 0;  // tuning hook: 0 auto, else RPW * 10 + KU
-extern "C" int lhrs_gemv_set_config(int cfg) { g_gemv_cfg = cfg; return 0; }
-
 template <int PRO, bool FP8>
 static int gemv_chunk(const void* W, long ldw, const float* wscale, const bf16_t* x, long ldx, const bf16_t* norm_w, float eps,
                       const bf16_t* residual, long ldr, void* y, long ldy, int B, int N, int K, int out_f32, hipStream_t s) {
   const dim3 blk(256);
   const size_t sm = (size_t)B * K * 2;
-  int cfg = g_gemv_cfg;
-  if (cfg == 0) cfg = 41;
-#define GEMV_LAUNCH(NB, RPW, KU)                                                                                       \
+#define GEMV_LAUNCH(NB, RPW)                                                                                            \
   do {                                                                                                                  \
-    if (sm > 65536) (void)hipFuncSetAttribute((const void*)gemv_kernel<NB, PRO, FP8, RPW, KU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-    hipLaunchKernelGGL((gemv_kernel<NB, PRO, FP8, RPW, KU>), dim3(cdiv(N, 4 * RPW)), blk, sm, s, W, ldw, wscale, x, ldx, norm_w, eps, residual, ldr, y, ldy, N, K, out_f32); \
+    if (sm > 65536) (void)hipFuncSetAttribute((const void*)gemv_kernel<NB, PRO, FP8, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+    hipLaunchKernelGGL((gemv_kernel<NB, PRO, FP8, RPW>), dim3(cdiv(N, 4 * RPW)), blk, sm, s, W, ldw, wscale, x, ldx, norm_w, eps, residual, ldr, y, ldy, N, K, out_f32); \
   } while (0)
-#define GEMV_CASE(NB)                                                             \
-  case NB:                                                                        \
-    if (B == 1 && !FP8 && cfg == 42) GEMV_LAUNCH(1, 4, 2);                        \
-    else if (B == 1 && !FP8 && cfg == 22) GEMV_LAUNCH(1, 2, 2);                   \
-    else if (B == 1 && !FP8 && cfg == 24) GEMV_LAUNCH(1, 2, 4);                   \
-    else if (B == 1 && !FP8 && cfg == 14) GEMV_LAUNCH(1, 1, 4);                   \
-    else if (B == 1 && !FP8 && cfg == 18) GEMV_LAUNCH(1, 1, 8);                   \
-    else GEMV_LAUNCH(NB, 4, 1);                                                   \
-    break;
+  // one row per wave for the smallest matrix (o_proj, 4096 x 4096: 1024 blocks instead of 256 - measured 9.1 vs 11.1 us), else four
+  if (B == 1 && !FP8 && (long)N * K <= 4096L * 4096L) { GEMV_LAUNCH(1, 1); LHRS_CHECK_LAUNCH("gemv"); return 0; }
+#define GEMV_CASE(NB) case NB: GEMV_LAUNCH(NB, 4); break;
   switch (B) { GEMV_CASE(1) GEMV_CASE(2) GEMV_CASE(3) GEMV_CASE(4) GEMV_CASE(5) GEMV_CASE(6) GEMV_CASE(7) GEMV_CASE(8) }
 #undef GEMV_CASE
 #undef GEMV_LAUNCH
