@@ -107,3 +107,44 @@ def test_unibind_end_to_end_vs_reference_golden_and_oracle():
     assert not bad, bad
     assert rel(model.rgb_pooler.g["out_proj.bias"], torch.from_numpy(z["g_out_proj_b"])) < 4e-2
     assert rel(model.rgb_pooler.g["query"][::4], torch.from_numpy(z["g_query"])) < 5e-2
+
+
+@pytest.mark.timeout(900)
+def test_ragged_right_padded_batch_vs_oracle():
+    """DataCollatorForSupervisedDataset batches: captions of different length, right-padded with pad_token_id = 0, labels -100 on the
+    pads, attention_mask = ids != 0.  Loss and d loss / d image_embedding against oracle autograd; padded rows are invisible."""
+    P = {"vit": OP.make_vit_params(seed=2), "pooler": OP.make_pooler_params(seed=1), "llama": OP.make_llama_params(seed=3, layers=2)}
+    model = UniBind(("rgb", "text"), None, device=DEV, llama_layers=2).load_params(P)
+    model.prepare_for_training()
+    g = torch.Generator().manual_seed(77)
+    B, T = 3, 21
+    lens = [21, 13, 6]
+    ids = torch.zeros((B, T), dtype=torch.int64)
+    for b, n in enumerate(lens):
+        ids[b, :n] = torch.randint(3, 32000, (n,), generator=g)
+        ids[b, 0], ids[b, 1] = 1, -200
+    labels = ids.clone()
+    labels[:, :2] = -100
+    labels[ids == 0] = -100
+    batch = dict(rgb=torch.randn(B, 3, 224, 224, generator=g), input_ids=ids, labels=labels, attention_mask=ids.ne(0))
+    loss = model(batch)["total_loss"].item()
+    d_image = model.text.backward()
+    # oracle: same forward with autograd through the image embedding
+    taps = O.vit_forward(P["vit"], batch["rgb"])
+    img = O.pooler_forward(P["pooler"], taps).detach().requires_grad_(True)
+    src, lab, mask = O.splice(ids, labels, batch["attention_mask"], img.shape[1])
+    emb = P["llama"]["embed"]
+    tok = emb[torch.gather(ids.clamp(min=0), 1, src.clamp(min=0))]
+    img_rows = img[torch.arange(B)[:, None], (-src - 1).clamp(0, img.shape[1] - 1)]
+    is_img = (src < 0) & (src > -10 ** 8)
+    embeds = torch.where(is_img[..., None], img_rows, tok)
+    embeds = torch.where((src <= -10 ** 8)[..., None], torch.zeros_like(embeds), embeds)
+    want = O.causal_lm_loss(P["llama"], O.llama_hidden(P["llama"], embeds, mask), lab)
+    want.backward()
+    assert abs(loss - want.item()) < 3e-3 * want.item(), (loss, want.item())
+    assert rel(d_image, img.grad) < 5e-2
+    # the value of the padding positions does not matter: junk ids under the mask give the same loss bit for bit
+    ids2 = ids.clone()
+    ids2[ids == 0] = 777
+    batch2 = dict(batch, input_ids=ids2)
+    assert model.eval()(batch2)["total_loss"].item() == model(batch)["total_loss"].item()
