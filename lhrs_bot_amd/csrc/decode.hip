@@ -138,6 +138,98 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// gemv_mfma_kernel: the same weight stream for 2..16 sequences at once (batched evaluation, main_vqa.py:205-214).  The per-weight
+// VALU work of gemv_kernel grows with the batch (8 FMAs per weight element at B = 8: VALU-bound at ~3x the B = 1 rate); here the
+// batch is the N dimension of v_mfma_f32_16x16x32_bf16, so every weight element still crosses the CU once and costs one MFMA lane.
+//   block = 16 output rows; the 4 waves split K into 4 contiguous quarters (rows are read in 64-B pieces straight into the MFMA A
+//   layout: lane (r, g) holds W[row0 + r][k0 + 8g .. +8]); x rows sit in LDS after the RMSNorm / SwiGLU prologue and feed the B
+//   operand (batch columns >= B read zeros); the 4 partial 16x16 tiles are summed through LDS.
+// ------------------------------------------------------------------------------------------------------------------
+template <int PRO>
+__global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict__ W, long ldw, const bf16_t* __restrict__ x, long ldx,
+                                                        const bf16_t* __restrict__ norm_w, float eps, const bf16_t* res, long ldr, void* y,
+                                                        long ldy, int NB, int N, int K, int out_f32) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float red[4];
+  __shared__ float part[4][16][17];
+  bf16_t* xs = reinterpret_cast<bf16_t*>(smem);  // [NB][K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  const int nch = K / 8;
+  const int row0 = blockIdx.x * 16;
+  const int kq = K / 4;                      // this wave's quarter of K (K % 128 == 0)
+  const bf16_t* wp = W + (long)min(row0 + fr, N - 1) * ldw + wave * kq + fg * 8;
+  constexpr int U = 4;                       // k-steps (of 32) in flight per wave
+  i32x4 wreg[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) wreg[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + u * 32));  // kq >= 128
+  for (int b = 0; b < (PRO == 0 ? 0 : NB); ++b) {  // PRO 0: x is read straight from L2 into the B fragments, nothing to stage
+    if (PRO == 2) {
+      for (int c = tid; c < nch; c += 256) {
+        const uint4 g = *reinterpret_cast<const uint4*>(x + b * ldx + c * 8);
+        const uint4 u = *reinterpret_cast<const uint4*>(x + b * ldx + K + c * 8);
+        uint4 o;
+        o.x = pack2bf(silu(bflo(g.x)) * bflo(u.x), silu(bfhi(g.x)) * bfhi(u.x));
+        o.y = pack2bf(silu(bflo(g.y)) * bflo(u.y), silu(bfhi(g.y)) * bfhi(u.y));
+        o.z = pack2bf(silu(bflo(g.z)) * bflo(u.z), silu(bfhi(g.z)) * bfhi(u.z));
+        o.w = pack2bf(silu(bflo(g.w)) * bflo(u.w), silu(bfhi(g.w)) * bfhi(u.w));
+        *reinterpret_cast<uint4*>(xs + b * K + c * 8) = o;
+      }
+    } else {
+      float q = 0.f;
+      for (int c = tid; c < nch; c += 256) {
+        const uint4 v = *reinterpret_cast<const uint4*>(x + b * ldx + c * 8);
+        *reinterpret_cast<uint4*>(xs + b * K + c * 8) = v;
+        if (PRO == 1)
+          q += bflo(v.x) * bflo(v.x) + bfhi(v.x) * bfhi(v.x) + bflo(v.y) * bflo(v.y) + bfhi(v.y) * bfhi(v.y) + bflo(v.z) * bflo(v.z) +
+               bfhi(v.z) * bfhi(v.z) + bflo(v.w) * bflo(v.w) + bfhi(v.w) * bfhi(v.w);
+      }
+      if (PRO == 1) {
+        const float rstd = rsqrtf(block_sum<4>(q, red) / (float)K + eps);
+        __syncthreads();
+        for (int c = tid; c < K; c += 256) xs[b * K + c] = f2bf(bf2f(norm_w[c]) * bf2f(f2bf(bf2f(xs[b * K + c]) * rstd)));
+      }
+    }
+  }
+  __syncthreads();
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const bf16_t* xq = (PRO == 0 ? x + (long)min(fr, NB - 1) * ldx : xs + (long)min(fr, NB - 1) * K) + wave * kq + fg * 8;
+  const bool live = fr < NB;
+  const int nsteps = kq / 32;
+  for (int s0 = 0; s0 < nsteps; s0 += U) {
+    i32x4 wnext[U];
+    bf16x8 xfrag[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int sn = min(s0 + U + u, nsteps - 1);
+      wnext[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + sn * 32));
+      xfrag[u] = *reinterpret_cast<const bf16x8*>(xq + min(s0 + u, nsteps - 1) * 32);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (s0 + u < nsteps) {
+        bf16x8 bfrag = xfrag[u];
+        if (!live) bfrag = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[u]), bfrag, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) wreg[u] = wnext[u];
+  }
+  // acc[r] = partial y[batch = fr][row0 + 4*fg + r] of this wave's K quarter
+#pragma unroll
+  for (int r = 0; r < 4; ++r) part[wave][fg * 4 + r][fr] = acc[r];
+  __syncthreads();
+  const int i = tid >> 4, b = tid & 15;  // 256 threads = 16 rows x 16 batch columns
+  const int row = row0 + i;
+  if (b < NB && row < N) {
+    float v = part[0][i][b] + part[1][i][b] + part[2][i][b] + part[3][i][b];
+    if (res) v += bf2f(res[b * ldr + row]);
+    if (out_f32) reinterpret_cast<float*>(y)[b * ldy + row] = v;
+    else reinterpret_cast<bf16_t*>(y)[b * ldy + row] = f2bf(v);
+  }
+}
+
 // per-row e4m3 quantisation: scale[n] = max|W[n,:]| / 448, W8 = round(W / scale)
 __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __restrict__ W, long ldw, uint8_t* __restrict__ W8, long ld8,
                                                              float* __restrict__ scale, int K) {
@@ -424,10 +516,12 @@ static int gemv_chunk(const void* W, long ldw, const float* wscale, const bf16_t
 extern "C" int lhrs_gemv(const void* W, long ldw, const float* wscale, int w_fp8, const void* x, long ldx, int prologue,
                          const void* norm_w, float eps, const void* residual, long ldr, void* y, long ldy, int B, int N, int K,
                          int out_f32, void* stream) {
-  LHRS_REQUIRE(B >= 1 && B <= 8 && N > 0 && K % 16 == 0 && ldx % 8 == 0, "gemv: B=%d N=%d K=%d", B, N, K);
+  LHRS_REQUIRE(B >= 1 && B <= 16 && N > 0 && K % 16 == 0 && ldx % 8 == 0, "gemv: B=%d (1..16) N=%d K=%d", B, N, K);
+  LHRS_REQUIRE(B <= 8 || (!w_fp8 && K % 128 == 0), "gemv: batches above 8 need bf16 weights and K %% 128 == 0");
   LHRS_REQUIRE(w_fp8 ? (ldw % 16 == 0 && wscale != nullptr) : (ldw % 8 == 0), "gemv: weight stride / scales");
   LHRS_REQUIRE(prologue >= 0 && prologue <= 2 && (prologue != 1 || norm_w != nullptr), "gemv: prologue %d", prologue);
-  const int bmax = (int)((152L * 1024) / ((long)K * 2));
+  int bmax = (int)((152L * 1024) / ((long)K * 2));
+  if (!w_fp8 && prologue == 0 && B >= 2 && K % 128 == 0) bmax = 16;  // the MFMA kernel reads x from L2: no LDS limit
   LHRS_REQUIRE(bmax >= 1, "gemv: one activation vector does not fit LDS (K=%d)", K);
   const long esz = out_f32 ? 4 : 2;
   hipStream_t s = (hipStream_t)stream;
@@ -437,6 +531,19 @@ extern "C" int lhrs_gemv(const void* W, long ldw, const float* wscale, int w_fp8
     const bf16_t* rb = residual ? (const bf16_t*)residual + b0 * ldr : nullptr;
     void* yb = (char*)y + b0 * ldy * esz;
     int rc;
+    if (!w_fp8 && nb >= 2 && K % 128 == 0) {  // batched: MFMA weight stream
+      const size_t sm = prologue == 0 ? 0 : (size_t)nb * K * 2;
+      const dim3 grid(cdiv(N, 16)), blk(256);
+#define GOM(P)                                                                                                                     \
+  do {                                                                                                                             \
+    if (sm > 65536) (void)hipFuncSetAttribute((const void*)gemv_mfma_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+    hipLaunchKernelGGL((gemv_mfma_kernel<P>), grid, blk, sm, s, (const bf16_t*)W, ldw, xb, ldx, (const bf16_t*)norm_w, eps, rb, ldr, yb, ldy, nb, N, K, out_f32); \
+  } while (0)
+      if (prologue == 0) GOM(0); else if (prologue == 1) GOM(1); else GOM(2);
+#undef GOM
+      LHRS_CHECK_LAUNCH("gemv_mfma");
+      continue;
+    }
 #define GO(P, F) rc = gemv_chunk<P, F>(W, ldw, wscale, xb, ldx, (const bf16_t*)norm_w, eps, rb, ldr, yb, ldy, nb, N, K, out_f32, s)
     if (w_fp8) { if (prologue == 0) GO(0, true); else if (prologue == 1) GO(1, true); else GO(2, true); }
     else { if (prologue == 0) GO(0, false); else if (prologue == 1) GO(1, false); else GO(2, false); }

@@ -373,7 +373,7 @@ def cross_entropy(logits, target, want_grad=True, inplace=True):
 
 # --------------------------------------------------------------------------------------------- decode
 def gemv(W, x, out, residual=None, out_f32=False):
-    """out[B, N] = x[B, K] @ W[N, K]^T (+ residual): batch <= 8 weight-streaming kernel of the decode step."""
+    """out[B, N] = x[B, K] @ W[N, K]^T (+ residual): weight-streaming kernels of the decode step (batch 1: VALU dot products, batch 2..16: MFMA with the batch as N)."""
     B, K = x.shape
     N = W.shape[0]
     st = _L().lhrs_gemv_bf16(W.data_ptr(), W.stride(0), x.data_ptr(), x.stride(0), _p(residual),

@@ -367,7 +367,7 @@ class TextModal:
         self.p["lm_head8"], self.p["lm_head8s"] = hk.quant_fp8_rows(self.p["lm_head"])
 
     def _decode_session(self, B, max_ctx, caches, max_new, weights="bf16", kmask=None):
-        """Static buffers + one captured hipGraph for the single-token step (batch <= 8): embedding gather, 32 x [RMSNorm,
+        """Static buffers + one captured hipGraph for the single-token step (batch <= 16): embedding gather, 32 x [RMSNorm,
         QKV GEMV, RoPE, KV append, attention over the cache, O GEMV + residual, RMSNorm, gate|up GEMV, SwiGLU, down GEMV +
         residual], final norm, lm_head GEMV -> fp32 logits.  Context length / positions live on the device
         (decode_advance), so the graph is captured once and replayed for every token."""
@@ -395,26 +395,36 @@ class TextModal:
         def W(L, name):  # (weight, per-row scale or None)
             return (L[name + "8"], L[name + "8s"]) if fp8 else (L[name], None)
 
+        batched = B >= 4 and not fp8  # the MFMA weight stream reads x from L2: norm / SwiGLU run once, not once per block (pays from batch 4)
+        if batched:
+            s.hn = torch.zeros((B, d), device=dev, dtype=bf)
+            s.actb = torch.zeros((B, ff), device=dev, dtype=bf)
+
+        def lin(w, sc, x_in, out, K, pro=hk.PRO_NONE, norm_w=None, residual=None, out_f32=False):
+            if batched and pro == hk.PRO_RMSNORM:
+                hk.rmsnorm_fwd(x_in, norm_w, self.eps, out=s.hn)
+                x_in, pro, norm_w = s.hn, hk.PRO_NONE, None
+            elif batched and pro == hk.PRO_SWIGLU:
+                hk.swiglu_fwd(x_in, ff, out=s.actb)
+                x_in, pro = s.actb, hk.PRO_NONE
+            hk.gemv_fused(w, x_in, out, K, wscale=sc, prologue=pro, norm_w=norm_w, eps=self.eps, residual=residual, out_f32=out_f32)
+
         def enqueue():
             hk.decode_advance(s.state, s.desc, s.pos, B, max_ctx, 1)
             hk.gather_rows(self.p["embed"], s.tok32, out=s.x)
             x, x2 = s.x, s.x2
             for L, (kc, vc) in zip(self.p["layers"], caches):
-                w, sc = W(L, "qkv_w")
-                hk.gemv_fused(w, x, s.qkv, d, wscale=sc, prologue=hk.PRO_RMSNORM, norm_w=L["ln1_w"], eps=self.eps)
+                lin(*W(L, "qkv_w"), x, s.qkv, d, hk.PRO_RMSNORM, L["ln1_w"])
                 if hd == 128:  # RoPE + KV append + attention over the cache in one launch
                     hk.decode_attn(s.qkv, kc, vc, self.cos, self.sin, s.pos, s.o, B, H, hd, max_ctx, scale, key_mask=kmask)
                 else:
                     hk.rope_kv_append(s.qkv, kc, vc, self.cos, self.sin, s.pos, B, H, hd, max_ctx)
                     hk.attn_fwd(s.qkv[:, :d], kc, vc, s.o, None, s.desc, B, H, hd, 1, 1 << 30, 64, True, scale, key_mask=kmask)
-                w, sc = W(L, "o_w")
-                hk.gemv_fused(w, s.o, x2, d, wscale=sc, residual=x)
-                w, sc = W(L, "gu_w")
-                hk.gemv_fused(w, x2, s.gu, d, wscale=sc, prologue=hk.PRO_RMSNORM, norm_w=L["ln2_w"], eps=self.eps)
-                w, sc = W(L, "down_w")
-                hk.gemv_fused(w, s.gu, x, ff, wscale=sc, prologue=hk.PRO_SWIGLU, residual=x2)
+                lin(*W(L, "o_w"), s.o, x2, d, residual=x)
+                lin(*W(L, "gu_w"), x2, s.gu, d, hk.PRO_RMSNORM, L["ln2_w"])
+                lin(*W(L, "down_w"), s.gu, x, ff, hk.PRO_SWIGLU, residual=x2)
             w, sc = (self.p["lm_head8"], self.p["lm_head8s"]) if fp8 else (self.p["lm_head"], None)
-            hk.gemv_fused(w, x, s.logits, d, wscale=sc, prologue=hk.PRO_RMSNORM, norm_w=self.p["norm_w"], eps=self.eps, out_f32=True)
+            lin(w, sc, x, s.logits, d, hk.PRO_RMSNORM, self.p["norm_w"], out_f32=True)
 
         s.enqueue = enqueue
         s.graph = None
@@ -428,7 +438,7 @@ class TextModal:
         a KV cache; returns only the NEW token ids [B, n_new] (HF generate started from inputs_embeds).  Greedy
         (do_sample=False, the evaluation scripts' mode) runs entirely in HIP kernels; with do_sample=True the HIP-computed
         fp32 logits go through HF's temperature / top-k / top-p warpers and one multinomial draw per token.  The
-        single-token step is a captured hipGraph over static buffers (batch <= 8); without eos / stopping criteria / streamer
+        single-token step is a captured hipGraph over static buffers (batch <= 16; from batch 2 the weight stream runs on MFMA); without eos / stopping criteria / streamer
         the host never synchronises inside the loop."""
         embeds, _, mask, _ = self.prepare_inputs_for_multimodal(input_ids, attention_mask, None, image_embedding)
         B, S0, d = embeds.shape
@@ -483,7 +493,7 @@ class TextModal:
             return stopping_criteria is not None and any(c(ids_so_far, lg) for c in stopping_criteria)
 
         n_done = 1
-        if B <= 8:
+        if B <= 16:
             s = self._decode_session(B, max_ctx, caches, max_new_tokens, weights, kmask)
             s.state[0], s.state[1] = S0, 0
             side = torch.cuda.Stream(device=dev)

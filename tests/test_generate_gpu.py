@@ -62,7 +62,7 @@ def test_sampling_path_runs_and_respects_eos():
 def test_gemv_and_graph_decode_equal_eager_decode():
     g = torch.Generator().manual_seed(3)
     W = (torch.randn(4096, 11008, generator=g) * 0.02).to(DEV, torch.bfloat16)
-    for B in (1, 3, 8):
+    for B in (1, 2, 3, 8, 16):
         x = torch.randn(B, 11008, generator=g).to(DEV, torch.bfloat16)
         res = torch.randn(B, 4096, generator=g).to(DEV, torch.bfloat16)
         y = torch.empty(B, 4096, device=DEV, dtype=torch.bfloat16)
@@ -91,6 +91,8 @@ def test_fp8_weight_decode_and_fused_prologues():
     y_ref = torch.empty_like(y)
     hk.gemv(W, hk.rmsnorm_fwd(x, nw), y_ref)
     assert torch.equal(y, y_ref)
+    hk.gemv_fused(W, x[:1], y[:1], 4096, prologue=hk.PRO_RMSNORM, norm_w=nw)     # batch 1 = the VALU kernel, batch >= 2 = MFMA
+    assert rel(y[:1], y_ref[:1]) < 4e-3
     gu = torch.randn(2, 2 * 11008, generator=g).to(DEV, torch.bfloat16)
     Wd = (torch.randn(4096, 11008, generator=g) * 0.02).to(DEV, torch.bfloat16)
     hk.gemv_fused(Wd, gu, y, 11008, prologue=hk.PRO_SWIGLU)
