@@ -169,6 +169,8 @@ int lhrs_graph_destroy(void* exec);
  * lhrs/CustomTrainer/hook/deepspeed_hook.py:4-19.                                                         */
 int lhrs_sqnorm_nblk(long n); /* host helper */
 int lhrs_sqnorm(const float* g, long n, float* partial, float* out, int accumulate, void* stream);
+/* gradient accumulation (DeepSpeed "gradient_accumulation_steps", main_pretrain_stage1.py:61,115): y = x or y += x, fp32, n % 4 == 0 */
+int lhrs_accum_f32(float* y, const float* x, long n, int copy_only, void* stream);
 int lhrs_adan_step(float* param, const float* grad, float* exp_avg, float* exp_avg_diff, float* exp_avg_sq,
                    float* pre_grad, void* shadow_bf16, long n, int step, float lr, float beta1, float beta2, float beta3,
                    float eps, float weight_decay, int no_prox, const float* gnorm_sq, float max_norm, float grad_scale,

@@ -78,9 +78,28 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 inline int ogrid(long n) { long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
+// gradient accumulation over micro-batches (DeepSpeed gradient_accumulation_steps): y = x (copy) or y += x, fp32, 16 B per lane
+__global__ void accum_f32_kernel(float* __restrict__ y, const float* __restrict__ x, long n4, int copy_only) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(x)[i];
+    if (copy_only) { reinterpret_cast<float4*>(y)[i] = a; continue; }
+    float4 b = reinterpret_cast<float4*>(y)[i];
+    b.x += a.x; b.y += a.y; b.z += a.z; b.w += a.w;
+    reinterpret_cast<float4*>(y)[i] = b;
+  }
+}
+
 }  // namespace
 
 extern "C" int lhrs_sqnorm_nblk(long n) { return ogrid(n); }
+
+// y = x (copy_only) or y += x over n fp32 elements (n % 4 == 0): the accumulation buffer of gradient_accumulation_steps > 1
+extern "C" int lhrs_accum_f32(float* y, const float* x, long n, int copy_only, void* stream) {
+  LHRS_REQUIRE(n > 0 && n % 4 == 0 && y && x, "accum_f32: n=%ld", n);
+  hipLaunchKernelGGL(accum_f32_kernel, dim3(ogrid(n / 4)), dim3(256), 0, (hipStream_t)stream, y, x, n / 4, copy_only);
+  LHRS_CHECK_LAUNCH("accum_f32");
+  return 0;
+}
 
 // out (+)= sum(g[i]^2); partial: lhrs_sqnorm_nblk(n) floats of workspace
 extern "C" int lhrs_sqnorm(const float* g, long n, float* partial, float* out, int accumulate, void* stream) {

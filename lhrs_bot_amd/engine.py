@@ -138,7 +138,8 @@ def _pooler_wd_ranges(pool):
 
 class LHRSEngine:
     def __init__(self, model, optimizer: str = "adanp", lr: float = 2e-4, weight_decay: float = 0.0,
-                 max_grad_norm: float = 0.3, betas=None, eps: float = 1e-8, process_group=None, comm_dtype=torch.float32):
+                 max_grad_norm: float = 0.3, betas=None, eps: float = 1e-8, process_group=None, comm_dtype=torch.float32,
+                 gradient_accumulation_steps: int = 1):
         self.module = self.model = model
         self.pool = model.rgb_pooler
         self.opt_name = optimizer.lower()
@@ -169,6 +170,11 @@ class LHRSEngine:
                 self.state[st.name].update(exp_avg_diff=z(), pre_grad=z())
         self.gnorm_sq = torch.zeros((), device=dev)
         self.global_steps = 0
+        # DeepSpeed gradient_accumulation_steps (main_pretrain_stage1.py:61,115): backward() scales the loss by 1/GAS and sums the
+        # micro-batch gradients; step() only acts on every GAS-th call; the all-reduce happens once, at the boundary
+        self.gas = max(1, int(gradient_accumulation_steps))
+        self.micro_steps = 0
+        self._acc = {st.name: torch.zeros_like(st.grad) for st in self.stores} if self.gas > 1 else {}
         self.optimizer = _Optimizer(lr, weight_decay, sum(s.numel_decay for s in self.stores), sum(s.numel_nodecay for s in self.stores))
         # ---- data parallel
         self.pg = process_group
@@ -190,17 +196,38 @@ class LHRSEngine:
         self.model.train()
         return self
 
+    def is_gradient_accumulation_boundary(self) -> bool:
+        return (self.micro_steps + 1) % self.gas == 0
+
     def backward(self, loss=None):
-        """Hand-written backward; gradient ranges are all-reduced on the comm stream as they become final."""
+        """Hand-written backward; gradient ranges are all-reduced on the comm stream as they become final (with gradient
+        accumulation: once per window, after the last micro-batch has been added)."""
         pool_on = self.pool.requires_grad
-        r_lora = self.reducers.get("lora")
-        d_image = self.model.text.backward(need_input_grad=pool_on,
+        overlap = self.gas == 1
+        r_lora = self.reducers.get("lora") if overlap else None
+        d_image = self.model.text.backward(loss_scale=1.0 / self.gas, need_input_grad=pool_on,
                                            on_layer_ready=(lambda l: r_lora.ready(str(l))) if r_lora else None)
         if pool_on:
-            r_pool = self.reducers.get("rgb_pooler")
+            r_pool = self.reducers.get("rgb_pooler") if overlap else None
             self.pool.backward(d_image, on_ready=r_pool.ready if r_pool else None)
+        if self.gas > 1:
+            first, last = self.micro_steps % self.gas == 0, self.is_gradient_accumulation_boundary()
+            for st in self.stores:
+                if not first:
+                    hk.accum_f32(st.grad, self._acc[st.name])                # grad = this micro-batch + the window so far
+                if not last:
+                    hk.accum_f32(self._acc[st.name], st.grad, copy_only=True)
+            if last:
+                for st in self.stores:
+                    r = self.reducers.get(st.name)
+                    if r is not None:
+                        for key, _, _ in st.buckets:
+                            r.ready(key)
 
     def step(self, lr_kwargs: Optional[Dict] = None):
+        self.micro_steps += 1
+        if self.micro_steps % self.gas != 0:
+            return  # DeepSpeed: engine.step() is a no-op inside an accumulation window
         for r in self.reducers.values():
             r.finish()
         self.global_steps += 1

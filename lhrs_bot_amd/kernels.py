@@ -467,6 +467,13 @@ def sqnorm(g, out, accumulate=False):
     return out
 
 
+def accum_f32(y, x, copy_only=False):
+    """y = x (copy_only) or y += x on flat fp32 buffers (gradient accumulation)."""
+    assert y.dtype == torch.float32 and x.dtype == torch.float32 and y.numel() == x.numel()
+    _lib.check(_L().lhrs_accum_f32(y.data_ptr(), x.data_ptr(), y.numel(), int(copy_only), _stream()), "accum_f32")
+    return y
+
+
 def adan_step(p, g, m, v, n, pre, shadow, step, lr, betas=(0.98, 0.92, 0.99), eps=1e-8, wd=0.0, no_prox=True,
               gnorm_sq=None, max_norm=0.0, grad_scale=1.0):
     st = _L().lhrs_adan_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n.data_ptr(), pre.data_ptr(), _p(shadow),

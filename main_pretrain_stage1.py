@@ -40,6 +40,7 @@ def parse_option():
     p.add_argument("--enable-amp", type=str2bool, default=True)
     p.add_argument("--use-checkpoint", action="store_true", help="accepted for flag compatibility; unused (288 GB HBM)")
     p.add_argument("--wandb", type=str2bool, default=False)
+    p.add_argument("--accumulation-steps", type=int, default=1, help="gradient accumulation steps")
     p.add_argument("--local_rank", type=int, default=0)
     # knobs of the synthetic run
     p.add_argument("--epoch-len", type=int, default=20, help="iterations per epoch of the synthetic loader")
@@ -57,7 +58,8 @@ def main(config):
                                tune_im_start=config.get("tune_im_start", False))
     loader = SyntheticStage1Loader(batch_size=config.batch_size, epoch_len=config.epoch_len, seed=config.seed)
     engine = LHRSEngine(model, optimizer=config.get("optimizer", "adanp"), lr=float(config.get("lr", 2e-4)),
-                        weight_decay=float(config.get("wd", 0.0)), max_grad_norm=float(config.get("max_grad_norm", 0.3)))
+                        weight_decay=float(config.get("wd", 0.0)), max_grad_norm=float(config.get("max_grad_norm", 0.3)),
+                        gradient_accumulation_steps=int(config.get("accumulation_steps", 1) or 1))
     trainer = EpochBasedTrainer(model=engine, optimizer=engine.optimizer, lr_scheduler=config.get("schedule", {"name": "const"}),
                                 data_loader=loader, max_epochs=int(config.get("epochs", 1) or 1), work_dir=config.output,
                                 log_period=config.log_period, save_ckpt_by="iter", ckpt_period=1000, accelerator=config.accelerator,

