@@ -201,3 +201,26 @@ def test_data_boundary_matches_reference_functions():
     images, ids, targets, names, mask = D.DataCollatorForVGSupervisedDataset(tok)(inst)
     assert ids.tolist() == z["vg"]["ids"] and mask.tolist() == z["vg"]["mask"] and targets == z["vg"]["targets"]
     assert names == z["vg"]["names"] and list(images.shape) == z["vg"]["images_shape"]
+
+
+def test_keywords_stopping_criteria_matches_reference():
+    import json
+
+    from lhrs_bot_amd.eval_utils import KeywordsStoppingCriteria
+
+    z = json.load(open(os.path.join(G, "stopping_criteria.json")))
+    vocab = {int(k): v for k, v in z["vocab"].items()}
+
+    class Tok:  # identical to tests/golden/make_golden_stop.py
+        bos_token_id = 1
+
+        def __call__(self, text):
+            inv = {v: k for k, v in vocab.items()}
+            return type("E", (), {"input_ids": [1] + [inv[w] for w in text.split(" ") if w]})()
+
+        def batch_decode(self, ids, skip_special_tokens=True):
+            return [" ".join(vocab[int(t)] for t in row if not (skip_special_tokens and int(t) in (1, 9))) for row in ids]
+
+    for c in z["cases"]:
+        crit = KeywordsStoppingCriteria(z["keywords"], Tok(), torch.zeros((1, c["prompt_len"]), dtype=torch.long))
+        assert crit(torch.tensor([c["out"]]), None) == c["stop"], c
