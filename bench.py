@@ -247,7 +247,7 @@ def main():
                        "grad_allreduce": a.comm_dtype if world > 1 else "none"},
             "loss": round(final_loss, 4),
             "step_mfma_frac": round(sps / world * f_alg(S) / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 and a.stage == 1 else None,
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_256r_kernel (256x256 tile, 16 waves, BK=64 double-buffered LDS stages via global_load_lds DMA, v_mfma_f32_32x32x16_bf16)", "achieved": round(ach, 1),
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_256r_kernel<ACT, 0> (256x256 tile, 16 waves, BK=64 double-buffered LDS stages via global_load_lds DMA, v_mfma_f32_32x32x16_bf16; the two launches per layer with a fused SwiGLU epilogue are timed by rocprof only)", "achieved": round(ach, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "launches_timed": int(n_samp), "avg_launch_us": round(1e3 * ms / max(n_samp, 1), 2),
                          "sclk_mhz_during_timed_region": round(sclk) if sclk else None, "package_power_w": round(watts) if watts else None,
