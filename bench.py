@@ -85,7 +85,15 @@ def cpu_baseline(S: int, budget_s: float = 25.0):
     t_head = time.perf_counter() - t0
     t_layer = max(t_l1 - t_head, 1e-6)
     t_full = t_vit + t_pool + t_head + 32 * t_layer
-    return {"value": NB / t_full, "unit": "samples/s", "cores": threads, "kind": "port",
+    cpu_model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": NB / t_full, "unit": "samples/s", "cores": threads, "kind": "port", "cpu_model": cpu_model,
             "sample": (f"{NB} samples, S={S}: ViT-L/14 fwd {t_vit:.2f}s + AttnPooler fwd+bwd {t_pool:.2f}s + lm_head/CE fwd+bwd {t_head:.2f}s "
                        f"+ 1 of 32 LLaMA-7B layers fwd+dX-bwd {t_layer:.2f}s, extrapolated x32 (oracle/lhrs_oracle.py, fp32 torch CPU)")}
 
