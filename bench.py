@@ -156,6 +156,8 @@ def main():
                     help="1: projector-only + Adan (the headline metric, BASELINE configs[1..2]); 3: LoRA r=8 on q,k,v,o + AdamW, projector "
                          "frozen (BASELINE configs[3]); 2: LoRA r=128 on every linear + projector, AdamW (Config/multi_modal_stage2.yaml)")
     ap.add_argument("--comm-dtype", default="float32", choices=["float32", "bfloat16"])
+    ap.add_argument("--bits", type=int, default=16, choices=[16, 8],
+                    help="stages 2/3 only: 8 = frozen decoder linears in e4m3 (the reference's `bits: 8` base weights)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -194,6 +196,8 @@ def main():
             model.enable_lora(r=8, alpha=16, targets=("q", "k", "v", "o"))
         else:
             model.enable_lora(r=128, alpha=256)
+        if a.bits == 8:
+            model.text.quantize_base(8)
         model.prepare_for_training(freeze_text=False, tune_rgb_pooler=a.stage == 2)
         engine = LHRSEngine(model, optimizer="adamw", lr=1e-4 if a.stage == 3 else 2e-4, weight_decay=0.0, max_grad_norm=1.0,
                             comm_dtype=getattr(torch, a.comm_dtype))
@@ -246,7 +250,7 @@ def main():
             "metric": ("stage-1 pretrain samples/sec (224^2 image + 128-tok caption)" if a.stage == 1 else
                        f"stage-{a.stage} LoRA train samples/sec (224^2 image + 128-tok sequence)"), "value": round(sps, 3), "unit": "samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.bits == 16 or a.stage == 1 else "e4m3 base weights + bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: stage-1 projector-only, CLIP ViT-L/14@224 + AttnPooler + LLaMA2-7B "
                                    f"({a.llama_layers} layers), S={S}, random-init weights",
                        "micro_batch_per_gpu": B, "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",

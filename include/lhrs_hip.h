@@ -48,6 +48,11 @@ int lhrs_gemm_bf16_nt_lora(const void* A, int lda, const void* B, int ldb, const
                            int out_f32, int accumulate, float alpha, void* stream);
 /* 256x256-tile kernel choice (tuning / A-B tests): 0 never, 1 plain 4-stage ring, 2 default (16-wave BK=64 two-buffer kernel
  * when K % 64 == 0, else the BK=32 ring), 3 the 8-wave BK=64 kernel, 4 always the BK=32 ring */
+/* 8-bit frozen base weights (the reference trains stages 2/3 with `bits: 8`, lhrs/models/text_modal.py:91-131 -> bitsandbytes LLM.int8;
+ * here OCP e4m3 with per-row fp32 scales on the 2x-rate block-scaled MFMA, unit block scales): C[M, N] bf16 =
+ * sa[m] * sb[n] * (A8[M, K] . B8[N, K]^T) (+ residual).  A8 / B8 from lhrs_quant_fp8_rows; lda / ldb in bytes; K % 128 == 0. */
+int lhrs_gemm_fp8_nt(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, void* C, int ldc,
+                     int M, int N, int K, const void* residual, int ldr, float alpha, void* stream);
 /* LLaMA MLP with SwiGLU fused into the GEMM epilogues (HF LlamaMLP.forward: down(silu(gate(x)) * up(x)); text_modal.py:258-294).
  * fwd: gu[M, 2*ff] = X.Wgu^T (+ A2.B2^T), act[M, ff] = silu(gate) * up.  bwd: dgu[M, 2*ff] = swiglu'(gu) * (dY.WdT^T (+ A2.B2^T)),
  * dgu may alias gu; dact_scratch [M, ff] is only touched by the unfused fallback (may be NULL when lhrs_gemm_swiglu_fusable() == 1).

@@ -49,6 +49,9 @@ struct GemmArgs {
   const bf16_t* aux;
   bf16_t* aux_out;
   long ld_aux;
+  // e4m3 operands (gemm_fp8_256_kernel): per-row dequantisation scales of A (length M) and B (length N)
+  const float* sa;
+  const float* sb;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -1005,6 +1008,182 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256r_kernel(GemmArgs g) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// e4m3 x e4m3 -> bf16 GEMM for FROZEN base weights in 8-bit (the reference trains stages 2/3 with `bits: 8` base weights,
+// lhrs/models/text_modal.py:91-131 -> bitsandbytes LLM.int8): C[m][n] = sa[m] * sb[n] * sum_k A8[m][k] * B8[n][k]
+// (+ residual).  Same skeleton as gemm_nt_256q_kernel - 256x256 tile, 8 waves, two 64 KiB LDS buffers filled by global_load_lds,
+// one barrier per stage - but a stage row is 128 BYTES = 128 k and the product runs on v_mfma_scale_f32_32x32x64_f8f6f4 with unit
+// block scales (the only 2x-rate fp8 MFMA of gfx950): a stage is two blocks of 8 MFMAs (64 k each, 16 passes), every lane feeds
+// 32 consecutive k-bytes of its row (two ds_read_b128) to both operands.  Twice the FLOPs of the bf16 kernel per byte moved.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+__global__ __launch_bounds__(512, 2) void gemm_fp8_256_kernel(GemmArgs g) {
+  constexpr int BM = 256, BN = 256, BKB = 128;  // bytes (= k) per stage row
+  constexpr int A_BYTES = BM * BKB, STAGE = A_BYTES + BN * BKB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  int tm, tn;
+  tile_coords(g, tm, tn);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const bool isA = wave < 4;
+  const char* base1 = reinterpret_cast<const char*>(isA ? g.A : g.B);
+  const long ld1 = isA ? g.lda : g.ldb;  // bytes
+  const int row0 = isA ? tm * BM : tn * BN, rmax = (isA ? g.M : g.N) - 1;
+  unsigned off1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ridx = (wave & 3) * 8 + j;
+    const int lchunk = (lane & 7) ^ ((((j & 1) << 2) + (lane >> 4)) & 7);
+    const int row = min(row0 + ridx * 8 + (lane >> 3), rmax);
+    off1[j] = (unsigned)((long)row * ld1 + lchunk * 16);
+  }
+  const int dst0 = (isA ? 0 : A_BYTES) + (wave & 3) * 8192;
+  auto issue1 = [&](int kt, int j) {
+    const char* p = base1 + (long)kt * BKB + off1[j];
+    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + (kt & 1) * STAGE + dst0 + j * 1024), 16, 0, 0);
+  };
+
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int sw = (fr >> 1) & 7;
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+  const unsigned a_base = lds0 + (wm * 128 + fr) * 128;
+  const unsigned b_base = lds0 + A_BYTES + (wn * 64 + fr) * 128;
+  unsigned kofs[2][2];  // [k-step][16-B half]
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) kofs[ks][hh] = ((ks * 4 + fh * 2 + hh) ^ sw) * 16;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  i32x8 a0[4], b0[2], a1[4], b1[2];
+  // one fragment = two ds_read_b128 (k-bytes [0,16) and [16,32) of the lane's 32) forming one 8-VGPR operand.  Plain LDS loads, not
+  // inline asm as in the bf16 kernels: the halves of an 8-register tuple cannot be named as asm outputs, and letting the compiler see
+  // the loads keeps its register reuse and s_waitcnt placement correct around the 16-pass MFMAs (sched_barriers pin the interleave)
+  typedef const __attribute__((address_space(3))) i32x4* lds4_t;
+#define RD8(dst, addr0, addr1, off)                                                                                  \
+  do {                                                                                                               \
+    const i32x4 lo_ = *reinterpret_cast<lds4_t>((size_t)((addr0) + (off)));                                          \
+    const i32x4 hi_ = *reinterpret_cast<lds4_t>((size_t)((addr1) + (off)));                                          \
+    dst = i32x8{lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]};                                     \
+  } while (0)
+#define MF8(A_, B_, mi, ni)                                                                                          \
+  acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B_[ni], A_[mi], acc[mi][ni], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F); \
+  __builtin_amdgcn_sched_barrier(0);
+#define SB8 __builtin_amdgcn_sched_barrier(0);
+  // one block: 8 MFMAs (64 k); fillers: the 6 fragments (12 reads) of the next block and up to 8 DMA pieces of stage kd
+#define BLOCK8(Ac, Bc, An, Bn, aa0, aa1, ba0, ba1, RD, kd, d0, NDMA)                                       \
+  MF8(Ac, Bc, 0, 0) if (RD) RD8(Bn[0], ba0, ba1, 0);     if (NDMA > 0) issue1(kd, d0);     SB8             \
+  MF8(Ac, Bc, 0, 1) if (RD) RD8(Bn[1], ba0, ba1, 4096);  if (NDMA > 1) issue1(kd, d0 + 1); SB8             \
+  MF8(Ac, Bc, 1, 0) if (RD) RD8(An[0], aa0, aa1, 0);     if (NDMA > 2) issue1(kd, d0 + 2); SB8             \
+  MF8(Ac, Bc, 1, 1) if (RD) RD8(An[1], aa0, aa1, 4096);  if (NDMA > 3) issue1(kd, d0 + 3); SB8             \
+  MF8(Ac, Bc, 2, 0) if (RD) RD8(An[2], aa0, aa1, 8192);  if (NDMA > 4) issue1(kd, d0 + 4); SB8             \
+  MF8(Ac, Bc, 2, 1) if (RD) RD8(An[3], aa0, aa1, 12288); if (NDMA > 5) issue1(kd, d0 + 5); SB8             \
+  MF8(Ac, Bc, 3, 0)                                      if (NDMA > 6) issue1(kd, d0 + 6); SB8             \
+  MF8(Ac, Bc, 3, 1)                                      if (NDMA > 7) issue1(kd, d0 + 7); SB8
+
+  const int nk = g.K / BKB;  // >= 2 (host guarantees)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) issue1(0, j);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) issue1(1, j);
+  {
+    const unsigned aa0 = a_base + kofs[0][0], aa1 = a_base + kofs[0][1], ba0 = b_base + kofs[0][0], ba1 = b_base + kofs[0][1];
+    RD8(b0[0], ba0, ba1, 0); RD8(b0[1], ba0, ba1, 4096);
+    RD8(a0[0], aa0, aa1, 0); RD8(a0[1], aa0, aa1, 4096); RD8(a0[2], aa0, aa1, 8192); RD8(a0[3], aa0, aa1, 12288);
+  }
+  {  // block ks0 of stage 0; loads ks1 of stage 0
+    const unsigned aa0 = a_base + kofs[1][0], aa1 = a_base + kofs[1][1], ba0 = b_base + kofs[1][0], ba1 = b_base + kofs[1][1];
+    BLOCK8(a0, b0, a1, b1, aa0, aa1, ba0, ba1, true, 0, 0, 0)
+  }
+  auto stage = [&](auto dma_c, int kt) {
+    constexpr bool DMA = decltype(dma_c)::value;
+    const unsigned so = (kt & 1) * STAGE;
+    // block ks1(kt-1): retire its fragment reads, then the barrier that publishes stage kt and frees the other buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    {
+      const unsigned aa0 = a_base + so + kofs[0][0], aa1 = a_base + so + kofs[0][1], ba0 = b_base + so + kofs[0][0], ba1 = b_base + so + kofs[0][1];
+      BLOCK8(a1, b1, a0, b0, aa0, aa1, ba0, ba1, true, kt + 1, 0, (DMA ? 8 : 0))
+    }
+      {
+      const unsigned aa0 = a_base + so + kofs[1][0], aa1 = a_base + so + kofs[1][1], ba0 = b_base + so + kofs[1][0], ba1 = b_base + so + kofs[1][1];
+      BLOCK8(a0, b0, a1, b1, aa0, aa1, ba0, ba1, true, 0, 0, 0)
+    }
+  };
+  for (int kt = 1; kt < nk - 1; ++kt) stage(std::true_type{}, kt);
+  stage(std::false_type{}, nk - 1);
+  { BLOCK8(a1, b1, a0, b0, a_base, a_base, b_base, b_base, false, 0, 0, 0) }
+#undef BLOCK8
+#undef SB8
+#undef MF8
+#undef RD8
+
+  __builtin_amdgcn_s_barrier();
+  char* reg = smem + wave * 16384;
+  {
+    float sbv[2][4][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = min(tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4, g.N - 4);
+        const float4 s4 = *reinterpret_cast<const float4*>(g.sb + n);
+        sbv[ni][q][0] = s4.x; sbv[ni][q][1] = s4.y; sbv[ni][q][2] = s4.z; sbv[ni][q][3] = s4.w;
+      }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int row = mi * 32 + fr;
+      const float sa = g.sa[min(tm * BM + wm * 128 + row, g.M - 1)] * g.alpha;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = acc[mi][ni][4 * q + i] * sa * sbv[ni][q][i];
+          const int u = ni * 8 + q * 2 + fh;
+          *reinterpret_cast<uint2*>(reg + row * 128 + ((u ^ ((row & 7) << 1)) << 3)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  {
+    const int rsub = lane >> 3, c = lane & 7;
+    const int n = tn * BN + wn * 64 + c * 8;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = i * 8 + rsub;
+      const int m = tm * BM + wm * 128 + row;
+      uint4 val = *reinterpret_cast<const uint4*>(reg + row * 128 + ((c ^ (row & 7)) << 4));
+      if (m < g.M && n < g.N) {
+        if (g.res) {
+          const uint4 r = *reinterpret_cast<const uint4*>(g.res + (long)m * g.ldr + n);
+          val.x = pack2bf(bflo(val.x) + bflo(r.x), bfhi(val.x) + bfhi(r.x));
+          val.y = pack2bf(bflo(val.y) + bflo(r.y), bfhi(val.y) + bfhi(r.y));
+          val.z = pack2bf(bflo(val.z) + bflo(r.z), bfhi(val.z) + bfhi(r.z));
+          val.w = pack2bf(bflo(val.w) + bflo(r.w), bfhi(val.w) + bfhi(r.w));
+        }
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n) = val;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // ---- optional live timing of the GEMM launches (bench.py roofline leg) -----------------------------------
@@ -1091,7 +1270,7 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   LHRS_REQUIRE(!accumulate || out_f32, "gemm: accumulate needs f32 output");
   LHRS_REQUIRE(act >= 0 && act <= 3, "gemm: unknown activation %d", act);
   GemmArgs g;
-  g.epi = 0; g.ff = 0; g.aux = nullptr; g.aux_out = nullptr; g.ld_aux = 0;
+  g.epi = 0; g.ff = 0; g.aux = nullptr; g.aux_out = nullptr; g.ld_aux = 0; g.sa = nullptr; g.sb = nullptr;
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C;
   g.bias = (const bf16_t*)bias; g.res = (const bf16_t*)residual;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
@@ -1238,5 +1417,23 @@ extern "C" int lhrs_gemm_swiglu_bwd(const void* dY, int ldy, const void* WdT, in
   prof_count(M, ff, K + K2);
   hipLaunchKernelGGL((gemm_nt_256r_kernel<0, 2>), dim3(g.tilesM * g.tilesN), dim3(1024), 0, s, g);
   LHRS_CHECK_LAUNCH("gemm_swiglu_bwd");
+  return 0;
+}
+
+
+// C[M, N] (bf16) = sa[m] * sb[n] * (A8[M, K] . B8[N, K]^T) (+ residual): e4m3 operands with per-row fp32 scales (lhrs_quant_fp8_rows).
+// K % 128 == 0, N % 8 == 0; lda / ldb in BYTES (>= K, multiples of 16).
+extern "C" int lhrs_gemm_fp8_nt(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, void* C, int ldc,
+                                int M, int N, int K, const void* residual, int ldr, float alpha, void* stream) {
+  LHRS_REQUIRE(M > 0 && N > 0 && K >= 256 && K % 128 == 0, "gemm_fp8: M=%d N=%d K=%d (K %% 128 == 0, K >= 256)", M, N, K);
+  LHRS_REQUIRE(lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K && sa && sb, "gemm_fp8: lda=%ld ldb=%ld", lda, ldb);
+  LHRS_REQUIRE(N % 8 == 0 && ldc % 8 == 0 && ldc >= N && (residual == nullptr || ldr % 8 == 0), "gemm_fp8: N=%d ldc=%d ldr=%d", N, ldc, ldr);
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  g.A = (const bf16_t*)A8; g.B = (const bf16_t*)B8; g.C = C; g.res = (const bf16_t*)residual;
+  g.M = M; g.N = N; g.K = K; g.lda = (int)lda; g.ldb = (int)ldb; g.ldc = ldc; g.ldr = ldr; g.alpha = alpha; g.sa = sa; g.sb = sb;
+  g.tilesM = cdiv(M, 256); g.tilesN = cdiv(N, 256);
+  if (g_prof.on) { g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * K; }
+  hipLaunchKernelGGL(gemm_fp8_256_kernel, dim3(g.tilesM * g.tilesN), dim3(512), 0, (hipStream_t)stream, g);
+  LHRS_CHECK_LAUNCH("gemm_fp8_nt");
   return 0;
 }

@@ -97,6 +97,20 @@ def gemm_swiglu_bwd(dy, w_down_t, gu, ff, a2=None, b2=None, out=None):
     return dgu
 
 
+def gemm_fp8_nt(a8, sa, b8, sb, out=None, *, residual=None, alpha=1.0):
+    """out[M, N] bf16 = sa[:, None] * sb[None, :] * (a8 @ b8^T) (+ residual); a8 [M, K], b8 [N, K] uint8 e4m3 with per-row fp32 scales."""
+    M, K = a8.shape
+    N = b8.shape[0]
+    assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and sa.dtype == torch.float32 and sb.dtype == torch.float32
+    if out is None:
+        out = torch.empty((M, N), device=a8.device, dtype=torch.bfloat16)
+    st = _L().lhrs_gemm_fp8_nt(a8.data_ptr(), a8.stride(0), sa.data_ptr(), b8.data_ptr(), b8.stride(0), sb.data_ptr(), out.data_ptr(),
+                               out.stride(0), M, N, K, _p(residual), residual.stride(0) if residual is not None else 0, float(alpha),
+                               _stream())
+    _lib.check(st, "gemm_fp8_nt")
+    return out
+
+
 def gemm_tn_skinny(p, q, out, accumulate=False):
     """out[KP, N] (+)= p[M, KP]^T @ q[M, N]  (fp32 out; p, q token-major bf16, row strides free)."""
     M, KP = p.shape

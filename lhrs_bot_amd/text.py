@@ -145,6 +145,7 @@ class TextModal:
         self.sin = fr.sin().to(torch.bfloat16).float().to(self.device).contiguous()
         self._ctx = None
         self.lora: Optional[LoraStore] = None
+        self.base8 = False  # frozen decoder linears in e4m3 (quantize_base)
         self.text_encoder = self  # attribute path used by the entry scripts (.text.text_encoder)
 
     def get_text_encoder(self):
@@ -219,19 +220,33 @@ class TextModal:
         self.lora = LoraStore(len(self.p["layers"]), r, alpha, targets, dims, self.device, seed)
         return self.lora
 
-    def _lin(self, li, gname, x, W, residual=None, save=None):
-        """y = x W^T (+ s (x A^T) B^T when the group carries adapters) (+ residual)."""
+    def _q8(self, L, name):
+        """(e4m3 weight, per-row scales) of L[name] when the base weights are 8-bit (quantize_base), else None."""
+        return (L[name + "8"], L[name + "8s"]) if self.base8 else None
+
+    def _lin(self, li, gname, x, W, residual=None, save=None, q8=None):
+        """y = x W^T (+ s (x A^T) B^T when the group carries adapters) (+ residual).  q8 = (W8, scales): the frozen base product runs
+        on the e4m3 MFMA path (x quantised per row on the fly), the adapter update stays bf16 and is added by a second small GEMM."""
         lo = self.lora
-        if lo is None or gname not in lo.groups:
+        has_lora = lo is not None and gname in lo.groups
+        if has_lora:
+            T = hk.gemm_nt(x, lo.view(lo.shadow, li, gname, "A"), alpha=lo.s)          # [M, KP] = s * x A^T
+            if save is not None:
+                save["T_" + gname] = T
+        if q8 is not None:
+            x8, sx = hk.quant_fp8_rows(x)
+            y = hk.gemm_fp8_nt(x8, sx, q8[0], q8[1], residual=residual)
+            return hk.gemm_nt(T, lo.derived[(li, gname, "Bfull")], residual=y) if has_lora else y
+        if not has_lora:
             return hk.gemm_nt(x, W, residual=residual)
-        T = hk.gemm_nt(x, lo.view(lo.shadow, li, gname, "A"), alpha=lo.s)          # [M, KP] = s * x A^T
-        if save is not None:
-            save["T_" + gname] = T
         return hk.gemm_nt_lora(x, W, T, lo.derived[(li, gname, "Bfull")], residual=residual)
 
-    def _gu_fwd(self, li, h, W, save):
+    def _gu_fwd(self, li, h, W, save, q8=None):
         """gate|up projection with the SwiGLU in the GEMM epilogue (one launch): -> (gu [M, 2ff], act [M, ff])."""
         lo = self.lora
+        if self.base8:
+            gu = self._lin(li, "gu", h, W, save=save, q8=q8)
+            return gu, hk.swiglu_fwd(gu, self.ff)
         if lo is None or "gu" not in lo.groups:
             return hk.gemm_swiglu_fwd(h, W, self.ff)
         T = hk.gemm_nt(h, lo.view(lo.shadow, li, "gu", "A"), alpha=lo.s)
@@ -239,9 +254,11 @@ class TextModal:
             save["T_gu"] = T
         return hk.gemm_swiglu_fwd(h, W, self.ff, T, lo.derived[(li, "gu", "Bfull")])
 
-    def _down_bwd(self, li, dy, WT, gu, act, T):
+    def _down_bwd(self, li, dy, WT, gu, act, T, q8=None):
         """dgu (written over gu) = swiglu'(gu) * d_act with d_act = dy W_down (+ LoRA) never leaving the GEMM epilogue."""
         lo = self.lora
+        if q8 is not None:
+            return hk.swiglu_bwd(self._lin_bwd(li, "down", dy, WT, act, T, q8=q8), gu, self.ff, out=gu)
         if lo is None or "down" not in lo.groups:
             return hk.gemm_swiglu_bwd(dy, WT, gu, self.ff)
         G = lo.groups["down"]
@@ -252,14 +269,24 @@ class TextModal:
         hk.blockdiag_mask(dBD, lo.r, G["fout"], G["mask"])
         return dgu
 
-    def _lin_bwd(self, li, gname, dy, WT, x, T):
-        """dx = dy W (+ s (dy B) A); adapter gradients dA = (s dy B)^T x, dB^T = (s x A^T)^T dy written into lora.grad."""
+    def _lin_bwd(self, li, gname, dy, WT, x, T, q8=None):
+        """dx = dy W (+ s (dy B) A); adapter gradients dA = (s dy B)^T x, dB^T = (s x A^T)^T dy written into lora.grad.
+        q8 = (WT8, scales): e4m3 copy of the transposed base weight (per in-feature scales), dy quantised per row on the fly."""
         lo = self.lora
-        if lo is None or gname not in lo.groups:
+        has_lora = lo is not None and gname in lo.groups
+        if q8 is not None:
+            dy8, sdy = hk.quant_fp8_rows(dy)
+            dx = hk.gemm_fp8_nt(dy8, sdy, q8[0], q8[1])
+            if not has_lora:
+                return dx
+        elif not has_lora:
             return hk.gemm_nt(dy, WT)
         G = lo.groups[gname]
         U = hk.gemm_nt(dy, lo.view(lo.shadow, li, gname, "BD"), alpha=lo.s)         # [M, KP] = s * dy B
-        dx = hk.gemm_nt_lora(dy, WT, U, lo.derived[(li, gname, "AT")])
+        if q8 is not None:
+            dx = hk.gemm_nt(U, lo.derived[(li, gname, "AT")], residual=dx)
+        else:
+            dx = hk.gemm_nt_lora(dy, WT, U, lo.derived[(li, gname, "AT")])
         hk.gemm_tn_skinny(U, x, lo.view(lo.grad, li, gname, "A"))
         dBD = hk.gemm_tn_skinny(T, dy, lo.view(lo.grad, li, gname, "BD"))
         hk.blockdiag_mask(dBD, lo.r, G["fout"], G["mask"])
@@ -286,15 +313,15 @@ class TextModal:
         M = x.shape[0]
         rec = {} if save is not None else None
         h = hk.rmsnorm_fwd(x, L["ln1_w"], self.eps)
-        qkv = self._lin(li, "qkv", h, L["qkv_w"], save=rec)
+        qkv = self._lin(li, "qkv", h, L["qkv_w"], save=rec, q8=self._q8(L, "qkv_w"))
         hk.rope_(qkv, M, 2 * H, hd, self.cos, self.sin, pos_mod=S)
         o = torch.empty((M, d), device=self.device, dtype=torch.bfloat16)
         lse = torch.empty((B, H, LT), device=self.device, dtype=torch.float32)
         hk.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, desc, B, H, hd, S, S, LT, True, 1.0 / math.sqrt(hd))
-        x_mid = self._lin(li, "o", o, L["o_w"], residual=x, save=rec)
+        x_mid = self._lin(li, "o", o, L["o_w"], residual=x, save=rec, q8=self._q8(L, "o_w"))
         h = hk.rmsnorm_fwd(x_mid, L["ln2_w"], self.eps, out=h)
-        gu, act = self._gu_fwd(li, h, L["gu_w"], rec)
-        x_out = self._lin(li, "down", act, L["down_w"], residual=x_mid, save=rec)
+        gu, act = self._gu_fwd(li, h, L["gu_w"], rec, q8=self._q8(L, "gu_w"))
+        x_out = self._lin(li, "down", act, L["down_w"], residual=x_mid, save=rec, q8=self._q8(L, "down_w"))
         if save is not None:
             rec.update(x_in=x, qkv=qkv, o=o, lse=lse, x_mid=x_mid, gu=gu)
             save.append(rec)
@@ -365,6 +392,24 @@ class TextModal:
             for k in ("qkv_w", "o_w", "gu_w", "down_w"):
                 L[k + "8"], L[k + "8s"] = hk.quant_fp8_rows(L[k])
         self.p["lm_head8"], self.p["lm_head8s"] = hk.quant_fp8_rows(self.p["lm_head"])
+
+    def quantize_base(self, bits: int = 8):
+        """`bits: 8` of Config/multi_modal_stage{2,3}.yaml (text_modal.py:91-131: the reference loads the frozen LLaMA through
+        bitsandbytes LLM.int8 for stages 2/3).  MI355X-native equivalent: every decoder linear (lm_head stays bf16, as bitsandbytes
+        skips it) gets OCP e4m3 copies with one fp32 scale per output row - of W for the forward product and of W^T for the dX product -
+        and TRAINING runs both on the 2x-rate block-scaled MFMA with activations quantised per row on the fly.  LoRA adapters, norms,
+        attention and the loss stay bf16 / fp32.  bitsandbytes is not importable here: the scheme is ours, parity vs LLM.int8 unpinned."""
+        if bits not in (8, 16):
+            raise NotImplementedError(f"bits={bits}: 16 (bf16) or 8 (e4m3 base weights)")
+        if bits == 16:
+            self.base8 = False
+            return self
+        self.quantize_fp8()
+        for L in self.p["layers"]:
+            for k in ("qkv_wT", "o_wT", "gu_wT", "down_wT"):
+                L[k + "8"], L[k + "8s"] = hk.quant_fp8_rows(L[k])
+        self.base8 = True
+        return self
 
     def _decode_session(self, B, max_ctx, caches, max_new, weights="bf16", kmask=None):
         """Static buffers + one captured hipGraph for the single-token step (batch <= 16): embedding gather, 32 x [RMSNorm,
@@ -575,17 +620,17 @@ class TextModal:
             L, s = p["layers"][li], c["layers"][li]
             gu, qkv = s["gu"], s["qkv"]
             act = hk.swiglu_fwd(gu, ff) if lo is not None and "down" in lo.groups else None      # x of the down projection
-            dgu = self._down_bwd(li, dx, L["down_wT"], gu, act, s.get("T_down"))
+            dgu = self._down_bwd(li, dx, L["down_wT"], gu, act, s.get("T_down"), q8=self._q8(L, "down_wT"))
             h2 = hk.rmsnorm_fwd(s["x_mid"], L["ln2_w"], self.eps) if lo is not None and "gu" in lo.groups else None
-            dh = self._lin_bwd(li, "gu", dgu, L["gu_wT"], h2, s.get("T_gu"))
+            dh = self._lin_bwd(li, "gu", dgu, L["gu_wT"], h2, s.get("T_gu"), q8=self._q8(L, "gu_wT"))
             dx_mid = hk.rmsnorm_bwd(dh, s["x_mid"], L["ln2_w"], None, add=dx, eps=self.eps, out=dh)
-            do = self._lin_bwd(li, "o", dx_mid, L["o_wT"], s["o"], s.get("T_o"))
+            do = self._lin_bwd(li, "o", dx_mid, L["o_wT"], s["o"], s.get("T_o"), q8=self._q8(L, "o_wT"))
             hk.attn_delta(s["o"], do, delta, desc, B, H, hd, S, LT)
             hk.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], do, s["lse"], delta, dqkv[:, :d], dqkv[:, d:2 * d],
                         dqkv[:, 2 * d:], desc, B, H, hd, S, S, LT, True, scale)
             hk.rope_(dqkv, M, 2 * H, hd, self.cos, self.sin, pos_mod=S, inverse=True)
             h1 = hk.rmsnorm_fwd(s["x_in"], L["ln1_w"], self.eps) if lo is not None and "qkv" in lo.groups else None
-            dh1 = self._lin_bwd(li, "qkv", dqkv, L["qkv_wT"], h1, s.get("T_qkv"))
+            dh1 = self._lin_bwd(li, "qkv", dqkv, L["qkv_wT"], h1, s.get("T_qkv"), q8=self._q8(L, "qkv_wT"))
             dx = hk.rmsnorm_bwd(dh1, s["x_in"], L["ln1_w"], None, add=dx_mid, eps=self.eps, out=dh1)
             s.clear()
             if on_layer_ready is not None:
