@@ -53,6 +53,11 @@ int lhrs_gemm_bf16_nt_lora(const void* A, int lda, const void* B, int ldb, const
  * sa[m] * sb[n] * (A8[M, K] . B8[N, K]^T) (+ residual).  A8 / B8 from lhrs_quant_fp8_rows; lda / ldb in bytes; K % 128 == 0. */
 int lhrs_gemm_fp8_nt(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, void* C, int ldc,
                      int M, int N, int K, const void* residual, int ldr, float alpha, void* stream);
+/* ... + alpha * A2[M, K2] . B2[N, K2]^T in bf16 on the same accumulators: the LoRA update of an 8-bit base linear (peft lora.Linear over
+ * a bitsandbytes base, text_modal.py:91-151); lda2 / ldb2 in elements, K2 % 64 == 0 */
+int lhrs_gemm_fp8_nt_lora(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, const void* A2,
+                          int lda2, const void* B2, int ldb2, int K2, void* C, int ldc, int M, int N, int K,
+                          const void* residual, int ldr, float alpha, void* stream);
 /* LLaMA MLP with SwiGLU fused into the GEMM epilogues (HF LlamaMLP.forward: down(silu(gate(x)) * up(x)); text_modal.py:258-294).
  * fwd: gu[M, 2*ff] = X.Wgu^T (+ A2.B2^T), act[M, ff] = silu(gate) * up.  bwd: dgu[M, 2*ff] = swiglu'(gu) * (dY.WdT^T (+ A2.B2^T)),
  * dgu may alias gu; dact_scratch [M, ff] is only touched by the unfused fallback (may be NULL when lhrs_gemm_swiglu_fusable() == 1).

@@ -230,23 +230,55 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
   }
 }
 
-// per-row e4m3 quantisation: scale[n] = max|W[n,:]| / 448, W8 = round(W / scale)
+// per-row e4m3 quantisation: scale[n] = max|W[n,:]| / 448, W8 = round(W / scale).  One block per row, 16-B loads; the row stays in
+// registers between the max and the conversion (up to 12 chunks of 8 per thread = K <= 24576; longer rows are re-read from L2).
+constexpr int QCH = 12;
 __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __restrict__ W, long ldw, uint8_t* __restrict__ W8, long ld8,
                                                              float* __restrict__ scale, int K) {
   __shared__ float red[4];
-  const int n = blockIdx.x;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int nch = K / 8;  // K % 16 == 0
+  const bf16_t* row = W + (long)n * ldw;
+  uint4 keep[QCH];
   float m = 0.f;
-  for (int k = threadIdx.x; k < K; k += 256) m = fmaxf(m, fabsf(bf2f(W[(long)n * ldw + k])));
+#pragma unroll
+  for (int i = 0; i < QCH; ++i) {
+    const int c = tid + i * 256;
+    keep[i] = make_uint4(0, 0, 0, 0);
+    if (c < nch) {
+      keep[i] = *reinterpret_cast<const uint4*>(row + c * 8);
+      float v[8];
+      unpack8(keep[i], v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+    }
+  }
+  for (int c = tid + QCH * 256; c < nch; c += 256) {
+    float v[8];
+    unpack8(*reinterpret_cast<const uint4*>(row + c * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+  }
   m = block_max<4>(m, red);
   const float sc = m > 0.f ? m / 448.f : 1.f;
-  if (threadIdx.x == 0) scale[n] = sc;
+  if (tid == 0) scale[n] = sc;
   const float inv = 1.f / sc;
-  for (int k4 = threadIdx.x; k4 < K / 4; k4 += 256) {
-    const bf16_t* p = W + (long)n * ldw + k4 * 4;
-    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(p[0]) * inv, bf2f(p[1]) * inv, 0, false);
-    pk = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(p[2]) * inv, bf2f(p[3]) * inv, pk, true);
-    *reinterpret_cast<int*>(W8 + (long)n * ld8 + k4 * 4) = pk;
+  uint8_t* orow = W8 + (long)n * ld8;
+  auto cvt8 = [&](const uint4& raw, int c) {
+    float v[8];
+    unpack8(raw, v);
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, hi, true);
+    *reinterpret_cast<int2*>(orow + c * 8) = make_int2(lo, hi);
+  };
+#pragma unroll
+  for (int i = 0; i < QCH; ++i) {
+    const int c = tid + i * 256;
+    if (c < nch) cvt8(keep[i], c);
   }
+  for (int c = tid + QCH * 256; c < nch; c += 256) cvt8(*reinterpret_cast<const uint4*>(row + c * 8), c);
 }
 
 // RoPE on the new q / k rows + append of (rotated k, v) to the cache at the device-resident position
@@ -559,7 +591,7 @@ extern "C" int lhrs_gemv_bf16(const void* W, long ldw, const void* x, long ldx, 
 }
 
 extern "C" int lhrs_quant_fp8_rows(const void* W, long ldw, void* W8, long ld8, float* scale, int N, int K, void* stream) {
-  LHRS_REQUIRE(N > 0 && K % 16 == 0 && ld8 % 16 == 0, "quant_fp8_rows: N=%d K=%d ld8=%ld", N, K, ld8);
+  LHRS_REQUIRE(N > 0 && K % 16 == 0 && ld8 % 16 == 0 && ldw % 8 == 0, "quant_fp8_rows: N=%d K=%d ldw=%ld ld8=%ld", N, K, ldw, ld8);
   hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W, ldw, (uint8_t*)W8, ld8, scale, K);
   LHRS_CHECK_LAUNCH("quant_fp8_rows");
   return 0;

@@ -1034,17 +1034,24 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256_kernel(GemmArgs g) {
   const char* base1 = reinterpret_cast<const char*>(isA ? g.A : g.B);
   const long ld1 = isA ? g.lda : g.ldb;  // bytes
   const int row0 = isA ? tm * BM : tn * BN, rmax = (isA ? g.M : g.N) - 1;
-  unsigned off1[8];
+  // optional bf16 pair (fused LoRA update, K2 % 64 == 0): its 64-k stages have the same 128-byte row image and follow the e4m3 stages
+  const char* base2 = reinterpret_cast<const char*>(isA ? g.A2 : g.B2);
+  const long ld2 = (isA ? g.lda2 : g.ldb2) * 2L;  // bytes
+  const int nk1 = g.K / BKB;
+  unsigned off1[8], off2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int ridx = (wave & 3) * 8 + j;
     const int lchunk = (lane & 7) ^ ((((j & 1) << 2) + (lane >> 4)) & 7);
     const int row = min(row0 + ridx * 8 + (lane >> 3), rmax);
     off1[j] = (unsigned)((long)row * ld1 + lchunk * 16);
+    off2[j] = g.K2 > 0 ? (unsigned)((long)row * ld2 + lchunk * 16) : 0u;
   }
   const int dst0 = (isA ? 0 : A_BYTES) + (wave & 3) * 8192;
+  const int nk_all = nk1 + g.K2 / 64;    // e4m3 stages + bf16 stages of the fused pair
   auto issue1 = [&](int kt, int j) {
-    const char* p = base1 + (long)kt * BKB + off1[j];
+    if (kt >= nk_all) return;            // (wave-uniform) nothing left to fetch
+    const char* p = kt < nk1 ? base1 + (long)kt * BKB + off1[j] : base2 + (long)(kt - nk1) * BKB + off2[j];
     __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + (kt & 1) * STAGE + dst0 + j * 1024), 16, 0, 0);
   };
 
@@ -1094,7 +1101,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256_kernel(GemmArgs g) {
   MF8(Ac, Bc, 3, 0)                                      if (NDMA > 6) issue1(kd, d0 + 6); SB8             \
   MF8(Ac, Bc, 3, 1)                                      if (NDMA > 7) issue1(kd, d0 + 7); SB8
 
-  const int nk = g.K / BKB;  // >= 2 (host guarantees)
+  const int nk = nk1;                    // e4m3 stages, >= 2 (host guarantees)
 #pragma unroll
   for (int j = 0; j < 8; ++j) issue1(0, j);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1110,8 +1117,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256_kernel(GemmArgs g) {
     const unsigned aa0 = a_base + kofs[1][0], aa1 = a_base + kofs[1][1], ba0 = b_base + kofs[1][0], ba1 = b_base + kofs[1][1];
     BLOCK8(a0, b0, a1, b1, aa0, aa1, ba0, ba1, true, 0, 0, 0)
   }
-  auto stage = [&](auto dma_c, int kt) {
-    constexpr bool DMA = decltype(dma_c)::value;
+  auto stage = [&](int kt) {
+    constexpr bool DMA = true;  // issue1 is a no-op past the last stage
     const unsigned so = (kt & 1) * STAGE;
     // block ks1(kt-1): retire its fragment reads, then the barrier that publishes stage kt and frees the other buffer
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1125,13 +1132,53 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256_kernel(GemmArgs g) {
       BLOCK8(a0, b0, a1, b1, aa0, aa1, ba0, ba1, true, 0, 0, 0)
     }
   };
-  for (int kt = 1; kt < nk - 1; ++kt) stage(std::true_type{}, kt);
-  stage(std::false_type{}, nk - 1);
+  for (int kt = 1; kt < nk; ++kt) stage(kt);  // the last e4m3 stage already fetches the first bf16 stage of a fused pair
   { BLOCK8(a1, b1, a0, b0, a_base, a_base, b_base, b_base, false, 0, 0, 0) }
 #undef BLOCK8
 #undef SB8
 #undef MF8
 #undef RD8
+
+  bool scaled = false;
+  if (nk_all > nk) {
+    // ---- fused LoRA pair: bring the e4m3 sums to real units, then keep accumulating bf16 products (C layout is dtype-independent)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const float sa = g.sa[min(tm * BM + wm * 128 + mi * 32 + fr, g.M - 1)];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 s4 = *reinterpret_cast<const float4*>(g.sb + min(tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4, g.N - 4));
+          acc[mi][ni][4 * q] *= sa * s4.x; acc[mi][ni][4 * q + 1] *= sa * s4.y;
+          acc[mi][ni][4 * q + 2] *= sa * s4.z; acc[mi][ni][4 * q + 3] *= sa * s4.w;
+        }
+    }
+    scaled = true;
+    typedef const __attribute__((address_space(3))) bf16x8* ldsb_t;
+    for (int kt = nk; kt < nk_all; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // stage kt has landed everywhere; every wave is done with the other buffer
+      if (kt + 1 < nk_all) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) issue1(kt + 1, j);
+      }
+      const unsigned so = (kt & 1) * STAGE;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const unsigned ko = (((kk * 2 + fh) ^ sw) * 16);
+        bf16x8 af[4], bfr[2];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<ldsb_t>((size_t)(a_base + so + ko + mi * 4096));
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) bfr[ni] = *reinterpret_cast<ldsb_t>((size_t)(b_base + so + ko + ni * 4096));
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+      }
+    }
+  }
 
   __builtin_amdgcn_s_barrier();
   char* reg = smem + wave * 16384;
@@ -1142,13 +1189,14 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256_kernel(GemmArgs g) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = min(tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4, g.N - 4);
-        const float4 s4 = *reinterpret_cast<const float4*>(g.sb + n);
+        float4 s4 = *reinterpret_cast<const float4*>(g.sb + n);
+        if (scaled) s4 = make_float4(1.f, 1.f, 1.f, 1.f);
         sbv[ni][q][0] = s4.x; sbv[ni][q][1] = s4.y; sbv[ni][q][2] = s4.z; sbv[ni][q][3] = s4.w;
       }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       const int row = mi * 32 + fr;
-      const float sa = g.sa[min(tm * BM + wm * 128 + row, g.M - 1)] * g.alpha;
+      const float sa = (scaled ? 1.f : g.sa[min(tm * BM + wm * 128 + row, g.M - 1)]) * g.alpha;
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -1421,19 +1469,36 @@ extern "C" int lhrs_gemm_swiglu_bwd(const void* dY, int ldy, const void* WdT, in
 }
 
 
-// C[M, N] (bf16) = sa[m] * sb[n] * (A8[M, K] . B8[N, K]^T) (+ residual): e4m3 operands with per-row fp32 scales (lhrs_quant_fp8_rows).
-// K % 128 == 0, N % 8 == 0; lda / ldb in BYTES (>= K, multiples of 16).
-extern "C" int lhrs_gemm_fp8_nt(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, void* C, int ldc,
-                                int M, int N, int K, const void* residual, int ldr, float alpha, void* stream) {
+// C[M, N] (bf16) = alpha * sa[m] * sb[n] * (A8[M, K] . B8[N, K]^T) (+ residual): e4m3 operands with per-row fp32 scales
+// (lhrs_quant_fp8_rows).  K % 128 == 0, N % 8 == 0; lda / ldb in BYTES (>= K, multiples of 16).
+static int gemm_fp8_launch(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, const void* A2, int lda2,
+                           const void* B2, int ldb2, int K2, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
+                           float alpha, void* stream) {
   LHRS_REQUIRE(M > 0 && N > 0 && K >= 256 && K % 128 == 0, "gemm_fp8: M=%d N=%d K=%d (K %% 128 == 0, K >= 256)", M, N, K);
   LHRS_REQUIRE(lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K && sa && sb, "gemm_fp8: lda=%ld ldb=%ld", lda, ldb);
   LHRS_REQUIRE(N % 8 == 0 && ldc % 8 == 0 && ldc >= N && (residual == nullptr || ldr % 8 == 0), "gemm_fp8: N=%d ldc=%d ldr=%d", N, ldc, ldr);
+  LHRS_REQUIRE(K2 == 0 || (A2 && B2 && K2 % 64 == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && lda2 >= K2 && ldb2 >= K2),
+               "gemm_fp8: bad bf16 pair (K2=%d lda2=%d ldb2=%d)", K2, lda2, ldb2);
   GemmArgs g; memset(&g, 0, sizeof(g));
   g.A = (const bf16_t*)A8; g.B = (const bf16_t*)B8; g.C = C; g.res = (const bf16_t*)residual;
   g.M = M; g.N = N; g.K = K; g.lda = (int)lda; g.ldb = (int)ldb; g.ldc = ldc; g.ldr = ldr; g.alpha = alpha; g.sa = sa; g.sb = sb;
+  g.A2 = (const bf16_t*)A2; g.B2 = (const bf16_t*)B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
   g.tilesM = cdiv(M, 256); g.tilesN = cdiv(N, 256);
-  if (g_prof.on) { g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * K; }
+  if (g_prof.on) { g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * (K + K2); }
   hipLaunchKernelGGL(gemm_fp8_256_kernel, dim3(g.tilesM * g.tilesN), dim3(512), 0, (hipStream_t)stream, g);
   LHRS_CHECK_LAUNCH("gemm_fp8_nt");
   return 0;
+}
+
+extern "C" int lhrs_gemm_fp8_nt(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, void* C, int ldc,
+                                int M, int N, int K, const void* residual, int ldr, float alpha, void* stream) {
+  return gemm_fp8_launch(A8, lda, sa, B8, ldb, sb, nullptr, 0, nullptr, 0, 0, C, ldc, M, N, K, residual, ldr, alpha, stream);
+}
+
+// ... + alpha * A2[M, K2] . B2[N, K2]^T in bf16 on the same accumulators (the LoRA update of an 8-bit base linear), K2 % 64 == 0
+extern "C" int lhrs_gemm_fp8_nt_lora(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, const void* A2,
+                                     int lda2, const void* B2, int ldb2, int K2, void* C, int ldc, int M, int N, int K,
+                                     const void* residual, int ldr, float alpha, void* stream) {
+  LHRS_REQUIRE(K2 > 0, "gemm_fp8_lora: K2=%d", K2);
+  return gemm_fp8_launch(A8, lda, sa, B8, ldb, sb, A2, lda2, B2, ldb2, K2, C, ldc, M, N, K, residual, ldr, alpha, stream);
 }

@@ -97,16 +97,22 @@ def gemm_swiglu_bwd(dy, w_down_t, gu, ff, a2=None, b2=None, out=None):
     return dgu
 
 
-def gemm_fp8_nt(a8, sa, b8, sb, out=None, *, residual=None, alpha=1.0):
-    """out[M, N] bf16 = sa[:, None] * sb[None, :] * (a8 @ b8^T) (+ residual); a8 [M, K], b8 [N, K] uint8 e4m3 with per-row fp32 scales."""
+def gemm_fp8_nt(a8, sa, b8, sb, out=None, *, residual=None, alpha=1.0, a2=None, b2=None):
+    """out[M, N] bf16 = alpha * (sa[:, None] * sb[None, :] * (a8 @ b8^T) + a2 @ b2^T) (+ residual); a8 [M, K], b8 [N, K] uint8 e4m3 with
+    per-row fp32 scales; the optional bf16 pair a2 [M, K2], b2 [N, K2] (LoRA update) is accumulated by the same launch."""
     M, K = a8.shape
     N = b8.shape[0]
     assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and sa.dtype == torch.float32 and sb.dtype == torch.float32
     if out is None:
         out = torch.empty((M, N), device=a8.device, dtype=torch.bfloat16)
-    st = _L().lhrs_gemm_fp8_nt(a8.data_ptr(), a8.stride(0), sa.data_ptr(), b8.data_ptr(), b8.stride(0), sb.data_ptr(), out.data_ptr(),
-                               out.stride(0), M, N, K, _p(residual), residual.stride(0) if residual is not None else 0, float(alpha),
-                               _stream())
+    ldr = residual.stride(0) if residual is not None else 0
+    if a2 is None:
+        st = _L().lhrs_gemm_fp8_nt(a8.data_ptr(), a8.stride(0), sa.data_ptr(), b8.data_ptr(), b8.stride(0), sb.data_ptr(), out.data_ptr(),
+                                   out.stride(0), M, N, K, _p(residual), ldr, float(alpha), _stream())
+    else:
+        st = _L().lhrs_gemm_fp8_nt_lora(a8.data_ptr(), a8.stride(0), sa.data_ptr(), b8.data_ptr(), b8.stride(0), sb.data_ptr(), a2.data_ptr(),
+                                        a2.stride(0), b2.data_ptr(), b2.stride(0), a2.shape[1], out.data_ptr(), out.stride(0), M, N, K,
+                                        _p(residual), ldr, float(alpha), _stream())
     _lib.check(st, "gemm_fp8_nt")
     return out
 

@@ -226,7 +226,7 @@ class TextModal:
 
     def _lin(self, li, gname, x, W, residual=None, save=None, q8=None):
         """y = x W^T (+ s (x A^T) B^T when the group carries adapters) (+ residual).  q8 = (W8, scales): the frozen base product runs
-        on the e4m3 MFMA path (x quantised per row on the fly), the adapter update stays bf16 and is added by a second small GEMM."""
+        on the e4m3 MFMA path (x quantised per row on the fly), the adapter update stays bf16 and rides on the same accumulators (lhrs_gemm_fp8_nt_lora)."""
         lo = self.lora
         has_lora = lo is not None and gname in lo.groups
         if has_lora:
@@ -235,8 +235,9 @@ class TextModal:
                 save["T_" + gname] = T
         if q8 is not None:
             x8, sx = hk.quant_fp8_rows(x)
-            y = hk.gemm_fp8_nt(x8, sx, q8[0], q8[1], residual=residual)
-            return hk.gemm_nt(T, lo.derived[(li, gname, "Bfull")], residual=y) if has_lora else y
+            if has_lora:
+                return hk.gemm_fp8_nt(x8, sx, q8[0], q8[1], residual=residual, a2=T, b2=lo.derived[(li, gname, "Bfull")])
+            return hk.gemm_fp8_nt(x8, sx, q8[0], q8[1], residual=residual)
         if not has_lora:
             return hk.gemm_nt(x, W, residual=residual)
         return hk.gemm_nt_lora(x, W, T, lo.derived[(li, gname, "Bfull")], residual=residual)
@@ -276,15 +277,14 @@ class TextModal:
         has_lora = lo is not None and gname in lo.groups
         if q8 is not None:
             dy8, sdy = hk.quant_fp8_rows(dy)
-            dx = hk.gemm_fp8_nt(dy8, sdy, q8[0], q8[1])
             if not has_lora:
-                return dx
+                return hk.gemm_fp8_nt(dy8, sdy, q8[0], q8[1])
         elif not has_lora:
             return hk.gemm_nt(dy, WT)
         G = lo.groups[gname]
         U = hk.gemm_nt(dy, lo.view(lo.shadow, li, gname, "BD"), alpha=lo.s)         # [M, KP] = s * dy B
         if q8 is not None:
-            dx = hk.gemm_nt(U, lo.derived[(li, gname, "AT")], residual=dx)
+            dx = hk.gemm_fp8_nt(dy8, sdy, q8[0], q8[1], a2=U, b2=lo.derived[(li, gname, "AT")])
         else:
             dx = hk.gemm_nt_lora(dy, WT, U, lo.derived[(li, gname, "AT")])
         hk.gemm_tn_skinny(U, x, lo.view(lo.grad, li, gname, "A"))

@@ -37,6 +37,12 @@ def test_gemm_fp8_matches_dequantised_product(M, N, K):
     assert rel(ref, x.float() @ w.float().t()) < 4e-2                        # what the 8-bit base costs a single linear
     with pytest.raises(RuntimeError):
         hk.gemm_fp8_nt(x8[:, :K - 64], sx, w8[:, :K - 64], sw)              # K % 128 != 0 is rejected at the ABI
+    # fused bf16 pair (LoRA update on an 8-bit base): same launch, same accumulators
+    for K2 in (64, 192):
+        a2 = (torch.randn(M, K2, generator=g) * 0.3).to(DEV, torch.bfloat16)
+        b2 = (torch.randn(N, K2, generator=g) * 0.1).to(DEV, torch.bfloat16)
+        y = hk.gemm_fp8_nt(x8, sx, w8, sw, residual=r, a2=a2, b2=b2)
+        assert rel(y, ref + a2.float() @ b2.float().t() + r.float()) < 3e-3, K2
 
 
 @pytest.mark.timeout(900)
