@@ -58,6 +58,10 @@ int lhrs_gemm_fp8_nt(const void* A8, long lda, const float* sa, const void* B8, 
 int lhrs_gemm_fp8_nt_lora(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, const void* A2,
                           int lda2, const void* B2, int ldb2, int K2, void* C, int ldc, int M, int N, int K,
                           const void* residual, int ldr, float alpha, void* stream);
+/* SwiGLU forward / backward (HF LlamaMLP) emitting the per-row e4m3 operand of the next 8-bit-base GEMM directly; the bf16 result is
+ * written only when the pointer is non-NULL (an adapter needs it).  act8 [rows, F] / dgu8 [rows, 2F] bytes, scale [rows] fp32. */
+int lhrs_swiglu_fwd_q(const void* gate_up, void* act, void* act8, float* scale, long rows, int F, void* stream);
+int lhrs_swiglu_bwd_q(const void* dact, const void* gate_up, void* dgu, void* dgu8, float* scale, long rows, int F, void* stream);
 /* LLaMA MLP with SwiGLU fused into the GEMM epilogues (HF LlamaMLP.forward: down(silu(gate(x)) * up(x)); text_modal.py:258-294).
  * fwd: gu[M, 2*ff] = X.Wgu^T (+ A2.B2^T), act[M, ff] = silu(gate) * up.  bwd: dgu[M, 2*ff] = swiglu'(gu) * (dY.WdT^T (+ A2.B2^T)),
  * dgu may alias gu; dact_scratch [M, ff] is only touched by the unfused fallback (may be NULL when lhrs_gemm_swiglu_fusable() == 1).

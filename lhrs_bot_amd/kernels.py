@@ -269,6 +269,26 @@ def swiglu_fwd(gate_up, F, out=None):
     return act
 
 
+def swiglu_fwd_q(gate_up, F, want_bf16=False):
+    """-> (act bf16 or None, act8 uint8 [rows, F], scale fp32 [rows]): SwiGLU + per-row e4m3 quantisation in one pass."""
+    rows = gate_up.shape[0]
+    act = torch.empty((rows, F), device=gate_up.device, dtype=torch.bfloat16) if want_bf16 else None
+    act8 = torch.empty((rows, F), device=gate_up.device, dtype=torch.uint8)
+    sc = torch.empty(rows, device=gate_up.device, dtype=torch.float32)
+    _lib.check(_L().lhrs_swiglu_fwd_q(gate_up.data_ptr(), _p(act), act8.data_ptr(), sc.data_ptr(), rows, F, _stream()), "swiglu_fwd_q")
+    return act, act8, sc
+
+
+def swiglu_bwd_q(dact, gate_up, F, want_bf16=False):
+    """-> (dgu bf16 written over gate_up or None, dgu8 uint8 [rows, 2F], scale fp32 [rows])."""
+    rows = gate_up.shape[0]
+    dgu8 = torch.empty((rows, 2 * F), device=gate_up.device, dtype=torch.uint8)
+    sc = torch.empty(rows, device=gate_up.device, dtype=torch.float32)
+    _lib.check(_L().lhrs_swiglu_bwd_q(dact.data_ptr(), gate_up.data_ptr(), gate_up.data_ptr() if want_bf16 else None, dgu8.data_ptr(),
+                                      sc.data_ptr(), rows, F, _stream()), "swiglu_bwd_q")
+    return (gate_up if want_bf16 else None), dgu8, sc
+
+
 def swiglu_bwd(dact, gate_up, F, out=None):
     rows = gate_up.shape[0]
     dgu = torch.empty_like(gate_up) if out is None else out

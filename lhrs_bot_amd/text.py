@@ -224,7 +224,7 @@ class TextModal:
         """(e4m3 weight, per-row scales) of L[name] when the base weights are 8-bit (quantize_base), else None."""
         return (L[name + "8"], L[name + "8s"]) if self.base8 else None
 
-    def _lin(self, li, gname, x, W, residual=None, save=None, q8=None):
+    def _lin(self, li, gname, x, W, residual=None, save=None, q8=None, xq=None):
         """y = x W^T (+ s (x A^T) B^T when the group carries adapters) (+ residual).  q8 = (W8, scales): the frozen base product runs
         on the e4m3 MFMA path (x quantised per row on the fly), the adapter update stays bf16 and rides on the same accumulators (lhrs_gemm_fp8_nt_lora)."""
         lo = self.lora
@@ -234,7 +234,7 @@ class TextModal:
             if save is not None:
                 save["T_" + gname] = T
         if q8 is not None:
-            x8, sx = hk.quant_fp8_rows(x)
+            x8, sx = xq if xq is not None else hk.quant_fp8_rows(x)  # xq: the producer already emitted the e4m3 operand
             if has_lora:
                 return hk.gemm_fp8_nt(x8, sx, q8[0], q8[1], residual=residual, a2=T, b2=lo.derived[(li, gname, "Bfull")])
             return hk.gemm_fp8_nt(x8, sx, q8[0], q8[1], residual=residual)
@@ -245,21 +245,24 @@ class TextModal:
     def _gu_fwd(self, li, h, W, save, q8=None):
         """gate|up projection with the SwiGLU in the GEMM epilogue (one launch): -> (gu [M, 2ff], act [M, ff])."""
         lo = self.lora
-        if self.base8:
+        if self.base8:  # SwiGLU emits the e4m3 operand of the down projection; bf16 act only if an adapter on `down` needs it
             gu = self._lin(li, "gu", h, W, save=save, q8=q8)
-            return gu, hk.swiglu_fwd(gu, self.ff)
+            act, act8, sact = hk.swiglu_fwd_q(gu, self.ff, want_bf16=lo is not None and "down" in lo.groups)
+            return gu, act, (act8, sact)
         if lo is None or "gu" not in lo.groups:
-            return hk.gemm_swiglu_fwd(h, W, self.ff)
+            return hk.gemm_swiglu_fwd(h, W, self.ff) + (None,)
         T = hk.gemm_nt(h, lo.view(lo.shadow, li, "gu", "A"), alpha=lo.s)
         if save is not None:
             save["T_gu"] = T
-        return hk.gemm_swiglu_fwd(h, W, self.ff, T, lo.derived[(li, "gu", "Bfull")])
+        return hk.gemm_swiglu_fwd(h, W, self.ff, T, lo.derived[(li, "gu", "Bfull")]) + (None,)
 
     def _down_bwd(self, li, dy, WT, gu, act, T, q8=None):
         """dgu (written over gu) = swiglu'(gu) * d_act with d_act = dy W_down (+ LoRA) never leaving the GEMM epilogue."""
         lo = self.lora
-        if q8 is not None:
-            return hk.swiglu_bwd(self._lin_bwd(li, "down", dy, WT, act, T, q8=q8), gu, self.ff, out=gu)
+        if q8 is not None:  # -> (d(gate|up) bf16 over gu or None, its e4m3 operand for the gate|up dX product)
+            dact = self._lin_bwd(li, "down", dy, WT, act, T, q8=q8)
+            dgu, dgu8, sdgu = hk.swiglu_bwd_q(dact, gu, self.ff, want_bf16=lo is not None and "gu" in lo.groups)
+            return dgu, (dgu8, sdgu)
         if lo is None or "down" not in lo.groups:
             return hk.gemm_swiglu_bwd(dy, WT, gu, self.ff)
         G = lo.groups["down"]
@@ -270,13 +273,13 @@ class TextModal:
         hk.blockdiag_mask(dBD, lo.r, G["fout"], G["mask"])
         return dgu
 
-    def _lin_bwd(self, li, gname, dy, WT, x, T, q8=None):
+    def _lin_bwd(self, li, gname, dy, WT, x, T, q8=None, dyq=None):
         """dx = dy W (+ s (dy B) A); adapter gradients dA = (s dy B)^T x, dB^T = (s x A^T)^T dy written into lora.grad.
         q8 = (WT8, scales): e4m3 copy of the transposed base weight (per in-feature scales), dy quantised per row on the fly."""
         lo = self.lora
         has_lora = lo is not None and gname in lo.groups
         if q8 is not None:
-            dy8, sdy = hk.quant_fp8_rows(dy)
+            dy8, sdy = dyq if dyq is not None else hk.quant_fp8_rows(dy)
             if not has_lora:
                 return hk.gemm_fp8_nt(dy8, sdy, q8[0], q8[1])
         elif not has_lora:
@@ -320,8 +323,8 @@ class TextModal:
         hk.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, desc, B, H, hd, S, S, LT, True, 1.0 / math.sqrt(hd))
         x_mid = self._lin(li, "o", o, L["o_w"], residual=x, save=rec, q8=self._q8(L, "o_w"))
         h = hk.rmsnorm_fwd(x_mid, L["ln2_w"], self.eps, out=h)
-        gu, act = self._gu_fwd(li, h, L["gu_w"], rec, q8=self._q8(L, "gu_w"))
-        x_out = self._lin(li, "down", act, L["down_w"], residual=x_mid, save=rec, q8=self._q8(L, "down_w"))
+        gu, act, actq = self._gu_fwd(li, h, L["gu_w"], rec, q8=self._q8(L, "gu_w"))
+        x_out = self._lin(li, "down", act, L["down_w"], residual=x_mid, save=rec, q8=self._q8(L, "down_w"), xq=actq)
         if save is not None:
             rec.update(x_in=x, qkv=qkv, o=o, lse=lse, x_mid=x_mid, gu=gu)
             save.append(rec)
@@ -621,8 +624,11 @@ class TextModal:
             gu, qkv = s["gu"], s["qkv"]
             act = hk.swiglu_fwd(gu, ff) if lo is not None and "down" in lo.groups else None      # x of the down projection
             dgu = self._down_bwd(li, dx, L["down_wT"], gu, act, s.get("T_down"), q8=self._q8(L, "down_wT"))
+            dguq = None
+            if self.base8:
+                dgu, dguq = dgu
             h2 = hk.rmsnorm_fwd(s["x_mid"], L["ln2_w"], self.eps) if lo is not None and "gu" in lo.groups else None
-            dh = self._lin_bwd(li, "gu", dgu, L["gu_wT"], h2, s.get("T_gu"), q8=self._q8(L, "gu_wT"))
+            dh = self._lin_bwd(li, "gu", dgu, L["gu_wT"], h2, s.get("T_gu"), q8=self._q8(L, "gu_wT"), dyq=dguq)
             dx_mid = hk.rmsnorm_bwd(dh, s["x_mid"], L["ln2_w"], None, add=dx, eps=self.eps, out=dh)
             do = self._lin_bwd(li, "o", dx_mid, L["o_wT"], s["o"], s.get("T_o"), q8=self._q8(L, "o_wT"))
             hk.attn_delta(s["o"], do, delta, desc, B, H, hd, S, LT)

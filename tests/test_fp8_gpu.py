@@ -72,3 +72,22 @@ def test_lora_step_on_e4m3_base_tracks_the_bf16_base():
     cos = torch.nn.functional.cosine_similarity(g8.flatten().double(), g16.flatten().double(), dim=0).item()
     assert cos > 0.97, cos
     assert 0.8 < (g8.norm() / g16.norm()).item() < 1.25
+
+
+def test_swiglu_with_fused_quantisation_equals_swiglu_then_quant():
+    g = torch.Generator().manual_seed(4)
+    for rows, F in ((300, 11008), (64, 512)):
+        gu = torch.randn(rows, 2 * F, generator=g).to(DEV, torch.bfloat16)
+        dact = (torch.randn(rows, F, generator=g) * 0.1).to(DEV, torch.bfloat16)
+        act_ref = hk.swiglu_fwd(gu, F)
+        a8_ref, sa_ref = hk.quant_fp8_rows(act_ref)
+        act, a8, sa = hk.swiglu_fwd_q(gu, F, want_bf16=True)
+        assert torch.equal(act, act_ref) and torch.equal(a8, a8_ref) and torch.equal(sa, sa_ref)
+        assert hk.swiglu_fwd_q(gu, F)[0] is None
+        dgu_ref = hk.swiglu_bwd(dact, gu, F)
+        d8_ref, sd_ref = hk.quant_fp8_rows(dgu_ref)
+        gu2 = gu.clone()
+        _, d8, sd = hk.swiglu_bwd_q(dact, gu2, F)
+        assert torch.equal(gu2, gu) and torch.equal(d8, d8_ref) and torch.equal(sd, sd_ref)
+        dgu, d8, sd = hk.swiglu_bwd_q(dact, gu2, F, want_bf16=True)      # in place over gu
+        assert dgu.data_ptr() == gu2.data_ptr() and torch.equal(dgu, dgu_ref) and torch.equal(d8, d8_ref)
