@@ -62,6 +62,11 @@ int lhrs_gemm_fp8_nt_lora(const void* A8, long lda, const float* sa, const void*
  * written only when the pointer is non-NULL (an adapter needs it).  act8 [rows, F] / dgu8 [rows, 2F] bytes, scale [rows] fp32. */
 int lhrs_swiglu_fwd_q(const void* gate_up, void* act, void* act8, float* scale, long rows, int F, void* stream);
 int lhrs_swiglu_bwd_q(const void* dact, const void* gate_up, void* dgu, void* dgu8, float* scale, long rows, int F, void* stream);
+/* skinny-N product C[M, N <= 384] = alpha * A[M, K] . B[N, K]^T - the LoRA down-projections s * x.A^T and s * dy.B of peft lora.Linear
+ * (text_modal.py:133-151) - with K split across blocks; workspace: lhrs_gemm_skinny_splits(K) * M * N floats, caller-owned. */
+int lhrs_gemm_skinny_splits(int K);
+int lhrs_gemm_bf16_nt_skinny(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, float alpha,
+                             float* workspace, void* stream);
 /* LLaMA MLP with SwiGLU fused into the GEMM epilogues (HF LlamaMLP.forward: down(silu(gate(x)) * up(x)); text_modal.py:258-294).
  * fwd: gu[M, 2*ff] = X.Wgu^T (+ A2.B2^T), act[M, ff] = silu(gate) * up.  bwd: dgu[M, 2*ff] = swiglu'(gu) * (dY.WdT^T (+ A2.B2^T)),
  * dgu may alias gu; dact_scratch [M, ff] is only touched by the unfused fallback (may be NULL when lhrs_gemm_swiglu_fusable() == 1).

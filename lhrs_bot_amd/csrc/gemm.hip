@@ -52,6 +52,8 @@ struct GemmArgs {
   // e4m3 operands (gemm_fp8_256_kernel): per-row dequantisation scales of A (length M) and B (length N)
   const float* sa;
   const float* sb;
+  // split-K of the small-tile kernel (skinny-N products): block (x, y) reduces K-slice y of length ksplit into f32 slab y of C
+  int ksplit;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -118,6 +120,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 
   int tm, tn;
   tile_coords(g, tm, tn);
+  if (g.ksplit > 0) {  // this block's K-slice and its private f32 output slab
+    const int sp = blockIdx.y;
+    g.A += (long)sp * g.ksplit; g.B += (long)sp * g.ksplit;
+    g.C = reinterpret_cast<float*>(g.C) + (long)sp * g.M * g.ldc;
+    g.K = min(g.ksplit, g.K - sp * g.ksplit);
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1232,6 +1240,21 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256_kernel(GemmArgs g) {
   }
 }
 
+// sum of `splits` f32 slabs [M, ldc] -> bf16 C[M, N] * alpha
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, bf16_t* __restrict__ C, long ldc, int M, int N, int splits, float alpha) {
+  const long total = (long)M * (N / 4);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / (N / 4);
+    const int n = (int)(i % (N / 4)) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < splits; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(part + ((long)k * M + m) * N + n);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<uint2*>(C + m * ldc + n) = make_uint2(pack2bf(s.x * alpha, s.y * alpha), pack2bf(s.z * alpha, s.w * alpha));
+  }
+}
+
 }  // namespace
 
 // ---- optional live timing of the GEMM launches (bench.py roofline leg) -----------------------------------
@@ -1318,7 +1341,7 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   LHRS_REQUIRE(!accumulate || out_f32, "gemm: accumulate needs f32 output");
   LHRS_REQUIRE(act >= 0 && act <= 3, "gemm: unknown activation %d", act);
   GemmArgs g;
-  g.epi = 0; g.ff = 0; g.aux = nullptr; g.aux_out = nullptr; g.ld_aux = 0; g.sa = nullptr; g.sb = nullptr;
+  g.epi = 0; g.ff = 0; g.aux = nullptr; g.aux_out = nullptr; g.ld_aux = 0; g.sa = nullptr; g.sb = nullptr; g.ksplit = 0;
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C;
   g.bias = (const bf16_t*)bias; g.res = (const bf16_t*)residual;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
@@ -1501,4 +1524,36 @@ extern "C" int lhrs_gemm_fp8_nt_lora(const void* A8, long lda, const float* sa, 
                                      const void* residual, int ldr, float alpha, void* stream) {
   LHRS_REQUIRE(K2 > 0, "gemm_fp8_lora: K2=%d", K2);
   return gemm_fp8_launch(A8, lda, sa, B8, ldb, sb, A2, lda2, B2, ldb2, K2, C, ldc, M, N, K, residual, ldr, alpha, stream);
+}
+
+
+// Skinny-N product C[M, N] (bf16) = alpha * A[M, K] . B[N, K]^T for N <= 384 (the LoRA down-projections x.A^T / dy.B, peft lora.Linear):
+// HBM-bound on A, but one 64-row block walking all of K with a two-stage pipeline is latency-bound (74 us at M = 8190, K = 4096);
+// here K is split `lhrs_gemm_skinny_splits(K)` ways across blockIdx.y into f32 slabs of the workspace, then summed (~15 us).
+// workspace: lhrs_gemm_skinny_splits(K) * M * N floats.
+extern "C" int lhrs_gemm_skinny_splits(int K) {
+  int s = K / 512;
+  return s < 1 ? 1 : (s > 16 ? 16 : s);
+}
+
+extern "C" int lhrs_gemm_bf16_nt_skinny(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, float alpha,
+                                        float* workspace, void* stream) {
+  LHRS_REQUIRE(M > 0 && N > 0 && N <= 384 && N % 64 == 0 && K % 64 == 0 && workspace != nullptr, "gemm_skinny: M=%d N=%d K=%d", M, N, K);
+  LHRS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K && ldc >= N && ldc % 4 == 0, "gemm_skinny: lda=%d ldb=%d ldc=%d", lda, ldb, ldc);
+  const int splits = lhrs_gemm_skinny_splits(K);
+  int ks = cdiv(K / 64, splits) * 64;
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = workspace; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = N;
+  g.alpha = 1.f; g.out_f32 = 1; g.ksplit = ks;
+  g.tilesM = cdiv(M, 64); g.tilesN = cdiv(N, 64);
+  const int used = cdiv(K, ks);
+  hipStream_t s = (hipStream_t)stream;
+  if (g_prof.on) { g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * K; }
+  hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 0>), dim3(g.tilesM * g.tilesN, used), dim3(256), 0, s, g);
+  LHRS_CHECK_LAUNCH("gemm_skinny");
+  const long work = (long)M * (N / 4);
+  int rg = (int)((work + 255) / 256); if (rg > 8192) rg = 8192;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, s, workspace, (bf16_t*)C, (long)ldc, M, N, used, alpha);
+  LHRS_CHECK_LAUNCH("gemm_skinny_reduce");
+  return 0;
 }

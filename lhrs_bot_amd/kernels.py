@@ -117,6 +117,20 @@ def gemm_fp8_nt(a8, sa, b8, sb, out=None, *, residual=None, alpha=1.0, a2=None, 
     return out
 
 
+def gemm_nt_skinny(a, b, alpha=1.0):
+    """out[M, N] bf16 = alpha * a[M, K] @ b[N, K]^T for a skinny N (64..384): split-K launch + reduction (LoRA down-projections)."""
+    M, K = a.shape
+    N = b.shape[0]
+    if N > 128 or N % 64 or M < 1024 or K < 1024:  # wider adapters: the f32 slabs cost more than the latency they hide (measured)
+        return gemm_nt(a, b, alpha=alpha)
+    out = torch.empty((M, N), device=a.device, dtype=torch.bfloat16)
+    ws = torch.empty(_L().lhrs_gemm_skinny_splits(K) * M * N, device=a.device, dtype=torch.float32)
+    st = _L().lhrs_gemm_bf16_nt_skinny(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N, K,
+                                       float(alpha), ws.data_ptr(), _stream())
+    _lib.check(st, "gemm_bf16_nt_skinny")
+    return out
+
+
 def gemm_tn_skinny(p, q, out, accumulate=False):
     """out[KP, N] (+)= p[M, KP]^T @ q[M, N]  (fp32 out; p, q token-major bf16, row strides free)."""
     M, KP = p.shape

@@ -230,7 +230,7 @@ class TextModal:
         lo = self.lora
         has_lora = lo is not None and gname in lo.groups
         if has_lora:
-            T = hk.gemm_nt(x, lo.view(lo.shadow, li, gname, "A"), alpha=lo.s)          # [M, KP] = s * x A^T
+            T = hk.gemm_nt_skinny(x, lo.view(lo.shadow, li, gname, "A"), alpha=lo.s)          # [M, KP] = s * x A^T
             if save is not None:
                 save["T_" + gname] = T
         if q8 is not None:
@@ -251,7 +251,7 @@ class TextModal:
             return gu, act, (act8, sact)
         if lo is None or "gu" not in lo.groups:
             return hk.gemm_swiglu_fwd(h, W, self.ff) + (None,)
-        T = hk.gemm_nt(h, lo.view(lo.shadow, li, "gu", "A"), alpha=lo.s)
+        T = hk.gemm_nt_skinny(h, lo.view(lo.shadow, li, "gu", "A"), alpha=lo.s)
         if save is not None:
             save["T_gu"] = T
         return hk.gemm_swiglu_fwd(h, W, self.ff, T, lo.derived[(li, "gu", "Bfull")]) + (None,)
@@ -266,7 +266,7 @@ class TextModal:
         if lo is None or "down" not in lo.groups:
             return hk.gemm_swiglu_bwd(dy, WT, gu, self.ff)
         G = lo.groups["down"]
-        U = hk.gemm_nt(dy, lo.view(lo.shadow, li, "down", "BD"), alpha=lo.s)
+        U = hk.gemm_nt_skinny(dy, lo.view(lo.shadow, li, "down", "BD"), alpha=lo.s)
         dgu = hk.gemm_swiglu_bwd(dy, WT, gu, self.ff, U, lo.derived[(li, "down", "AT")])
         hk.gemm_tn_skinny(U, act, lo.view(lo.grad, li, "down", "A"))
         dBD = hk.gemm_tn_skinny(T, dy, lo.view(lo.grad, li, "down", "BD"))
@@ -285,7 +285,7 @@ class TextModal:
         elif not has_lora:
             return hk.gemm_nt(dy, WT)
         G = lo.groups[gname]
-        U = hk.gemm_nt(dy, lo.view(lo.shadow, li, gname, "BD"), alpha=lo.s)         # [M, KP] = s * dy B
+        U = hk.gemm_nt_skinny(dy, lo.view(lo.shadow, li, gname, "BD"), alpha=lo.s)         # [M, KP] = s * dy B
         if q8 is not None:
             dx = hk.gemm_fp8_nt(dy8, sdy, q8[0], q8[1], a2=U, b2=lo.derived[(li, gname, "AT")])
         else:

@@ -423,3 +423,13 @@ def test_gemm_fused_swiglu_bit_identical_to_unfused(M, lora):
     dgu_ref = hk.swiglu_bwd(dact_ref, gu_ref, ff)
     dgu = hk.gemm_swiglu_bwd(dy, wdT, gu, ff, a2b, b2b)          # in place over gu
     assert dgu.data_ptr() == gu.data_ptr() and torch.equal(dgu, dgu_ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(8190, 64, 4096), (4095, 128, 11008), (8190, 384, 4096), (2000, 64, 22016), (300, 64, 4096)])
+def test_gemm_nt_skinny_split_k(M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
+    b = (torch.randn(N, K, generator=g) * 0.05).to(DEV, torch.bfloat16)
+    y = hk.gemm_nt_skinny(a, b, alpha=2.0)
+    ref = 2.0 * (a.float() @ b.float().t())
+    assert y.shape == (M, N) and rel_err(y, ref) < 4e-3
