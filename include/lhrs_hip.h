@@ -63,8 +63,8 @@ int lhrs_gemm_fp8_nt_lora(const void* A8, long lda, const float* sa, const void*
 int lhrs_swiglu_fwd_q(const void* gate_up, void* act, void* act8, float* scale, long rows, int F, void* stream);
 int lhrs_swiglu_bwd_q(const void* dact, const void* gate_up, void* dgu, void* dgu8, float* scale, long rows, int F, void* stream);
 /* skinny-N product C[M, N <= 384] = alpha * A[M, K] . B[N, K]^T - the LoRA down-projections s * x.A^T and s * dy.B of peft lora.Linear
- * (text_modal.py:133-151) - with K split across blocks; workspace: lhrs_gemm_skinny_splits(K) * M * N floats, caller-owned. */
-int lhrs_gemm_skinny_splits(int K);
+ * (text_modal.py:133-151) - with K split across blocks; workspace: lhrs_gemm_skinny_splits(K, N) * M * N floats, caller-owned. */
+int lhrs_gemm_skinny_splits(int K, int N);
 int lhrs_gemm_bf16_nt_skinny(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, float alpha,
                              float* workspace, void* stream);
 /* LLaMA MLP with SwiGLU fused into the GEMM epilogues (HF LlamaMLP.forward: down(silu(gate(x)) * up(x)); text_modal.py:258-294).
@@ -141,6 +141,8 @@ int lhrs_colsum(const void* x, long ld, float* out, float* partial, int rows, in
 int lhrs_cast_f32_to_bf16(const float* in, void* out, long n, void* stream);
 int lhrs_cast_bf16_to_f32(const void* in, float* out, long n, void* stream);
 int lhrs_transpose(const void* in, long ld_in, void* out, long ld_out, int rows, int cols, int rows_pad, void* stream);
+/* n transposes in one launch; desc = device int64 [n][7] {src, dst, ld_in, ld_out, rows, cols, first_tile} (64x64 tiles, first_tile ascending) */
+int lhrs_transpose_batched(const long* desc, int n, int total_tiles, void* stream);
 
 /* ---- AttnPooler layout (lhrs/models/common_arch.py:134-173: query expand, split, cat(sub_token, sub_image)) ---- */
 int lhrs_pooler_build(const void* query, const void* img, void* t, void* kv, int B, int nq0, int nq1, int nq2, int ni0,

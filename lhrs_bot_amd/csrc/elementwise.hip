@@ -184,6 +184,31 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
   }
 }
 
+// many small transposes in ONE launch (the LoRA operand refresh after an optimizer step: 8 per layer): desc[i] = {src, dst, ld_in, ld_out,
+// rows, cols, first_tile}; a block finds its matrix by a linear scan of first_tile (n is a few hundred)
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const long* __restrict__ desc, int n) {
+  __shared__ bf16_t tile[64][66];
+  const int t = blockIdx.x;
+  int i = 0;
+  while (i + 1 < n && desc[(i + 1) * 7 + 6] <= t) ++i;
+  const bf16_t* in = reinterpret_cast<const bf16_t*>(desc[i * 7]);
+  bf16_t* out = reinterpret_cast<bf16_t*>(desc[i * 7 + 1]);
+  const long ld_in = desc[i * 7 + 2], ld_out = desc[i * 7 + 3];
+  const int rows = (int)desc[i * 7 + 4], cols = (int)desc[i * 7 + 5];
+  const int lt = t - (int)desc[i * 7 + 6], tr = (rows + 63) / 64;
+  const int r0 = (lt % tr) * 64, c0 = (lt / tr) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int rr = r0 + r, c = c0 + tx;
+    tile[r][tx] = (rr < rows && c < cols) ? in[(long)rr * ld_in + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int c = c0 + r, rr = r0 + tx;
+    if (c < cols && rr < rows) out[(long)c * ld_out + rr] = tile[tx][r];
+  }
+}
+
 inline int grid_for(long work, int block = 256) {
   long g = (work + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -288,5 +313,13 @@ extern "C" int lhrs_transpose(const void* in, long ld_in, void* out, long ld_out
   hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(rows_pad, 64), cdiv(cols, 64)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, rows, cols, rows_pad);
   LHRS_CHECK_LAUNCH("transpose");
+  return 0;
+}
+
+// desc: device int64 [n][7] = {src, dst, ld_in, ld_out, rows, cols, first_tile}, first_tile ascending; total_tiles = sum of ceil(rows/64)*ceil(cols/64)
+extern "C" int lhrs_transpose_batched(const long* desc, int n, int total_tiles, void* stream) {
+  LHRS_REQUIRE(desc != nullptr && n > 0 && total_tiles > 0, "transpose_batched: n=%d tiles=%d", n, total_tiles);
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, desc, n);
+  LHRS_CHECK_LAUNCH("transpose_batched");
   return 0;
 }

@@ -1529,18 +1529,19 @@ extern "C" int lhrs_gemm_fp8_nt_lora(const void* A8, long lda, const float* sa, 
 
 // Skinny-N product C[M, N] (bf16) = alpha * A[M, K] . B[N, K]^T for N <= 384 (the LoRA down-projections x.A^T / dy.B, peft lora.Linear):
 // HBM-bound on A, but one 64-row block walking all of K with a two-stage pipeline is latency-bound (74 us at M = 8190, K = 4096);
-// here K is split `lhrs_gemm_skinny_splits(K)` ways across blockIdx.y into f32 slabs of the workspace, then summed (~15 us).
-// workspace: lhrs_gemm_skinny_splits(K) * M * N floats.
-extern "C" int lhrs_gemm_skinny_splits(int K) {
+// here K is split `lhrs_gemm_skinny_splits(K, N)` ways across blockIdx.y into f32 slabs of the workspace, then summed (~15 us).
+// workspace: lhrs_gemm_skinny_splits(K, N) * M * N floats.
+extern "C" int lhrs_gemm_skinny_splits(int K, int N) {
   int s = K / 512;
-  return s < 1 ? 1 : (s > 16 ? 16 : s);
+  const int cap = N <= 128 ? 16 : 4;  // wide adapters: the f32 slabs (splits * M * N * 4 B) soon cost more than the latency they hide
+  return s < 1 ? 1 : (s > cap ? cap : s);
 }
 
 extern "C" int lhrs_gemm_bf16_nt_skinny(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, float alpha,
                                         float* workspace, void* stream) {
   LHRS_REQUIRE(M > 0 && N > 0 && N <= 384 && N % 64 == 0 && K % 64 == 0 && workspace != nullptr, "gemm_skinny: M=%d N=%d K=%d", M, N, K);
   LHRS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K && ldc >= N && ldc % 4 == 0, "gemm_skinny: lda=%d ldb=%d ldc=%d", lda, ldb, ldc);
-  const int splits = lhrs_gemm_skinny_splits(K);
+  const int splits = lhrs_gemm_skinny_splits(K, N);
   int ks = cdiv(K / 64, splits) * 64;
   GemmArgs g; memset(&g, 0, sizeof(g));
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = workspace; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = N;

@@ -121,14 +121,32 @@ def gemm_nt_skinny(a, b, alpha=1.0):
     """out[M, N] bf16 = alpha * a[M, K] @ b[N, K]^T for a skinny N (64..384): split-K launch + reduction (LoRA down-projections)."""
     M, K = a.shape
     N = b.shape[0]
-    if N > 128 or N % 64 or M < 1024 or K < 1024:  # wider adapters: the f32 slabs cost more than the latency they hide (measured)
+    if N > 384 or N % 64 or M < 1024 or K < 1024:
         return gemm_nt(a, b, alpha=alpha)
     out = torch.empty((M, N), device=a.device, dtype=torch.bfloat16)
-    ws = torch.empty(_L().lhrs_gemm_skinny_splits(K) * M * N, device=a.device, dtype=torch.float32)
+    ws = torch.empty(_L().lhrs_gemm_skinny_splits(K, N) * M * N, device=a.device, dtype=torch.float32)
     st = _L().lhrs_gemm_bf16_nt_skinny(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N, K,
                                        float(alpha), ws.data_ptr(), _stream())
     _lib.check(st, "gemm_bf16_nt_skinny")
     return out
+
+
+class BatchedTranspose:
+    """out_i = in_i^T for a fixed list of (in, out) bf16 matrix pairs, refreshed by ONE launch (lhrs_transpose_batched)."""
+
+    def __init__(self, pairs):
+        rows, tiles = [], 0
+        for src, dst in pairs:
+            r, c = src.shape
+            assert dst.shape == (c, r) and src.stride(1) == 1 and dst.stride(1) == 1
+            rows.append([src.data_ptr(), dst.data_ptr(), src.stride(0), dst.stride(0), r, c, tiles])
+            tiles += ((r + 63) // 64) * ((c + 63) // 64)
+        self.keep = pairs
+        self.n, self.tiles = len(rows), tiles
+        self.desc = torch.tensor(rows, dtype=torch.int64).to(pairs[0][0].device)
+
+    def run(self):
+        _lib.check(_L().lhrs_transpose_batched(self.desc.data_ptr(), self.n, self.tiles, _stream()), "transpose_batched")
 
 
 def gemm_tn_skinny(p, q, out, accumulate=False):

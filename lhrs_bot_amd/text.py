@@ -93,13 +93,19 @@ class LoraStore:
         return n * self.nl
 
     def refresh(self):
-        """bf16 shadow + transposed operands after a load / optimizer step."""
+        """bf16 shadow + transposed operands after a load / optimizer step (all 8 transposes of every layer in one launch)."""
         hk.cast_f32_to_bf16(self.master, self.shadow)
-        for l in range(self.nl):
-            for gname in self.groups:
-                self.derived[(l, gname, "AT")] = hk.transpose(self.view(self.shadow, l, gname, "A"), out=self.derived.get((l, gname, "AT")))
-                self.derived[(l, gname, "Bfull")] = hk.transpose(self.view(self.shadow, l, gname, "BD"),
-                                                                 out=self.derived.get((l, gname, "Bfull")))
+        if getattr(self, "_bt", None) is None:
+            pairs = []
+            for l in range(self.nl):
+                for gname in self.groups:
+                    for kind, dk in (("A", "AT"), ("BD", "Bfull")):
+                        src = self.view(self.shadow, l, gname, kind)
+                        dst = torch.empty((src.shape[1], src.shape[0]), device=src.device, dtype=torch.bfloat16)
+                        self.derived[(l, gname, dk)] = dst
+                        pairs.append((src, dst))
+            self._bt = hk.BatchedTranspose(pairs)
+        self._bt.run()
 
     # peft-layout accessors (A_p [r, in], B_p [out, r]) for tests / checkpoints
     def get_adapter(self, l, proj):
