@@ -17,15 +17,22 @@ namespace {
 
 __device__ __forceinline__ int sub_off(int row, int c) { return row * 128 + ((c ^ (row & 7)) << 4); }  // [64][64] bf16, swizzled
 
-// global [rows m0.., 64 cols c0..] -> LDS sub-tile; rows >= m_end are ZERO (they are summed over)
-__device__ __forceinline__ void load_sub(char* lds, const bf16_t* base, long ld, int m0, int m_end, int c0, int tid) {
+// global [rows m0.., 64 cols c0..] -> registers (two 16-B chunks per thread) -> LDS sub-tile; rows >= m_end are ZERO (they are summed over)
+struct SubRegs { uint4 v[2]; };
+__device__ __forceinline__ void fetch_sub(SubRegs& rg, const bf16_t* base, long ld, int m0, int m_end, int c0, int tid) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int idx = tid + i * 256;
     const int r = idx >> 3, c = idx & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (m0 + r < m_end) v = *reinterpret_cast<const uint4*>(base + (long)(m0 + r) * ld + c0 + c * 8);
-    *reinterpret_cast<uint4*>(lds + sub_off(r, c)) = v;
+    rg.v[i] = make_uint4(0, 0, 0, 0);
+    if (m0 + r < m_end) rg.v[i] = *reinterpret_cast<const uint4*>(base + (long)(m0 + r) * ld + c0 + c * 8);
+  }
+}
+__device__ __forceinline__ void store_sub(char* lds, const SubRegs& rg, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + i * 256;
+    *reinterpret_cast<uint4*>(lds + sub_off(idx >> 3, idx & 7)) = rg.v[i];
   }
 }
 
@@ -53,12 +60,24 @@ __global__ __launch_bounds__(256) void tn_skinny_kernel(const bf16_t* __restrict
 #pragma unroll
   for (int i = 0; i < IB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const unsigned qb = tr_base(lds_q, lane, wave);  // this wave's 16 output columns
-  for (int t = t0; t < t1; ++t) {
-    __syncthreads();
-    load_sub(lds_q, Q, ldq, t * 64, M, n0, tid);
+  // software pipeline: the global loads of token tile t + 1 are in flight (registers) while tile t is multiplied out of LDS
+  SubRegs rq, rp[NSUB];
+  if (t0 < t1) {
+    fetch_sub(rq, Q, ldq, t0 * 64, M, n0, tid);
 #pragma unroll
-    for (int sI = 0; sI < NSUB; ++sI) load_sub(lds_p + sI * 8192, P, ldp, t * 64, M, sI * 64, tid);
+    for (int sI = 0; sI < NSUB; ++sI) fetch_sub(rp[sI], P, ldp, t0 * 64, M, sI * 64, tid);
+  }
+  for (int t = t0; t < t1; ++t) {
+    __syncthreads();  // every wave is done reading tile t - 1
+    store_sub(lds_q, rq, tid);
+#pragma unroll
+    for (int sI = 0; sI < NSUB; ++sI) store_sub(lds_p + sI * 8192, rp[sI], tid);
     __syncthreads();
+    if (t + 1 < t1) {
+      fetch_sub(rq, Q, ldq, (t + 1) * 64, M, n0, tid);
+#pragma unroll
+      for (int sI = 0; sI < NSUB; ++sI) fetch_sub(rp[sI], P, ldp, (t + 1) * 64, M, sI * 64, tid);
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x4 qlo, qhi;
