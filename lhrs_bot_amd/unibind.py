@@ -33,6 +33,7 @@ class UniBind:
         assert len(activate_modal) > 0, "activate_modal should not be empty"
         self.modal = tuple(activate_modal)
         self.stage = _get(config, "stage", 1)
+        self.bits = int(_get(config, "bits", 16))  # Config/multi_modal_stage{2,3}.yaml: 8 -> 8-bit frozen base (text_modal.py:91-131)
         self.device = torch.device(device)
         if "rgb" in self.modal:
             self.rgb = VisionModal(config, device, layers=vit_layers)
@@ -62,6 +63,8 @@ class UniBind:
         self.train()
         if model_path is not None:
             self.custom_load_state_dict(model_path)
+        if self.bits == 8 and not self.text.base8 and self.text.p.get("layers"):
+            self.text.quantize_base(8)  # the YAML's `bits: 8`: e4m3 copies of the (now loaded) frozen decoder linears
 
     def train(self):
         self.training = True
