@@ -58,6 +58,12 @@ int lhrs_gemm_fp8_nt(const void* A8, long lda, const float* sa, const void* B8, 
 int lhrs_gemm_fp8_nt_lora(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, const void* A2,
                           int lda2, const void* B2, int ldb2, int K2, void* C, int ldc, int M, int N, int K,
                           const void* residual, int ldr, float alpha, void* stream);
+/* lhrs_rmsnorm_fwd / lhrs_rmsnorm_bwd that also emit the per-row e4m3 copy of their result (bytes [rows, cols] + fp32 scale [rows]),
+ * bit-identical to lhrs_quant_fp8_rows of the bf16 result; y may be NULL in the forward */
+int lhrs_rmsnorm_fwd_q(const void* x, long ldx, const void* w, void* y, long ldy, void* y8, float* y8scale, int rows,
+                       int cols, float eps, void* stream);
+int lhrs_rmsnorm_bwd_q(const void* dy, const void* x, const void* w, const float* rstd, const void* add, void* dx,
+                       void* dx8, float* dx8scale, int rows, int cols, float eps, void* stream);
 /* SwiGLU forward / backward (HF LlamaMLP) emitting the per-row e4m3 operand of the next 8-bit-base GEMM directly; the bf16 result is
  * written only when the pointer is non-NULL (an adapter needs it).  act8 [rows, F] / dgu8 [rows, 2F] bytes, scale [rows] fp32. */
 int lhrs_swiglu_fwd_q(const void* gate_up, void* act, void* act8, float* scale, long rows, int F, void* stream);

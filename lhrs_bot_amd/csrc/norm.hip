@@ -153,11 +153,38 @@ __global__ __launch_bounds__(256) void layernorm_bwd_finalize(const float* __res
   }
 }
 
+// per-row e4m3 copy of a row held in registers (values as they were / would be stored in bf16): scale = max|v| / 448 (SURVEY §8 f-4:
+// the operand of the next 8-bit-base GEMM, bit-identical to lhrs_quant_fp8_rows of the bf16 row)
+template <int NCH>
+__device__ __forceinline__ void store_row_e4m3(unsigned char* y8, float* scale_out, int lane, float (&v)[NCH][8]) {
+  float m = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[c][i] = bf2f(f2bf(v[c][i]));
+      m = fmaxf(m, fabsf(v[c][i]));
+    }
+  m = wave_max(m);
+  const float sc = m > 0.f ? m / 448.f : 1.f;
+  if (lane == 0) *scale_out = sc;
+  const float inv = 1.f / sc;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][0] * inv, v[c][1] * inv, 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][2] * inv, v[c][3] * inv, lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][4] * inv, v[c][5] * inv, 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][6] * inv, v[c][7] * inv, hi, true);
+    *reinterpret_cast<int2*>(y8 + (c * 64 + lane) * 8) = make_int2(lo, hi);
+  }
+}
+
 // ---------------------------------------------------------------- RMSNorm
 template <int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                           bf16_t* __restrict__ y, float* __restrict__ rstd_out, int rows,
-                                                          long ldx, long ldy, float eps) {
+                                                          long ldx, long ldy, float eps, unsigned char* __restrict__ y8 = nullptr,
+                                                          float* __restrict__ y8scale = nullptr) {
   constexpr int cols = NCH * 512;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
@@ -175,15 +202,17 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[c][i] = g[c][i] * bf2f(f2bf(v[c][i] * rstd));  // HF rounds xhat before the weight
-  store_row<NCH>(y + row * ldy, lane, v);
+  if (y) store_row<NCH>(y + row * ldy, lane, v);
   if (rstd_out && lane == 0) rstd_out[row] = rstd;
+  if (y8) store_row_e4m3<NCH>(y8 + (long)row * cols, y8scale + row, lane, v);
 }
 
 // dx = rstd * (g*dy - xhat * mean(g*dy*xhat)) [+ add]   (activation gradient only: the LLaMA weights are frozen)
 template <int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* dy, const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ w, const float* __restrict__ rstd,
-                                                          const bf16_t* add, bf16_t* dx, int rows, long ld, float eps) {
+                                                          const bf16_t* add, bf16_t* dx, int rows, long ld, float eps,
+                                                          unsigned char* __restrict__ dx8 = nullptr, float* __restrict__ dx8scale = nullptr) {
   constexpr int cols = NCH * 512;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
@@ -226,6 +255,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* dy, cons
       for (int i = 0; i < 8; ++i) dv[c][i] += av[c][i];
   }
   store_row<NCH>(dx + row * ld, lane, dv);
+  if (dx8) store_row_e4m3<NCH>(dx8 + (long)row * cols, dx8scale + row, lane, dv);
 }
 
 }  // namespace
@@ -308,5 +338,30 @@ extern "C" int lhrs_rmsnorm_bwd(const void* dy, const void* x, const void* w, co
                                         (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)add,
                                         (bf16_t*)dx, rows, (long)cols, eps));
   LHRS_CHECK_LAUNCH("rmsnorm_bwd");
+  return 0;
+}
+
+// lhrs_rmsnorm_fwd / _bwd that ALSO emit the per-row e4m3 copy of their result (y8 [rows, cols] bytes + scale [rows]) for the next
+// 8-bit-base GEMM; y may be NULL in the forward when no adapter needs the bf16 activations
+extern "C" int lhrs_rmsnorm_fwd_q(const void* x, long ldx, const void* w, void* y, long ldy, void* y8, float* y8scale, int rows,
+                                  int cols, float eps, void* stream) {
+  LHRS_REQUIRE(rows > 0 && cols % 512 == 0 && y8 && y8scale, "rmsnorm_fwd_q: rows=%d cols=%d", rows, cols);
+  LHRS_REQUIRE(ldx % 8 == 0 && (y == nullptr || ldy % 8 == 0), "rmsnorm_fwd_q: row strides must be multiples of 8");
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_NCH(cols, hipLaunchKernelGGL((rmsnorm_fwd_kernel<NCH>), dim3(cdiv(rows, LN_WAVES)), dim3(256), 0, s,
+                                        (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, (float*)nullptr, rows, ldx, ldy, eps,
+                                        (unsigned char*)y8, y8scale));
+  LHRS_CHECK_LAUNCH("rmsnorm_fwd_q");
+  return 0;
+}
+
+extern "C" int lhrs_rmsnorm_bwd_q(const void* dy, const void* x, const void* w, const float* rstd, const void* add, void* dx,
+                                  void* dx8, float* dx8scale, int rows, int cols, float eps, void* stream) {
+  LHRS_REQUIRE(rows > 0 && cols % 512 == 0 && dx && dx8 && dx8scale, "rmsnorm_bwd_q: rows=%d cols=%d", rows, cols);
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_NCH(cols, hipLaunchKernelGGL((rmsnorm_bwd_kernel<NCH>), dim3(cdiv(rows, LN_WAVES)), dim3(256), 0, s,
+                                        (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)add,
+                                        (bf16_t*)dx, rows, (long)cols, eps, (unsigned char*)dx8, dx8scale));
+  LHRS_CHECK_LAUNCH("rmsnorm_bwd_q");
   return 0;
 }

@@ -215,6 +215,31 @@ def rmsnorm_bwd(dy, x, w, rstd=None, add=None, eps=1e-5, out=None):
     return dx
 
 
+def rmsnorm_fwd_q(x, w, eps=1e-5, want_bf16=True, out=None):
+    """-> (y bf16 or None, (y8 uint8 [rows, cols], scale fp32 [rows])): RMSNorm + per-row e4m3 copy of its output in one pass."""
+    rows, cols = x.shape
+    y = (torch.empty_like(x) if out is None else out) if want_bf16 else None
+    y8 = torch.empty((rows, cols), device=x.device, dtype=torch.uint8)
+    sc = torch.empty(rows, device=x.device, dtype=torch.float32)
+    st = _L().lhrs_rmsnorm_fwd_q(x.data_ptr(), x.stride(0), w.data_ptr(), _p(y), y.stride(0) if y is not None else 0, y8.data_ptr(),
+                                 sc.data_ptr(), rows, cols, eps, _stream())
+    _lib.check(st, "rmsnorm_fwd_q")
+    return y, (y8, sc)
+
+
+def rmsnorm_bwd_q(dy, x, w, rstd=None, add=None, eps=1e-5, out=None):
+    """-> (dx bf16, (dx8, scale)): RMSNorm backward (+ residual add) + per-row e4m3 copy of dx."""
+    rows, cols = x.shape
+    assert dy.is_contiguous() and x.is_contiguous()
+    dx = torch.empty_like(x) if out is None else out
+    d8 = torch.empty((rows, cols), device=x.device, dtype=torch.uint8)
+    sc = torch.empty(rows, device=x.device, dtype=torch.float32)
+    st = _L().lhrs_rmsnorm_bwd_q(dy.data_ptr(), x.data_ptr(), w.data_ptr(), _p(rstd), _p(add), dx.data_ptr(), d8.data_ptr(), sc.data_ptr(),
+                                 rows, cols, eps, _stream())
+    _lib.check(st, "rmsnorm_bwd_q")
+    return dx, (d8, sc)
+
+
 # --------------------------------------------------------------------------------------------- attention
 def make_desc(entries, device) -> torch.Tensor:
     """entries: list of (q_off, q_len, kv_off, kv_len[, kv_rows[, causal_off]]) -> int32 [n, 8] on device."""

@@ -248,11 +248,11 @@ class TextModal:
             return hk.gemm_nt(x, W, residual=residual)
         return hk.gemm_nt_lora(x, W, T, lo.derived[(li, gname, "Bfull")], residual=residual)
 
-    def _gu_fwd(self, li, h, W, save, q8=None):
+    def _gu_fwd(self, li, h, W, save, q8=None, xq=None):
         """gate|up projection with the SwiGLU in the GEMM epilogue (one launch): -> (gu [M, 2ff], act [M, ff])."""
         lo = self.lora
         if self.base8:  # SwiGLU emits the e4m3 operand of the down projection; bf16 act only if an adapter on `down` needs it
-            gu = self._lin(li, "gu", h, W, save=save, q8=q8)
+            gu = self._lin(li, "gu", h, W, save=save, q8=q8, xq=xq)
             act, act8, sact = hk.swiglu_fwd_q(gu, self.ff, want_bf16=lo is not None and "down" in lo.groups)
             return gu, act, (act8, sact)
         if lo is None or "gu" not in lo.groups:
@@ -262,11 +262,11 @@ class TextModal:
             save["T_gu"] = T
         return hk.gemm_swiglu_fwd(h, W, self.ff, T, lo.derived[(li, "gu", "Bfull")]) + (None,)
 
-    def _down_bwd(self, li, dy, WT, gu, act, T, q8=None):
+    def _down_bwd(self, li, dy, WT, gu, act, T, q8=None, dyq=None):
         """dgu (written over gu) = swiglu'(gu) * d_act with d_act = dy W_down (+ LoRA) never leaving the GEMM epilogue."""
         lo = self.lora
         if q8 is not None:  # -> (d(gate|up) bf16 over gu or None, its e4m3 operand for the gate|up dX product)
-            dact = self._lin_bwd(li, "down", dy, WT, act, T, q8=q8)
+            dact = self._lin_bwd(li, "down", dy, WT, act, T, q8=q8, dyq=dyq)
             dgu, dgu8, sdgu = hk.swiglu_bwd_q(dact, gu, self.ff, want_bf16=lo is not None and "gu" in lo.groups)
             return dgu, (dgu8, sdgu)
         if lo is None or "down" not in lo.groups:
@@ -321,15 +321,23 @@ class TextModal:
         d, H, hd, ff = self.d, self.heads, self.hd, self.ff
         M = x.shape[0]
         rec = {} if save is not None else None
-        h = hk.rmsnorm_fwd(x, L["ln1_w"], self.eps)
-        qkv = self._lin(li, "qkv", h, L["qkv_w"], save=rec, q8=self._q8(L, "qkv_w"))
+        lo = self.lora
+        hq = None
+        if self.base8:  # RMSNorm emits the e4m3 operand of the next GEMM; the bf16 copy only if an adapter reads it
+            h, hq = hk.rmsnorm_fwd_q(x, L["ln1_w"], self.eps, want_bf16=lo is not None and "qkv" in lo.groups)
+        else:
+            h = hk.rmsnorm_fwd(x, L["ln1_w"], self.eps)
+        qkv = self._lin(li, "qkv", h, L["qkv_w"], save=rec, q8=self._q8(L, "qkv_w"), xq=hq)
         hk.rope_(qkv, M, 2 * H, hd, self.cos, self.sin, pos_mod=S)
         o = torch.empty((M, d), device=self.device, dtype=torch.bfloat16)
         lse = torch.empty((B, H, LT), device=self.device, dtype=torch.float32)
         hk.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, desc, B, H, hd, S, S, LT, True, 1.0 / math.sqrt(hd))
         x_mid = self._lin(li, "o", o, L["o_w"], residual=x, save=rec, q8=self._q8(L, "o_w"))
-        h = hk.rmsnorm_fwd(x_mid, L["ln2_w"], self.eps, out=h)
-        gu, act, actq = self._gu_fwd(li, h, L["gu_w"], rec, q8=self._q8(L, "gu_w"))
+        if self.base8:
+            h, hq = hk.rmsnorm_fwd_q(x_mid, L["ln2_w"], self.eps, want_bf16=lo is not None and "gu" in lo.groups)
+        else:
+            h = hk.rmsnorm_fwd(x_mid, L["ln2_w"], self.eps, out=h)
+        gu, act, actq = self._gu_fwd(li, h, L["gu_w"], rec, q8=self._q8(L, "gu_w"), xq=hq)
         x_out = self._lin(li, "down", act, L["down_w"], residual=x_mid, save=rec, q8=self._q8(L, "down_w"), xq=actq)
         if save is not None:
             rec.update(x_in=x, qkv=qkv, o=o, lse=lse, x_mid=x_mid, gu=gu)
@@ -620,7 +628,11 @@ class TextModal:
         dhv = hk.gemm_nt(c["dlogits"], p["lm_headT"], alpha=loss_scale)
         dhid = torch.zeros((M, d), device=self.device, dtype=torch.bfloat16)
         hk.scatter_rows(dhv, c["rows"], dhid)
-        dx = hk.rmsnorm_bwd(dhid, c["x_last"], p["norm_w"], None, eps=self.eps)
+        dxq = None
+        if self.base8:
+            dx, dxq = hk.rmsnorm_bwd_q(dhid, c["x_last"], p["norm_w"], None, eps=self.eps)
+        else:
+            dx = hk.rmsnorm_bwd(dhid, c["x_last"], p["norm_w"], None, eps=self.eps)
         scale = 1.0 / math.sqrt(hd)
         delta = torch.empty((B, H, LT), device=self.device, dtype=torch.float32)
         dqkv = torch.empty((M, 3 * d), device=self.device, dtype=torch.bfloat16)
@@ -629,21 +641,28 @@ class TextModal:
             L, s = p["layers"][li], c["layers"][li]
             gu, qkv = s["gu"], s["qkv"]
             act = hk.swiglu_fwd(gu, ff) if lo is not None and "down" in lo.groups else None      # x of the down projection
-            dgu = self._down_bwd(li, dx, L["down_wT"], gu, act, s.get("T_down"), q8=self._q8(L, "down_wT"))
+            dgu = self._down_bwd(li, dx, L["down_wT"], gu, act, s.get("T_down"), q8=self._q8(L, "down_wT"), dyq=dxq)
             dguq = None
             if self.base8:
                 dgu, dguq = dgu
             h2 = hk.rmsnorm_fwd(s["x_mid"], L["ln2_w"], self.eps) if lo is not None and "gu" in lo.groups else None
             dh = self._lin_bwd(li, "gu", dgu, L["gu_wT"], h2, s.get("T_gu"), q8=self._q8(L, "gu_wT"), dyq=dguq)
-            dx_mid = hk.rmsnorm_bwd(dh, s["x_mid"], L["ln2_w"], None, add=dx, eps=self.eps, out=dh)
-            do = self._lin_bwd(li, "o", dx_mid, L["o_wT"], s["o"], s.get("T_o"), q8=self._q8(L, "o_wT"))
+            dmq = None
+            if self.base8:
+                dx_mid, dmq = hk.rmsnorm_bwd_q(dh, s["x_mid"], L["ln2_w"], None, add=dx, eps=self.eps, out=dh)
+            else:
+                dx_mid = hk.rmsnorm_bwd(dh, s["x_mid"], L["ln2_w"], None, add=dx, eps=self.eps, out=dh)
+            do = self._lin_bwd(li, "o", dx_mid, L["o_wT"], s["o"], s.get("T_o"), q8=self._q8(L, "o_wT"), dyq=dmq)
             hk.attn_delta(s["o"], do, delta, desc, B, H, hd, S, LT)
             hk.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], do, s["lse"], delta, dqkv[:, :d], dqkv[:, d:2 * d],
                         dqkv[:, 2 * d:], desc, B, H, hd, S, S, LT, True, scale)
             hk.rope_(dqkv, M, 2 * H, hd, self.cos, self.sin, pos_mod=S, inverse=True)
             h1 = hk.rmsnorm_fwd(s["x_in"], L["ln1_w"], self.eps) if lo is not None and "qkv" in lo.groups else None
             dh1 = self._lin_bwd(li, "qkv", dqkv, L["qkv_wT"], h1, s.get("T_qkv"), q8=self._q8(L, "qkv_wT"))
-            dx = hk.rmsnorm_bwd(dh1, s["x_in"], L["ln1_w"], None, add=dx_mid, eps=self.eps, out=dh1)
+            if self.base8:
+                dx, dxq = hk.rmsnorm_bwd_q(dh1, s["x_in"], L["ln1_w"], None, add=dx_mid, eps=self.eps, out=dh1)
+            else:
+                dx = hk.rmsnorm_bwd(dh1, s["x_in"], L["ln1_w"], None, add=dx_mid, eps=self.eps, out=dh1)
             s.clear()
             if on_layer_ready is not None:
                 on_layer_ready(li)

@@ -91,3 +91,21 @@ def test_swiglu_with_fused_quantisation_equals_swiglu_then_quant():
         assert torch.equal(gu2, gu) and torch.equal(d8, d8_ref) and torch.equal(sd, sd_ref)
         dgu, d8, sd = hk.swiglu_bwd_q(dact, gu2, F, want_bf16=True)      # in place over gu
         assert dgu.data_ptr() == gu2.data_ptr() and torch.equal(dgu, dgu_ref) and torch.equal(d8, d8_ref)
+
+
+def test_rmsnorm_with_fused_quantisation_equals_rmsnorm_then_quant():
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(300, 4096, generator=g).to(DEV, torch.bfloat16)
+    dy = (torch.randn(300, 4096, generator=g) * 0.1).to(DEV, torch.bfloat16)
+    add = torch.randn(300, 4096, generator=g).to(DEV, torch.bfloat16)
+    w = (1 + 0.1 * torch.randn(4096, generator=g)).to(DEV, torch.bfloat16)
+    y_ref = hk.rmsnorm_fwd(x, w)
+    y8_ref, s_ref = hk.quant_fp8_rows(y_ref)
+    y, (y8, s) = hk.rmsnorm_fwd_q(x, w)
+    assert torch.equal(y, y_ref) and torch.equal(y8, y8_ref) and torch.equal(s, s_ref)
+    none, (y8b, sb) = hk.rmsnorm_fwd_q(x, w, want_bf16=False)
+    assert none is None and torch.equal(y8b, y8_ref) and torch.equal(sb, s_ref)
+    dx_ref = hk.rmsnorm_bwd(dy, x, w, None, add=add)
+    d8_ref, ds_ref = hk.quant_fp8_rows(dx_ref)
+    dx, (d8, ds) = hk.rmsnorm_bwd_q(dy, x, w, None, add=add)
+    assert torch.equal(dx, dx_ref) and torch.equal(d8, d8_ref) and torch.equal(ds, ds_ref)
