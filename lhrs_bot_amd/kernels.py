@@ -215,12 +215,12 @@ def rmsnorm_bwd(dy, x, w, rstd=None, add=None, eps=1e-5, out=None):
     return dx
 
 
-def rmsnorm_fwd_q(x, w, eps=1e-5, want_bf16=True, out=None):
+def rmsnorm_fwd_q(x, w, eps=1e-5, want_bf16=True, out=None, q_out=None):
     """-> (y bf16 or None, (y8 uint8 [rows, cols], scale fp32 [rows])): RMSNorm + per-row e4m3 copy of its output in one pass."""
     rows, cols = x.shape
     y = (torch.empty_like(x) if out is None else out) if want_bf16 else None
-    y8 = torch.empty((rows, cols), device=x.device, dtype=torch.uint8)
-    sc = torch.empty(rows, device=x.device, dtype=torch.float32)
+    y8, sc = q_out if q_out is not None else (torch.empty((rows, cols), device=x.device, dtype=torch.uint8),
+                                              torch.empty(rows, device=x.device, dtype=torch.float32))
     st = _L().lhrs_rmsnorm_fwd_q(x.data_ptr(), x.stride(0), w.data_ptr(), _p(y), y.stride(0) if y is not None else 0, y8.data_ptr(),
                                  sc.data_ptr(), rows, cols, eps, _stream())
     _lib.check(st, "rmsnorm_fwd_q")
@@ -326,12 +326,12 @@ def swiglu_fwd(gate_up, F, out=None):
     return act
 
 
-def swiglu_fwd_q(gate_up, F, want_bf16=False):
+def swiglu_fwd_q(gate_up, F, want_bf16=False, q_out=None):
     """-> (act bf16 or None, act8 uint8 [rows, F], scale fp32 [rows]): SwiGLU + per-row e4m3 quantisation in one pass."""
     rows = gate_up.shape[0]
     act = torch.empty((rows, F), device=gate_up.device, dtype=torch.bfloat16) if want_bf16 else None
-    act8 = torch.empty((rows, F), device=gate_up.device, dtype=torch.uint8)
-    sc = torch.empty(rows, device=gate_up.device, dtype=torch.float32)
+    act8, sc = q_out if q_out is not None else (torch.empty((rows, F), device=gate_up.device, dtype=torch.uint8),
+                                                torch.empty(rows, device=gate_up.device, dtype=torch.float32))
     _lib.check(_L().lhrs_swiglu_fwd_q(gate_up.data_ptr(), _p(act), act8.data_ptr(), sc.data_ptr(), rows, F, _stream()), "swiglu_fwd_q")
     return act, act8, sc
 
@@ -493,11 +493,32 @@ def gemv_fused(W, x, out, K, *, wscale=None, prologue=PRO_NONE, norm_w=None, eps
     return out
 
 
-def quant_fp8_rows(W):
-    """bf16 [N, K] -> (uint8 e4m3 [N, K], fp32 per-row scale [N])."""
+def gemv_fp8_mfma(W8, wscale, x8, xscale, out, *, residual=None, out_f32=False):
+    """out[B, N] = xscale[:, None] * wscale[None, :] * (x8 @ W8^T) (+ residual): e4m3 weights and activations on the scaled MFMA."""
+    B, K = x8.shape
+    N = W8.shape[0]
+    st = _L().lhrs_gemv_fp8_mfma(W8.data_ptr(), W8.stride(0), wscale.data_ptr(), x8.data_ptr(), x8.stride(0), xscale.data_ptr(),
+                                 _p(residual), residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0), B, N, K,
+                                 int(out_f32), _stream())
+    _lib.check(st, "gemv_fp8_mfma")
+    return out
+
+
+def gemv_fp8_mfma_fused(W8, wscale, x, out, K, *, prologue=PRO_NONE, norm_w=None, eps=1e-5, residual=None, out_f32=False):
+    """batch <= 2: out = (e4m3(pro(x)) @ W8^T) * scales (+ residual), prologue and activation quantisation inside the kernel."""
+    B, N = x.shape[0], W8.shape[0]
+    st = _L().lhrs_gemv_fp8_mfma_fused(W8.data_ptr(), W8.stride(0), wscale.data_ptr(), x.data_ptr(), x.stride(0), prologue, _p(norm_w),
+                                       float(eps), _p(residual), residual.stride(0) if residual is not None else 0, out.data_ptr(),
+                                       out.stride(0), B, N, K, int(out_f32), _stream())
+    _lib.check(st, "gemv_fp8_mfma_fused")
+    return out
+
+
+def quant_fp8_rows(W, out=None):
+    """bf16 [N, K] -> (uint8 e4m3 [N, K], fp32 per-row scale [N]); out = preallocated (W8, scale) for graph-captured callers."""
     N, K = W.shape
-    W8 = torch.empty((N, K), device=W.device, dtype=torch.uint8)
-    sc = torch.empty(N, device=W.device, dtype=torch.float32)
+    W8, sc = out if out is not None else (torch.empty((N, K), device=W.device, dtype=torch.uint8),
+                                          torch.empty(N, device=W.device, dtype=torch.float32))
     _lib.check(_L().lhrs_quant_fp8_rows(W.data_ptr(), W.stride(0), W8.data_ptr(), W8.stride(0), sc.data_ptr(), N, K, _stream()), "quant_fp8_rows")
     return W8, sc
 

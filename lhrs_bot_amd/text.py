@@ -461,8 +461,24 @@ class TextModal:
         if batched:
             s.hn = torch.zeros((B, d), device=dev, dtype=bf)
             s.actb = torch.zeros((B, ff), device=dev, dtype=bf)
+        if fp8:  # e4m3 weights AND activations on the block-scaled MFMA: static e4m3 operand buffers (graph capture: no allocation)
+            s.x8 = (torch.zeros((B, d), device=dev, dtype=torch.uint8), torch.zeros(B, device=dev, dtype=torch.float32))
+            s.a8 = (torch.zeros((B, ff), device=dev, dtype=torch.uint8), torch.zeros(B, device=dev, dtype=torch.float32))
 
         def lin(w, sc, x_in, out, K, pro=hk.PRO_NONE, norm_w=None, residual=None, out_f32=False):
+            if fp8 and B <= 2:  # prologue + activation quantisation inside the GEMV: five launches per layer
+                hk.gemv_fp8_mfma_fused(w, sc, x_in, out, K, prologue=pro, norm_w=norm_w, eps=self.eps, residual=residual, out_f32=out_f32)
+                return
+            if fp8:
+                if pro == hk.PRO_RMSNORM:
+                    _, q = hk.rmsnorm_fwd_q(x_in, norm_w, self.eps, want_bf16=False, q_out=s.x8)
+                elif pro == hk.PRO_SWIGLU:
+                    _, a8, sa = hk.swiglu_fwd_q(x_in, ff, q_out=s.a8)
+                    q = (a8, sa)
+                else:
+                    q = hk.quant_fp8_rows(x_in, out=s.x8)
+                hk.gemv_fp8_mfma(w, sc, q[0], q[1], out, residual=residual, out_f32=out_f32)
+                return
             if batched and pro == hk.PRO_RMSNORM:
                 hk.rmsnorm_fwd(x_in, norm_w, self.eps, out=s.hn)
                 x_in, pro, norm_w = s.hn, hk.PRO_NONE, None
