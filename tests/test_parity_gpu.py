@@ -148,3 +148,31 @@ def test_ragged_right_padded_batch_vs_oracle():
     ids2[ids == 0] = 777
     batch2 = dict(batch, input_ids=ids2)
     assert model.eval()(batch2)["total_loss"].item() == model(batch)["total_loss"].item()
+
+
+@pytest.mark.timeout(900)
+def test_unibind_eight_layers_vs_reference_golden():
+    """Depth check: 8 LLaMA-7B-width layers, reference fixture tests/golden/unibind_e2e_8l.npz (make_golden_deep.py)."""
+    z = np.load(os.path.join(G, "unibind_e2e_8l.npz"))
+    nl = int(z["n_llama_layers"])
+    P = {"vit": OP.make_vit_params(seed=2), "pooler": OP.make_pooler_params(seed=1), "llama": OP.make_llama_params(seed=3, layers=nl)}
+    model = UniBind(("rgb", "text"), None, device=DEV, llama_layers=nl).load_params(P)
+    del P
+    model.prepare_for_training()
+    ids = torch.from_numpy(z["input_ids"])
+    labels = ids.clone()
+    labels[:, :2] = -100
+    rgb = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(int(z["rgb_seed"])))
+    assert abs(rgb.double().sum().item() - float(z["rgb_checksum"])) < 1e-6
+    out = model(dict(rgb=rgb, input_ids=ids, labels=labels, attention_mask=ids.ne(0)))
+    loss = out["total_loss"].item()
+    assert abs(loss - float(z["loss"])) < 3e-3 * float(z["loss"]), (loss, float(z["loss"]))
+    d_image = model.text.backward()
+    assert rel(d_image[:, ::4, ::4], torch.from_numpy(z["d_image"])) < 6e-2
+    model.rgb_pooler.backward(d_image)
+    torch.cuda.synchronize()
+    norms = dict(zip(z["grad_names"].tolist(), z["grad_norms"].tolist()))
+    bad = [(n, model.rgb_pooler.g[n].double().norm().item(), w) for n, w in norms.items()
+           if abs(model.rgb_pooler.g[n].double().norm().item() - w) > 6e-2 * w]
+    assert not bad, bad
+    assert rel(model.rgb_pooler.g["out_proj.bias"], torch.from_numpy(z["g_out_proj_b"])) < 6e-2
