@@ -1376,7 +1376,8 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   int slot = -1;
   if (g_prof.on) {
     g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * (K + K2);
-    if ((big || use256) && g_prof.used < g_prof.cap) {
+    const bool dominant = use256 && (g_gemm_allow_256 == 2 || g_gemm_allow_256 == 5) && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128;
+    if (dominant && g_prof.used < g_prof.cap) {  // time exactly the launches rocprof lists as gemm_nt_256r_kernel<ACT, 0>
       slot = g_prof.used++;
       g_prof.flops[slot] = 2.0 * M * N * (K + K2);
       (void)hipEventRecord(g_prof.ev[2 * slot], s);
