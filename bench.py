@@ -195,7 +195,7 @@ def main():
         if a.stage == 3:
             model.enable_lora(r=8, alpha=16, targets=("q", "k", "v", "o"))
         else:
-            model.enable_lora(r=128, alpha=256)
+            model.enable_lora(r=128, alpha=256, dropout=0.05)  # Config/multi_modal_stage2.yaml:81-86 (train mode: dropout active)
         if a.bits == 8:
             model.text.quantize_base(8)
         model.prepare_for_training(freeze_text=False, tune_rgb_pooler=a.stage == 2)
@@ -255,7 +255,7 @@ def main():
                                    f"({a.llama_layers} layers), S={S}, random-init weights",
                        "micro_batch_per_gpu": B, "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
                        "optimizer": "adanp" if a.stage == 1 else "adamw", "stage": a.stage,
-                       "lora": None if a.stage == 1 else ("r=8 on q,k,v,o" if a.stage == 3 else "r=128 on all 7 linears"),
+                       "lora": None if a.stage == 1 else ("r=8 on q,k,v,o, no dropout (text.eval())" if a.stage == 3 else "r=128 on all 7 linears, lora_dropout 0.05"),
                        "grad_allreduce": a.comm_dtype if world > 1 else "none"},
             "loss": round(final_loss, 4),
             "step_mfma_frac": round(sps / world * f_alg(S) / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 and a.stage == 1 else None,

@@ -82,6 +82,12 @@ int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int ldw, const
                          int K2, void* gu, int ld_gu, void* act, int ld_act, int M, int ff, int K, void* stream);
 int lhrs_gemm_swiglu_bwd(const void* dY, int ldy, const void* WdT, int ldw, const void* A2, int lda2, const void* B2, int ldb2,
                          int K2, const void* gu, void* dgu, int ld_gu, void* dact_scratch, int M, int ff, int K, void* stream);
+/* peft lora_dropout (lora.Linear.forward: lora_B(lora_A(dropout(x))); p = 0.05 in Config/multi_modal_stage2.yaml, train mode only).
+ * out = dropout(x) with a counter-based mask over the element index (regenerated identically by the backward), and the masked product
+ * C = mask * (alpha * A.B^T) / (1 - p) + residual the dX path needs (dx = dy.W + mask * (s dy B A) / (1 - p)). */
+int lhrs_dropout_bf16(const void* x, long ldx, void* out, long ldo, long rows, int cols, float p, unsigned seed, void* stream);
+int lhrs_gemm_bf16_nt_dropmask(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                               const void* residual, int ldr, float alpha, float p, unsigned seed, void* stream);
 int lhrs_gemm_set_policy(int allow_256);
 int lhrs_gemm_profile_enable(int max_samples);
 int lhrs_gemm_profile_read(double* out5_host);

@@ -34,6 +34,8 @@ def _ctype_of(param: str):
         return ctypes.c_float
     if "long" in base:
         return ctypes.c_long
+    if base.strip() == "unsigned":
+        return ctypes.c_uint
     if "int" in base or "uint8_t" in base:
         return ctypes.c_int
     raise ValueError(f"unparsed C parameter: {param!r}")

@@ -104,6 +104,13 @@ __device__ __forceinline__ void unpack8(const uint4& u, float (&v)[8]) {
 __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
   return make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
 }
+// LoRA dropout (peft lora.Linear: lora_B(lora_A(dropout(x))), p = 0.05 in Config/multi_modal_stage2.yaml): counter-based mask - element
+// idx of the adapter INPUT is kept iff lowbias32(idx, seed) >= p * 2^32 - so forward, backward and the tests regenerate the same mask
+__device__ __forceinline__ bool drop_keep(unsigned seed, long idx, unsigned thresh) {
+  unsigned x = ((unsigned)idx * 0x9E3779B1u) ^ ((unsigned)(idx >> 32) * 0x85EBCA77u) ^ seed;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x >= thresh;
+}
 __device__ __forceinline__ float silu(float x) { return x / (1.f + __expf(-x)); }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

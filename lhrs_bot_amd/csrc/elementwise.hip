@@ -78,6 +78,22 @@ __global__ void rope_kernel(bf16_t* x, long ld, int rows, int nheads, int D, con
   }
 }
 
+// ---- LoRA dropout: out[m, n] = keep(m * cols + n) ? x[m, n] / (1 - p) : 0
+__global__ void dropout_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ out, long ldo, long rows, int cols, float scale,
+                               unsigned seed, unsigned thresh) {
+  const int chunks = cols / 8;
+  const long total = rows * chunks;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = idx % chunks;
+    const long row = idx / chunks;
+    float v[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + row * ldx + c * 8), v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = drop_keep(seed, row * cols + c * 8 + i, thresh) ? v[i] * scale : 0.f;
+    *reinterpret_cast<uint4*>(out + row * ldo + c * 8) = pack8(v);
+  }
+}
+
 // ---- SwiGLU: gu[m, 0:F] = gate, gu[m, F:2F] = up
 __global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act, long rows, int F) {
   const int chunks = F / 8;
@@ -321,5 +337,15 @@ extern "C" int lhrs_transpose_batched(const long* desc, int n, int total_tiles, 
   LHRS_REQUIRE(desc != nullptr && n > 0 && total_tiles > 0, "transpose_batched: n=%d tiles=%d", n, total_tiles);
   hipLaunchKernelGGL(transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, desc, n);
   LHRS_CHECK_LAUNCH("transpose_batched");
+  return 0;
+}
+
+// out = dropout(x) with keep probability 1 - p and the counter-based mask of common.h (peft lora_dropout); cols % 8 == 0
+extern "C" int lhrs_dropout_bf16(const void* x, long ldx, void* out, long ldo, long rows, int cols, float p, unsigned seed, void* stream) {
+  LHRS_REQUIRE(rows > 0 && cols % 8 == 0 && p >= 0.f && p < 1.f && ldx % 8 == 0 && ldo % 8 == 0, "dropout: rows=%ld cols=%d p=%f", rows, cols, p);
+  const unsigned thresh = (unsigned)((double)p * 4294967296.0);
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(rows * (cols / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)out, ldo,
+                     rows, cols, 1.f / (1.f - p), seed, thresh);
+  LHRS_CHECK_LAUNCH("dropout");
   return 0;
 }

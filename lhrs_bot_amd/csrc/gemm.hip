@@ -52,6 +52,9 @@ struct GemmArgs {
   // e4m3 operands (gemm_fp8_256_kernel): per-row dequantisation scales of A (length M) and B (length N)
   const float* sa;
   const float* sb;
+  // dropout mask on alpha * A.B^T BEFORE bias / residual (LoRA dX path: dx = dy.W + mask * (U.A) / (1 - p)); drop_thresh = 0 -> off
+  float drop_scale;
+  unsigned drop_seed, drop_thresh;
   // split-K of the small-tile kernel (skinny-N products): block (x, y) reduces K-slice y of length ksplit into f32 slab y of C
   int ksplit;
 };
@@ -84,6 +87,10 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 template <int ACT>
 __device__ __forceinline__ void store4(const GemmArgs& g, int m, int n, f32x4 acc) {
   float v[4] = {acc[0] * g.alpha, acc[1] * g.alpha, acc[2] * g.alpha, acc[3] * g.alpha};
+  if (g.drop_thresh) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = drop_keep(g.drop_seed, (long)m * g.N + n + i, g.drop_thresh) ? v[i] * g.drop_scale : 0.f;
+  }
   if (g.bias) {
     const uint2 b = *reinterpret_cast<const uint2*>(g.bias + n);
     v[0] += bflo(b.x); v[1] += bfhi(b.x); v[2] += bflo(b.y); v[3] += bfhi(b.y);
@@ -939,7 +946,12 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256r_kernel(GemmArgs g) {
           float v[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            v[i] = acc[mi][ni][4 * q + i] * g.alpha + bias_v[ni][q][i];
+            v[i] = acc[mi][ni][4 * q + i] * g.alpha;
+            if (EPI == 0 && g.drop_thresh) {
+              const long e = (long)(tm * BM + wm * 64 + row) * g.N + tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4 + i;
+              v[i] = drop_keep(g.drop_seed, e, g.drop_thresh) ? v[i] * g.drop_scale : 0.f;
+            }
+            v[i] += bias_v[ni][q][i];
             if (ACT) v[i] = apply_act(v[i], ACT);
           }
           const int u = ni * 8 + q * 2 + fh;
@@ -1310,6 +1322,17 @@ extern "C" int lhrs_gemm_set_policy(int allow_256) { g_gemm_allow_256 = allow_25
 static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* bias,
                        const void* residual, int ldr, int act, int out_f32, int accumulate, float alpha, const void* A2,
                        int lda2, const void* B2, int ldb2, int K2, void* stream);
+static thread_local struct { float scale; unsigned seed, thresh; } t_drop = {1.f, 0u, 0u};  // set around one gemm_launch by the dropmask entry
+
+// C = mask * (alpha * A.B^T) / (1 - p) + residual, mask = the counter-based LoRA dropout mask over the [M, N] result (see common.h)
+extern "C" int lhrs_gemm_bf16_nt_dropmask(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                                          const void* residual, int ldr, float alpha, float p, unsigned seed, void* stream) {
+  LHRS_REQUIRE(p > 0.f && p < 1.f, "gemm_dropmask: p=%f", p);
+  t_drop.scale = 1.f / (1.f - p); t_drop.seed = seed; t_drop.thresh = (unsigned)((double)p * 4294967296.0);
+  const int rc = gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, nullptr, residual, ldr, 0, 0, 0, alpha, nullptr, 0, nullptr, 0, 0, stream);
+  t_drop.thresh = 0;
+  return rc;
+}
 
 extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N,
                                  int K, const void* bias, const void* residual, int ldr, int act, int out_f32,
@@ -1341,12 +1364,13 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   LHRS_REQUIRE(!accumulate || out_f32, "gemm: accumulate needs f32 output");
   LHRS_REQUIRE(act >= 0 && act <= 3, "gemm: unknown activation %d", act);
   GemmArgs g;
-  g.epi = 0; g.ff = 0; g.aux = nullptr; g.aux_out = nullptr; g.ld_aux = 0; g.sa = nullptr; g.sb = nullptr; g.ksplit = 0;
+  g.epi = 0; g.ff = 0; g.aux = nullptr; g.aux_out = nullptr; g.ld_aux = 0; g.sa = nullptr; g.sb = nullptr; g.ksplit = 0; g.drop_scale = 1.f; g.drop_seed = 0; g.drop_thresh = 0;
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C;
   g.bias = (const bf16_t*)bias; g.res = (const bf16_t*)residual;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
   g.alpha = alpha; g.act = act; g.out_f32 = out_f32; g.accum = accumulate;
   g.A2 = (const bf16_t*)A2; g.B2 = (const bf16_t*)B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
+  g.drop_scale = t_drop.scale; g.drop_seed = t_drop.seed; g.drop_thresh = t_drop.thresh;
   hipStream_t s = (hipStream_t)stream;
   // Tile choice: fill the 256 CUs.  Small problems (projector, ViT at small batch) take smaller tiles.
   const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
@@ -1364,7 +1388,8 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   } while (0)
   const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
   const bool al16 = out_f32 || (N % 8 == 0 && ldc % 8 == 0 && (residual == nullptr || ldr % 8 == 0));  // 16-B epilogue rows
-  const bool use256 = g_gemm_allow_256 && t256 >= 160 && K >= 96 && K % 32 == 0 && al16;  // ring prologue needs >= 3 stages
+  bool use256 = g_gemm_allow_256 && t256 >= 160 && K >= 96 && K % 32 == 0 && al16;  // ring prologue needs >= 3 stages
+  if (g.drop_thresh && !((g_gemm_allow_256 == 2 || g_gemm_allow_256 == 5) && K % 64 == 0 && K >= 128)) use256 = false;  // the mask lives in the r kernel and in store4
   if (K2 > 0 && !use256) {  // small problems: base GEMM, then the rank-K2 update accumulated on top of it
     if (gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, out_f32, accumulate, alpha, nullptr, 0, nullptr, 0, 0, stream))
       return -1;

@@ -149,6 +149,27 @@ class BatchedTranspose:
         _lib.check(_L().lhrs_transpose_batched(self.desc.data_ptr(), self.n, self.tiles, _stream()), "transpose_batched")
 
 
+def dropout(x, p, seed, out=None):
+    """peft lora_dropout on the adapter input: out = x * mask / (1 - p), mask regenerated from (seed, element index)."""
+    rows, cols = x.shape
+    out = torch.empty((rows, cols), device=x.device, dtype=torch.bfloat16) if out is None else out
+    _lib.check(_L().lhrs_dropout_bf16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), rows, cols, float(p), int(seed) & 0xFFFFFFFF,
+                                      _stream()), "dropout")
+    return out
+
+
+def gemm_nt_dropmask(a, b, p, seed, residual=None, alpha=1.0):
+    """out = mask * (alpha * a @ b^T) / (1 - p) + residual with the same counter-based mask as dropout() over the [M, N] result."""
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty((M, N), device=a.device, dtype=torch.bfloat16)
+    st = _L().lhrs_gemm_bf16_nt_dropmask(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N, K,
+                                         _p(residual), residual.stride(0) if residual is not None else 0, float(alpha), float(p),
+                                         int(seed) & 0xFFFFFFFF, _stream())
+    _lib.check(st, "gemm_bf16_nt_dropmask")
+    return out
+
+
 def gemm_tn_skinny(p, q, out, accumulate=False):
     """out[KP, N] (+)= p[M, KP]^T @ q[M, N]  (fp32 out; p, q token-major bf16, row strides free)."""
     M, KP = p.shape

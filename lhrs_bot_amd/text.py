@@ -50,8 +50,11 @@ class LoraStore:
         BD [KP, out_total]   block p = B_p^T at rows p*r.., cols p*out.. (block diagonal; off-blocks are masked to 0)
     and two derived bf16 operands rebuilt after every optimizer step: AT = A^T [in, KP], Bfull = BD^T [out_total, KP]."""
 
-    def __init__(self, n_layers, r, alpha, targets, dims, device, seed=0):
+    def __init__(self, n_layers, r, alpha, targets, dims, device, seed=0, dropout=0.0):
         self.r, self.s, self.targets, self.device, self.nl = int(r), float(alpha) / float(r), tuple(targets), device, n_layers
+        # peft lora_dropout: applied to the adapter input in train mode only; ONE counter-based mask per fused group and forward pass
+        # (peft draws one per wrapped nn.Linear: q, k, v - and gate, up - share a mask here because they share the stacked A product)
+        self.dropout, self.train_mode, self.drop_seed, self.drop_epoch = float(dropout), True, int(seed) * 2654435761 % (1 << 32), 0
         self.groups = {}
         for gname, (projs, fin, fout) in dims.items():
             mask = sum(1 << i for i, p in enumerate(projs) if p in self.targets)
@@ -91,6 +94,13 @@ class LoraStore:
         for G in self.groups.values():
             n += bin(G["mask"]).count("1") * self.r * (G["fin"] + G["fout"])
         return n * self.nl
+
+    def active_dropout(self) -> float:
+        return self.dropout if self.train_mode else 0.0
+
+    def seed_for(self, l: int, gname: str) -> int:
+        gid = list(self.groups).index(gname)
+        return (self.drop_seed + self.drop_epoch * 0x85EBCA77 + (l * 8 + gid) * 0x9E3779B1) & 0xFFFFFFFF
 
     def refresh(self):
         """bf16 shadow + transposed operands after a load / optimizer step (all 8 transposes of every layer in one launch)."""
@@ -218,13 +228,19 @@ class TextModal:
                                      "ln2_w": rn(d, std=0.0, mean=1.0), "gu_w": rn(2 * ff, d), "down_w": rn(d, ff)})
         self._finish()
 
-    def enable_lora(self, r=128, alpha=256, targets=LORA_ALL, seed=0) -> LoraStore:
+    def enable_lora(self, r=128, alpha=256, targets=LORA_ALL, seed=0, dropout=0.0) -> LoraStore:
         """TextModal.__init__ LoRA branch (text_modal.py:133-151): LoraConfig(r, lora_alpha, target_modules=all linears).
-        BASELINE config 4 uses r=8 on ("q","k","v","o").  Dropout is not applied (stage 3 runs text.eval())."""
+        BASELINE config 4 uses r=8 on ("q","k","v","o").  dropout = lora_dropout (0.05 in the stage-2 YAML; train mode only - stage 3
+        runs text.eval())."""
         dims = {"qkv": (("q", "k", "v"), self.d, self.d), "o": (("o",), self.d, self.d), "gu": (("gate", "up"), self.d, self.ff),
                 "down": (("down",), self.ff, self.d)}
-        self.lora = LoraStore(len(self.p["layers"]), r, alpha, targets, dims, self.device, seed)
+        self.lora = LoraStore(len(self.p["layers"]), r, alpha, targets, dims, self.device, seed, dropout)
         return self.lora
+
+    def _drop(self, rec, gname):
+        """(p, seed) of the dropout mask this group's forward used, or None"""
+        seed = rec.get("seed_" + gname)
+        return None if seed is None else (self.lora.dropout, seed)
 
     def _q8(self, L, name):
         """(e4m3 weight, per-row scales) of L[name] when the base weights are 8-bit (quantize_base), else None."""
@@ -236,7 +252,13 @@ class TextModal:
         lo = self.lora
         has_lora = lo is not None and gname in lo.groups
         if has_lora:
-            T = hk.gemm_nt_skinny(x, lo.view(lo.shadow, li, gname, "A"), alpha=lo.s)          # [M, KP] = s * x A^T
+            xa, pd = x, lo.active_dropout()
+            if pd > 0:  # lora_A(dropout(x)): the mask is regenerated from the saved seed in the backward
+                seed = lo.seed_for(li, gname)
+                xa = hk.dropout(x, pd, seed)
+                if save is not None:
+                    save["seed_" + gname] = seed
+            T = hk.gemm_nt_skinny(xa, lo.view(lo.shadow, li, gname, "A"), alpha=lo.s)          # [M, KP] = s * dropout(x) A^T
             if save is not None:
                 save["T_" + gname] = T
         if q8 is not None:
@@ -257,16 +279,24 @@ class TextModal:
             return gu, act, (act8, sact)
         if lo is None or "gu" not in lo.groups:
             return hk.gemm_swiglu_fwd(h, W, self.ff) + (None,)
-        T = hk.gemm_nt_skinny(h, lo.view(lo.shadow, li, "gu", "A"), alpha=lo.s)
+        ha, pd = h, lo.active_dropout()
+        if pd > 0:
+            seed = lo.seed_for(li, "gu")
+            ha = hk.dropout(h, pd, seed)
+            if save is not None:
+                save["seed_gu"] = seed
+        T = hk.gemm_nt_skinny(ha, lo.view(lo.shadow, li, "gu", "A"), alpha=lo.s)
         if save is not None:
             save["T_gu"] = T
         return hk.gemm_swiglu_fwd(h, W, self.ff, T, lo.derived[(li, "gu", "Bfull")]) + (None,)
 
-    def _down_bwd(self, li, dy, WT, gu, act, T, q8=None, dyq=None):
+    def _down_bwd(self, li, dy, WT, gu, act, T, q8=None, dyq=None, drop=None):
         """dgu (written over gu) = swiglu'(gu) * d_act with d_act = dy W_down (+ LoRA) never leaving the GEMM epilogue."""
         lo = self.lora
+        if drop is not None and q8 is None:  # masked adapter term: unfused sequence
+            return hk.swiglu_bwd(self._lin_bwd(li, "down", dy, WT, act, T, drop=drop), gu, self.ff, out=gu)
         if q8 is not None:  # -> (d(gate|up) bf16 over gu or None, its e4m3 operand for the gate|up dX product)
-            dact = self._lin_bwd(li, "down", dy, WT, act, T, q8=q8, dyq=dyq)
+            dact = self._lin_bwd(li, "down", dy, WT, act, T, q8=q8, dyq=dyq, drop=drop)
             dgu, dgu8, sdgu = hk.swiglu_bwd_q(dact, gu, self.ff, want_bf16=lo is not None and "gu" in lo.groups)
             return dgu, (dgu8, sdgu)
         if lo is None or "down" not in lo.groups:
@@ -279,7 +309,7 @@ class TextModal:
         hk.blockdiag_mask(dBD, lo.r, G["fout"], G["mask"])
         return dgu
 
-    def _lin_bwd(self, li, gname, dy, WT, x, T, q8=None, dyq=None):
+    def _lin_bwd(self, li, gname, dy, WT, x, T, q8=None, dyq=None, drop=None):
         """dx = dy W (+ s (dy B) A); adapter gradients dA = (s dy B)^T x, dB^T = (s x A^T)^T dy written into lora.grad.
         q8 = (WT8, scales): e4m3 copy of the transposed base weight (per in-feature scales), dy quantised per row on the fly."""
         lo = self.lora
@@ -292,7 +322,11 @@ class TextModal:
             return hk.gemm_nt(dy, WT)
         G = lo.groups[gname]
         U = hk.gemm_nt_skinny(dy, lo.view(lo.shadow, li, gname, "BD"), alpha=lo.s)         # [M, KP] = s * dy B
-        if q8 is not None:
+        if drop is not None:  # dx = dy W + mask * (U A) / (1 - p): the adapter term cannot share the base product's accumulators
+            base = hk.gemm_fp8_nt(dy8, sdy, q8[0], q8[1]) if q8 is not None else hk.gemm_nt(dy, WT)
+            dx = hk.gemm_nt_dropmask(U, lo.derived[(li, gname, "AT")], drop[0], drop[1], residual=base)
+            x = hk.dropout(x, drop[0], drop[1])                                            # dA sees the same masked input
+        elif q8 is not None:
             dx = hk.gemm_fp8_nt(dy8, sdy, q8[0], q8[1], a2=U, b2=lo.derived[(li, gname, "AT")])
         else:
             dx = hk.gemm_nt_lora(dy, WT, U, lo.derived[(li, gname, "AT")])
@@ -351,6 +385,8 @@ class TextModal:
         desc = hk.make_desc([(b * S, S, b * S, int(kv_len[b]), S, 0) for b in range(B)], self.device)
         LT = hk.pad64(S)
         saved: Optional[List] = [] if save_ctx else None
+        if self.lora is not None:
+            self.lora.drop_epoch += 1  # a fresh dropout mask per forward pass
         x = embeds.reshape(B * S, d)
         for li, L in enumerate(self.p["layers"]):
             x = self._layer_fwd(L, x, B, S, desc, LT, saved, li)
@@ -657,24 +693,24 @@ class TextModal:
             L, s = p["layers"][li], c["layers"][li]
             gu, qkv = s["gu"], s["qkv"]
             act = hk.swiglu_fwd(gu, ff) if lo is not None and "down" in lo.groups else None      # x of the down projection
-            dgu = self._down_bwd(li, dx, L["down_wT"], gu, act, s.get("T_down"), q8=self._q8(L, "down_wT"), dyq=dxq)
+            dgu = self._down_bwd(li, dx, L["down_wT"], gu, act, s.get("T_down"), q8=self._q8(L, "down_wT"), dyq=dxq, drop=self._drop(s, "down"))
             dguq = None
             if self.base8:
                 dgu, dguq = dgu
             h2 = hk.rmsnorm_fwd(s["x_mid"], L["ln2_w"], self.eps) if lo is not None and "gu" in lo.groups else None
-            dh = self._lin_bwd(li, "gu", dgu, L["gu_wT"], h2, s.get("T_gu"), q8=self._q8(L, "gu_wT"), dyq=dguq)
+            dh = self._lin_bwd(li, "gu", dgu, L["gu_wT"], h2, s.get("T_gu"), q8=self._q8(L, "gu_wT"), dyq=dguq, drop=self._drop(s, "gu"))
             dmq = None
             if self.base8:
                 dx_mid, dmq = hk.rmsnorm_bwd_q(dh, s["x_mid"], L["ln2_w"], None, add=dx, eps=self.eps, out=dh)
             else:
                 dx_mid = hk.rmsnorm_bwd(dh, s["x_mid"], L["ln2_w"], None, add=dx, eps=self.eps, out=dh)
-            do = self._lin_bwd(li, "o", dx_mid, L["o_wT"], s["o"], s.get("T_o"), q8=self._q8(L, "o_wT"), dyq=dmq)
+            do = self._lin_bwd(li, "o", dx_mid, L["o_wT"], s["o"], s.get("T_o"), q8=self._q8(L, "o_wT"), dyq=dmq, drop=self._drop(s, "o"))
             hk.attn_delta(s["o"], do, delta, desc, B, H, hd, S, LT)
             hk.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], do, s["lse"], delta, dqkv[:, :d], dqkv[:, d:2 * d],
                         dqkv[:, 2 * d:], desc, B, H, hd, S, S, LT, True, scale)
             hk.rope_(dqkv, M, 2 * H, hd, self.cos, self.sin, pos_mod=S, inverse=True)
             h1 = hk.rmsnorm_fwd(s["x_in"], L["ln1_w"], self.eps) if lo is not None and "qkv" in lo.groups else None
-            dh1 = self._lin_bwd(li, "qkv", dqkv, L["qkv_wT"], h1, s.get("T_qkv"), q8=self._q8(L, "qkv_wT"))
+            dh1 = self._lin_bwd(li, "qkv", dqkv, L["qkv_wT"], h1, s.get("T_qkv"), q8=self._q8(L, "qkv_wT"), drop=self._drop(s, "qkv"))
             if self.base8:
                 dx, dxq = hk.rmsnorm_bwd_q(dh1, s["x_in"], L["ln1_w"], None, add=dx_mid, eps=self.eps, out=dh1)
             else:

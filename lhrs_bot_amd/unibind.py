@@ -68,10 +68,14 @@ class UniBind:
 
     def train(self):
         self.training = True
+        if getattr(self, "text", None) is not None and self.text.lora is not None:
+            self.text.lora.train_mode = True
         return self
 
     def eval(self):
         self.training = False
+        if getattr(self, "text", None) is not None and self.text.lora is not None:
+            self.text.lora.train_mode = False  # lora_dropout off (peft: nn.Dropout in eval mode)
         return self
 
     def to(self, *a, **k):
@@ -92,10 +96,10 @@ class UniBind:
         self.text.load_params(P["llama"])
         return self
 
-    def enable_lora(self, r=128, alpha=256, targets=None, seed=0):
+    def enable_lora(self, r=128, alpha=256, targets=None, seed=0, dropout=0.0):
         """lora.enable / lora_r / lora_alpha of Config/multi_modal_stage2.yaml:81-86 (text_modal.py:133-151)."""
         from .text import LORA_ALL
-        return self.text.enable_lora(r=r, alpha=alpha, targets=targets or LORA_ALL, seed=seed)
+        return self.text.enable_lora(r=r, alpha=alpha, targets=targets or LORA_ALL, seed=seed, dropout=dropout)
 
     def encode_image(self, image, pool: bool = False):
         emb = self.rgb_pooler.forward(self.rgb.encode(image), save_ctx=False)

@@ -169,13 +169,21 @@ def _rms(x, w, eps):
     return w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))
 
 
+_GROUP_OF = {"q": "qkv", "k": "qkv", "v": "qkv", "o": "o", "gate": "gu", "up": "gu", "down": "down"}
+
+
 def _lora(L, proj, x):
-    """peft lora.Linear delta (peft 0.7.1, absent here - PARITY UNPINNED): s * (x A^T) B^T with s = lora_alpha / r; call site
-    lhrs/models/text_modal.py:133-151.  L["lora"] = {"scale": s, proj: (A [r,in], B [out,r])}."""
+    """peft lora.Linear delta (peft 0.7.1, absent here - PARITY UNPINNED): s * (dropout(x) A^T) B^T with s = lora_alpha / r; call site
+    lhrs/models/text_modal.py:133-151.  L["lora"] = {"scale": s, proj: (A [r,in], B [out,r])}; optional L["lora"]["drop"] =
+    {group: mask of x's shape holding 0 or 1/(1-p)} reproduces a given dropout draw (the engine's counter-based masks, one per fused
+    group - peft itself draws one per wrapped nn.Linear)."""
     lo = L.get("lora")
     if not lo or proj not in lo:
         return 0.0
     A, B = lo[proj]
+    mask = (lo.get("drop") or {}).get(_GROUP_OF[proj])
+    if mask is not None:
+        x = x * mask
     return lo["scale"] * F.linear(F.linear(x, A), B)
 
 

@@ -82,3 +82,55 @@ def test_lora_forward_backward_and_adamw(targets, r, train_pooler):
     # the refreshed operands are used by the next forward: loss must change and stay finite
     out2 = eng(batch)
     assert torch.isfinite(out2["total_loss"]) and out2["total_loss"].item() != out["total_loss"].item()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("bits", [16, 8])
+def test_lora_dropout_matches_oracle_with_the_same_masks(bits):
+    """peft lora_dropout (stage 2: p = 0.05; here 0.3 so that it matters): the engine's counter-based masks are exported (dropout of a
+    tensor of ones with the saved seeds) into the oracle, which then has to reproduce loss and every adapter gradient; eval() turns it off."""
+    from lhrs_bot_amd import kernels as hk
+    targets = ("q", "k", "v", "o", "gate", "up", "down")
+    model, lora, P, batch = make(targets, 8, False)
+    p = 0.3
+    lora.dropout = p
+    if bits == 8:
+        model.text.quantize_base(8)
+    eng = LHRSEngine(model, optimizer="adamw", lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
+    out = eng(batch)
+    recs = model.text._ctx["layers"]
+    B, S = model.text._ctx["B"], model.text._ctx["S"]
+    dims = {"qkv": 4096, "o": 4096, "gu": 4096, "down": 11008}
+    for l, rec in enumerate(recs):
+        masks = {}
+        for gname, fin in dims.items():
+            ones = torch.ones(B * S, fin, device=DEV, dtype=torch.bfloat16)
+            m = hk.dropout(ones, p, rec["seed_" + gname]).float().cpu().view(B, S, fin)
+            assert abs((m == 0).float().mean().item() - p) < 0.01                 # the drop rate is p
+            assert set(m.unique().tolist()) <= {0.0, float(torch.tensor(1 / (1 - p)).to(torch.bfloat16))}
+            masks[gname] = (m != 0).float() / (1 - p)
+        P["llama"]["layers"][l]["lora"]["drop"] = masks
+    assert len({rec["seed_qkv"] for rec in recs}) == len(recs)                     # a different mask per layer
+    eng.backward(out["total_loss"])
+    torch.cuda.synchronize()
+    loss = O.unibind_forward(P, batch)
+    loss.backward()
+    tol = 3e-3 if bits == 16 else 3e-2
+    assert abs(out["total_loss"].item() - loss.item()) < tol * loss.item()
+    if bits == 16:
+        for l in range(2):
+            for pr in targets:
+                dA, dB = lora.grad_adapter(l, pr)
+                Ao, Bo = P["llama"]["layers"][l]["lora"][pr]
+                assert rel(dA, Ao.grad) < 6e-2, (l, pr, "dA")
+                assert rel(dB, Bo.grad) < 6e-2, (l, pr, "dB")
+    # a new forward draws new masks; eval() switches the dropout off (loss equals the no-dropout loss of the oracle)
+    l2 = eng(batch)["total_loss"].item()
+    assert l2 != out["total_loss"].item()
+    model.eval()
+    for l in range(2):
+        del P["llama"]["layers"][l]["lora"]["drop"]
+    with torch.no_grad():
+        want = O.unibind_forward(P, batch).item()
+    got = model(batch)["total_loss"].item()
+    assert abs(got - want) < tol * want
