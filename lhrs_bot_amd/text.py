@@ -340,6 +340,10 @@ class TextModal:
         """Device-side restatement of text_modal.py:296-526 (one <image> per sample, tune_im_start off)."""
         ids = input_ids.to(self.device)
         B, T = ids.shape
+        if image_embedding is None:  # text-only turn (text_modal.py:321-339): no <image> token may be present, plain embeddings
+            if bool((ids == IMAGE_TOKEN_INDEX).any()):
+                raise ValueError("input_ids contain the <image> placeholder but no image embedding was given")
+            image_embedding = torch.zeros((B, 1, self.d), device=self.device, dtype=torch.bfloat16)
         NI = image_embedding.shape[1]
         has_img = (ids == IMAGE_TOKEN_INDEX).any(dim=1)
         n_img = (ids == IMAGE_TOKEN_INDEX).sum(dim=1)

@@ -121,9 +121,7 @@ class UniBind:
                  stopping_criteria=None, **kwargs):
         """UniBind.generate (lhrs/models/UniBind.py:214-242): encode the image once, then TextModal.generate."""
         assert hasattr(self, "text"), "text modal is not activate"
-        image_embedding = self.encode_image(images, pool=False) if images is not None else None
-        if image_embedding is None:
-            raise NotImplementedError("text-only generate")
+        image_embedding = self.encode_image(images, pool=False) if images is not None else None  # None: text-only turn
         return self.text.generate(input_ids=input_ids, image_embedding=image_embedding, do_sample=do_sample, temperature=temperature,
                                   max_new_tokens=max_new_tokens, streamer=streamer, use_cache=use_cache,
                                   stopping_criteria=stopping_criteria, **kwargs)

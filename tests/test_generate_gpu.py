@@ -47,6 +47,23 @@ def test_greedy_generate_matches_oracle_and_full_forward():
     assert rel(lg, logits) < 1e-2
 
 
+def test_text_only_generate_matches_oracle():
+    """UniBind.generate(images=None): a text-only turn - plain token embeddings, no splice (text_modal.py:321-339)."""
+    P = {"vit": OP.make_vit_params(seed=2), "pooler": OP.make_pooler_params(seed=1), "llama": OP.make_llama_params(seed=3, layers=2)}
+    model = UniBind(("rgb", "text"), None, device=DEV, llama_layers=2).load_params(P).eval()
+    ids = torch.tensor([[1, 50, 600, 7000, 80, 9]])
+    new_ids, logits = model.generate(ids, images=None, do_sample=False, max_new_tokens=3, return_logits=True)
+    emb = P["llama"]["embed"]
+    seq = ids.clone()
+    for t in range(3):
+        h = O.llama_hidden(P["llama"], emb[seq], None)
+        want = torch.nn.functional.linear(h[:, -1], P["llama"]["lm_head"]).float()
+        assert rel(logits[:, t], want) < 3e-2
+        seq = torch.cat([seq, new_ids[:, t:t + 1].cpu()], 1)
+    with pytest.raises(ValueError):
+        model.generate(torch.tensor([[1, -200, 5]]), images=None, max_new_tokens=1)
+
+
 def test_sampling_path_runs_and_respects_eos():
     model = UniBind(("rgb", "text"), None, device=DEV, llama_layers=1).init_random(seed=0).eval()
     ids = torch.tensor([[1, -200, 5, 6, 7]])
