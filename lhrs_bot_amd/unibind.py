@@ -33,6 +33,7 @@ class UniBind:
         assert len(activate_modal) > 0, "activate_modal should not be empty"
         self.modal = tuple(activate_modal)
         self.stage = _get(config, "stage", 1)
+        self.config = config
         self.bits = int(_get(config, "bits", 16))  # Config/multi_modal_stage{2,3}.yaml: 8 -> 8-bit frozen base (text_modal.py:91-131)
         self.device = torch.device(device)
         if "rgb" in self.modal:
@@ -56,6 +57,10 @@ class UniBind:
                              tune_im_start=False, compute_dtype=torch.bfloat16):
         if not freeze_vision or tune_im_start:
             raise NotImplementedError("the ViT and the embedding tables stay frozen (every shipped stage: tune_rgb_bk / tune_im_start False)")
+        if not freeze_text and self.text.lora is None and _get(self.config, "lora.enable", False):
+            # TextModal.__init__ LoRA branch (text_modal.py:133-151): LoraConfig(r, lora_alpha, lora_dropout) on every linear of the decoder
+            self.enable_lora(r=int(_get(self.config, "lora.lora_r", 128)), alpha=float(_get(self.config, "lora.lora_alpha", 256)),
+                             dropout=float(_get(self.config, "lora.lora_dropout", 0.0)))
         if not freeze_text and self.text.lora is None:
             raise NotImplementedError("freeze_text=False means LoRA training (freeze_text = not config.lora.enable): call "
                                       "model.enable_lora(...) first; full LLaMA fine-tuning is not on the reference's path")

@@ -18,7 +18,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from lhrs_bot_amd.engine import LHRSEngine  # noqa: E402
-from lhrs_bot_amd.trainer import (ConfigArgumentParser, ConfigDict, EpochBasedTrainer, SyntheticStage1Loader,  # noqa: E402
+from lhrs_bot_amd.trainer import (ConfigArgumentParser, ConfigDict, EpochBasedTrainer, IterBasedTrainer, SyntheticStage1Loader,  # noqa: E402
                                   init_distributed, str2bool)
 from lhrs_bot_amd.unibind import build_model  # noqa: E402
 
@@ -57,14 +57,20 @@ def main(config):
                                tune_rgb_pooler=config.get("tune_rgb_pooler", True), model_path=config.get("model_path"),
                                tune_im_start=config.get("tune_im_start", False))
     loader = SyntheticStage1Loader(batch_size=config.batch_size, epoch_len=config.epoch_len, seed=config.seed)
+    betas = config.get("betas")
     engine = LHRSEngine(model, optimizer=config.get("optimizer", "adanp"), lr=float(config.get("lr", 2e-4)),
                         weight_decay=float(config.get("wd", 0.0)), max_grad_norm=float(config.get("max_grad_norm", 0.3)),
+                        betas=tuple(betas) if betas else None,
                         gradient_accumulation_steps=int(config.get("accumulation_steps", 1) or 1))
-    trainer = EpochBasedTrainer(model=engine, optimizer=engine.optimizer, lr_scheduler=config.get("schedule", {"name": "const"}),
-                                data_loader=loader, max_epochs=int(config.get("epochs", 1) or 1), work_dir=config.output,
-                                log_period=config.log_period, save_ckpt_by="iter", ckpt_period=1000, accelerator=config.accelerator,
-                                enable_amp=config.enable_amp, wandb=config.wandb, gpus=config.gpus, max_num_checkpoints=1,
-                                clip_grad_norm=config.get("max_grad_norm", 0.3), is_distributed=config.is_distribute, deepspeed=True)
+    common = dict(model=engine, optimizer=engine.optimizer, lr_scheduler=config.get("schedule", {"name": "const"}), data_loader=loader,
+                  work_dir=config.output, log_period=config.log_period, save_ckpt_by="iter", accelerator=config.accelerator,
+                  enable_amp=config.enable_amp, wandb=config.wandb, gpus=config.gpus, max_num_checkpoints=1,
+                  clip_grad_norm=config.get("max_grad_norm", 0.3), is_distributed=config.is_distribute, deepspeed=True)
+    if int(config.get("stage", 1)) >= 3:   # main_pretrain_stage3.py:225-231: IterBasedTrainer(max_iters=config.epochs), ckpt_period 100
+        trainer = IterBasedTrainer(max_iters=int(config.get("epochs", 1) or 1), ckpt_period=100, **common)
+    else:                                  # main_pretrain_stage{1,2}.py: EpochBasedTrainer(max_epochs=config.epochs)
+        trainer = EpochBasedTrainer(max_epochs=int(config.get("epochs", 1) or 1), ckpt_period=1000 if int(config.get("stage", 1)) == 1 else 100,
+                                    **common)
     trainer.train(load_checkpoint=config.get("resume_path"))
     if config.rank == 0:
         model.custom_save_checkpoint(os.path.join(config.output, "checkpoints"))

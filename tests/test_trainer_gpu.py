@@ -90,3 +90,30 @@ def test_gradient_accumulation_equals_one_step_on_the_mean_gradient():
     a, b = m2.rgb_pooler.master, m1.rgb_pooler.master
     assert ((a - b).norm() / (b - before).norm()).item() < 2e-3          # bf16 rounding of the 1/2-scaled backward vs scaling afterwards
     assert (b - before).norm().item() > 0
+
+
+def test_stage2_and_stage3_drivers_from_yaml_keys(tmp_path):
+    """The shared driver with the stage-2 / stage-3 YAML keys (`stage`, `lora`, `bits: 8`, `optimizer: adamw`, `betas`, `epochs`): LoRA comes
+    from the config (text_modal.py:133-151), the base goes to 8 bit, stage 3 runs IterBasedTrainer(max_iters=epochs) on adapters
+    loaded from the stage-2 checkpoint directory (UniBind.custom_load_state_dict -> TextLoRA/)."""
+    import main_pretrain_stage1 as drv
+    from lhrs_bot_amd.trainer import ConfigDict
+
+    def cfg(stage, out, **kw):
+        c = ConfigDict(dict(stage=stage, batch_size=2, epoch_len=3, seed=1, llama_layers=1, log_period=1, output=str(out), accelerator="gpu",
+                            enable_amp=True, wandb=False, gpus=0, local_rank=0, rank=0, world_size=1, is_distribute=False,
+                            optimizer="adamw", lr=1e-4, wd=0.0, max_grad_norm=1.0, betas=[0.9, 0.95], epochs=1, bits=8,
+                            tune_rgb_pooler=stage == 2, lora=dict(enable=stage == 2, lora_r=8, lora_alpha=16, lora_dropout=0.05)))
+        c.update(kw)
+        return c
+
+    t2 = drv.main(cfg(2, tmp_path / "s2"))
+    m2 = t2.model.module
+    assert m2.text.lora is not None and m2.text.lora.r == 8 and m2.text.lora.dropout == 0.05 and m2.text.base8
+    assert {s.name for s in t2.model.stores} == {"rgb_pooler", "lora"} and t2.model.global_steps == 3
+    assert os.path.isdir(tmp_path / "s2" / "checkpoints" / "TextLoRA")
+    t3 = drv.main(cfg(3, tmp_path / "s3", epochs=4, model_path=str(tmp_path / "s2" / "checkpoints" / "FINAL.pt")))
+    m3 = t3.model.module
+    assert m3.text.lora is not None and m3.text.lora.r == 8 and m3.text.base8        # adapters came from TextLoRA/, base re-quantised
+    assert {s.name for s in t3.model.stores} == {"lora"} and t3.model.global_steps == 4
+    assert len(t3.history) == 4 and all(torch.isfinite(torch.tensor(h["loss"])) for h in t3.history)
