@@ -1322,7 +1322,9 @@ extern "C" int lhrs_gemm_set_policy(int allow_256) { g_gemm_allow_256 = allow_25
 static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* bias,
                        const void* residual, int ldr, int act, int out_f32, int accumulate, float alpha, const void* A2,
                        int lda2, const void* B2, int ldb2, int K2, void* stream);
-static thread_local struct { float scale; unsigned seed, thresh; } t_drop = {1.f, 0u, 0u};  // set around one gemm_launch by the dropmask entry
+// epilogue dropout mask of the NEXT gemm_launch on this host thread: set and cleared by lhrs_gemm_bf16_nt_dropmask only (keeps the
+// 21-argument launcher signature out of every other call site); thresh = 0 means no mask
+static thread_local struct { float scale; unsigned seed, thresh; } t_drop = {1.f, 0u, 0u};
 
 // C = mask * (alpha * A.B^T) / (1 - p) + residual, mask = the counter-based LoRA dropout mask over the [M, N] result (see common.h)
 extern "C" int lhrs_gemm_bf16_nt_dropmask(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
