@@ -109,3 +109,29 @@ def test_rmsnorm_with_fused_quantisation_equals_rmsnorm_then_quant():
     d8_ref, ds_ref = hk.quant_fp8_rows(dx_ref)
     dx, (d8, ds) = hk.rmsnorm_bwd_q(dy, x, w, None, add=add)
     assert torch.equal(dx, dx_ref) and torch.equal(d8, d8_ref) and torch.equal(ds, ds_ref)
+
+
+@pytest.mark.timeout(900)
+def test_lora_training_on_e4m3_base_follows_the_bf16_loss_curve():
+    """25 AdamW steps on a fixed batch (stage-3 shape: LoRA r=8 on q,k,v,o, 2 layers): the e4m3-base run must learn like the bf16-base run."""
+    from bench import make_batch
+
+    def curve(bits):
+        m = UniBind(("rgb", "text"), None, device=DEV, llama_layers=2).init_random(seed=5)
+        m.enable_lora(r=8, alpha=16, targets=("q", "k", "v", "o"), seed=3)
+        if bits == 8:
+            m.text.quantize_base(8)
+        m.prepare_for_training(freeze_text=False, tune_rgb_pooler=False)
+        e = LHRSEngine(m, optimizer="adamw", lr=2e-3, weight_decay=0.0, max_grad_norm=1.0)
+        b = make_batch(4, 40, torch.device(DEV), seed=9)
+        out = []
+        for _ in range(25):
+            loss = e(b)["total_loss"]
+            e.backward()
+            e.step()
+            out.append(loss.item())
+        return out
+
+    c16, c8 = curve(16), curve(8)
+    assert c16[-1] < 0.05 * c16[0] and c8[-1] < 0.05 * c8[0], (c16[0], c16[-1], c8[0], c8[-1])   # both fit the batch
+    assert all(abs(a - b) < 0.1 * b + 0.02 for a, b in zip(c8, c16)), list(zip(c8, c16))         # along the same curve
