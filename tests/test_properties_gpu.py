@@ -101,3 +101,33 @@ def test_gemm_degenerate_shapes():
         assert ((out - ref).norm() / ref.norm()).item() < 1e-5
     with pytest.raises(RuntimeError):
         hk.gemm_nt(torch.zeros(0, 64, device=DEV, dtype=torch.bfloat16), w[:, :64].contiguous())
+
+
+@pytest.mark.timeout(900)
+def test_maximum_sequence_length_end_to_end():
+    """model_max_length = 2048 text tokens + 143 image positions = S 2191: the tiled (non LDS-resident) attention kernels, the RoPE
+    table beyond position 2048 and the splice at its largest size, forward + backward on a 1-layer model; causality holds at that size."""
+    from lhrs_bot_amd.unibind import UniBind
+    model = UniBind(("rgb", "text"), None, device="cuda", llama_layers=1).init_random(seed=2)
+    model.prepare_for_training()
+    g = torch.Generator().manual_seed(1)
+    T = 2048
+    ids = torch.randint(3, 32000, (1, T), generator=g)
+    ids[0, 0], ids[0, 1] = 1, -200
+    labels = ids.clone()
+    labels[:, :2] = -100
+    rgb = torch.randn(1, 3, 224, 224, generator=g)
+    out = model(dict(rgb=rgb, input_ids=ids, labels=labels, attention_mask=ids.ne(0)))
+    loss = out["total_loss"].item()
+    assert 9.0 < loss < 12.5
+    model.backward()
+    gq = model.rgb_pooler.g["query"]
+    assert torch.isfinite(gq).all() and float(gq.abs().sum()) > 0
+    # changing the LAST token cannot change the hidden state of any earlier position: compare losses restricted to early labels
+    ids2 = ids.clone()
+    ids2[0, -1] = 17
+    lab_early = labels.clone()
+    lab_early[0, 1000:] = -100
+    a = model(dict(rgb=rgb, input_ids=ids, labels=lab_early, attention_mask=ids.ne(0)))["total_loss"].item()
+    b = model(dict(rgb=rgb, input_ids=ids2, labels=lab_early, attention_mask=ids.ne(0)))["total_loss"].item()
+    assert a == b
