@@ -385,6 +385,8 @@ class TextModal:
     def forward_hidden(self, embeds, mask_u8, save_ctx=True):
         """embeds [B,S,d] bf16, mask [B,S] uint8 (right padding) -> final-norm hidden [B*S, d]."""
         B, S, d = embeds.shape
+        if S > self.cos.shape[0]:
+            raise ValueError(f"sequence length {S} exceeds the {self.cos.shape[0]} positions of the RoPE table")
         kv_len = mask_u8.to(torch.int32).sum(dim=1).tolist() if mask_u8 is not None else [S] * B
         desc = hk.make_desc([(b * S, S, b * S, int(kv_len[b]), S, 0) for b in range(B)], self.device)
         LT = hk.pad64(S)
@@ -561,6 +563,8 @@ class TextModal:
         embeds, _, mask, _ = self.prepare_inputs_for_multimodal(input_ids, attention_mask, None, image_embedding)
         B, S0, d = embeds.shape
         max_ctx = S0 + max_new_tokens
+        if max_ctx > self.cos.shape[0]:
+            raise ValueError(f"prompt ({S0}) + max_new_tokens ({max_new_tokens}) exceeds the {self.cos.shape[0]} positions of the RoPE table")
         dev = self.device
         kmask = None
         if mask is not None and not bool(mask.bool().all()):
