@@ -82,6 +82,9 @@ class VisionModal:
         """rgb [B,3,224,224] float -> [B, 3*256, 1024] bf16 (the three taps without CLS)."""
         p, d, H = self.p, self.dim, self.heads
         B = rgb.shape[0]
+        side = int(round(self.n_patch ** 0.5)) * self.patch
+        if rgb.dim() != 4 or rgb.shape[1] != 3 or rgb.shape[2] != side or rgb.shape[3] != side:
+            raise ValueError(f"VisionModal.encode expects [B, 3, {side}, {side}] pixel_values (CLIPImageProcessor output), got {tuple(rgb.shape)}")
         n = self.n_patch + 1
         rgb = rgb.to(self.device, torch.float32)
         x = hk.gemm_nt(hk.patchify(rgb, self.patch, self.kp), p["patch_w"])
