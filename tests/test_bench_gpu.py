@@ -1,0 +1,31 @@
+"""bench.py contract: one JSON line with the driver's keys, the roofline and cpu_baseline objects (tiny model so that it runs in seconds)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(900)
+def test_bench_emits_the_contract_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--llama-layers", "2",
+                          "--micro-batch", "15"], capture_output=True, text=True, timeout=800, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "samples/s" and d["value"] > 0 and d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and 0 < r["achieved"] < r["peak"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["launches_timed"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "samples/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
