@@ -209,8 +209,8 @@ class CLIPImageProcessorHIP:
         else:
             import numpy as np
             if hasattr(im, "convert"):  # PIL: do_convert_rgb
-                im = np.asarray(im.convert("RGB"))
-            t = torch.from_numpy(np.ascontiguousarray(im))
+                im = np.array(im.convert("RGB"))
+            t = torch.from_numpy(np.array(im, copy=True))
         if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
             raise ValueError(f"expected a uint8 [H, W, 3] image, got {tuple(t.shape)} {t.dtype}")
         return t.to(self.device).contiguous()

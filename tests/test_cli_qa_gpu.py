@@ -1,0 +1,91 @@
+"""cli_qa.py on the HIP engine (BASELINE configs[4]): the synthetic decode run and the interactive loop
+with a toy tokenizer (tiny 2-layer model; the flow, not the language, is what is checked)."""
+import builtins
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cli_qa  # noqa: E402
+
+
+def test_synthetic_prompt_run(capsys):
+    cfg = cli_qa.parse_option(["--synthetic-prompt", "24", "--max-new-tokens", "12", "--llama-layers", "2"])
+    out = cli_qa.main(cfg)
+    assert tuple(out.shape) == (1, 12) and int(out.min()) >= 0 and int(out.max()) < 32000
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert line["new_tokens"] == 12 and line["prompt_positions"] == 24 - 1 + 144 and line["weights"] == "bf16" and line["value"] > 0
+    # same seed, e4m3 weight stream (`bits: 8` of Config/multi_modal_eval.yaml)
+    cfg8 = cli_qa.parse_option(["--synthetic-prompt", "24", "--max-new-tokens", "12", "--llama-layers", "2", "--opts", "bits", "8"])
+    assert cfg8.bits == 8
+    out8 = cli_qa.main(cfg8)
+    assert tuple(out8.shape) == (1, 12)
+    assert json.loads(capsys.readouterr().out.strip().splitlines()[-1])["weights"] == "fp8"
+
+
+class ToyTok:
+    """Word-level stand-in for the LLaMA tokenizer: ids 3.. by first appearance; 1 = <s>, 2 = </s>."""
+    bos_token_id, eos_token_id, pad_token_id, unk_token_id, model_max_length = 1, 2, 0, 0, 2048
+
+    def __init__(self):
+        self.vocab, self.inv = {}, {1: "<s>", 2: "</s>", 0: "<unk>"}
+
+    def __len__(self):
+        return 32000
+
+    def _id(self, w):
+        if w == "</s>":
+            return 2
+        if w not in self.vocab:
+            self.vocab[w] = 3 + len(self.vocab)
+            self.inv[self.vocab[w]] = w
+        return self.vocab[w]
+
+    def __call__(self, text):
+        return type("E", (), {"input_ids": [1] + [self._id(w) for w in text.split()]})()
+
+    def decode(self, ids, skip_special_tokens=False):
+        ids = [int(i) for i in (ids.tolist() if hasattr(ids, "tolist") else ids)]
+        return " ".join(self.inv.get(i, f"<{i}>") for i in ids if not (skip_special_tokens and i in (0, 1, 2)))
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        return [self.decode(row, skip_special_tokens) for row in ids]
+
+
+def test_interactive_loop(monkeypatch, capsys, tmp_path):
+    import numpy as np
+    import transformers
+    from PIL import Image
+
+    img = tmp_path / "tile.png"
+    Image.fromarray(np.random.default_rng(0).integers(0, 256, (300, 260, 3), dtype=np.uint8)).save(img)
+    tok = ToyTok()
+    monkeypatch.setattr(transformers.AutoTokenizer, "from_pretrained", staticmethod(lambda *a, **k: tok))
+    turns = iter(["what is in this image ?", "and how many ?", ""])
+    monkeypatch.setattr(builtins, "input", lambda prompt="": next(turns))
+    seen = []
+    import lhrs_bot_amd.unibind as U
+    orig = U.UniBind.generate
+
+    def spy(self, input_ids, **kw):
+        out = orig(self, input_ids, **kw)
+        seen.append((input_ids.clone(), kw["images"], out.clone()))
+        return out
+
+    monkeypatch.setattr(U.UniBind, "generate", spy)
+    cfg = cli_qa.parse_option(["--image-file", str(img), "--tokenizer-path", "unused", "--max-new-tokens", "6", "--llama-layers", "2"])
+    cli_qa.main(cfg)
+    text = capsys.readouterr().out
+    assert text.count("ASSISTANT: ") == 2 and "exit..." in text
+    assert len(seen) == 2
+    (ids1, im1, out1), (ids2, im2, out2) = seen
+    # first turn: BOS, system prompt ..., exactly one image placeholder, the image tensor handed to generate
+    assert ids1.shape[0] == 1 and int(ids1[0, 0]) == 1 and int((ids1 == -200).sum()) == 1 and tuple(im1.shape) == (1, 3, 224, 224)
+    # second turn: the history (first prompt + first answer) is a prefix-compatible longer prompt that still holds the placeholder
+    assert ids2.shape[1] > ids1.shape[1] and int((ids2 == -200).sum()) == 1 and im2 is im1
+    assert out1.shape[1] <= 6 and out2.shape[1] <= 6
