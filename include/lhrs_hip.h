@@ -185,6 +185,8 @@ int lhrs_gemv_bf16(const void* W, long ldw, const void* x, long ldx, const void*
                    int N, int K, int out_f32, void* stream);
 int lhrs_gemv(const void* W, long ldw, const float* wscale, int w_fp8, const void* x, long ldx, int prologue, const void* norm_w,
               float eps, const void* residual, long ldr, void* y, long ldy, int B, int N, int K, int out_f32, void* stream);
+/* kernel A/B tests only: rows per wave / 1-KiB chunks per iteration of the batch-1 bf16 GEMV (0, 0 = the built-in shape rule) */
+int lhrs_gemv_set_tuning(int rows_per_wave, int chunks_per_iteration);
 int lhrs_quant_fp8_rows(const void* W, long ldw, void* W8, long ld8, float* scale, int N, int K, void* stream);
 int lhrs_rope_kv_append(void* qkv, long ld, void* kcache, void* vcache, const float* cos_t, const float* sin_t, const int* pos, int B,
                         int H, int D, int max_ctx, void* stream);

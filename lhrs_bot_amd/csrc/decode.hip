@@ -16,7 +16,9 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 // PRO: what the block does to the activation rows while staging them in LDS (every block redoes it: 8-22 KB from L2)
 //   0 plain copy            1 RMSNorm (HF LlamaRMSNorm: w * bf16(x * rsqrt(mean x^2 + eps)))       2 SwiGLU: silu(x[k]) * x[K + k]
 // FP8: W is OCP e4m3 with one fp32 scale per output row (the 6.7 GB / token weight stream of SURVEY.md §8d)
-template <int NB, int PRO, bool FP8, int RPW = 4>
+// RPW rows per wave; UNR 1-KiB row chunks per lane-iteration (bf16 weights): RPW * UNR 16-B loads per lane are prefetched one iteration
+// ahead, so a wave keeps RPW * UNR .. 2 * RPW * UNR KiB in flight.  The per-row summation order does not depend on RPW / UNR.
+template <int NB, int PRO, bool FP8, int RPW = 4, int UNR = 1>
 __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, long ldw, const float* __restrict__ wscale,
                                                    const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ norm_w, float eps,
                                                    const bf16_t* res, long ldr, void* y, long ldy, int N, int K, int out_f32) {
@@ -27,14 +29,16 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
   const int nch = K / 8;
   const int row0 = (blockIdx.x * 4 + wave) * RPW;  // 4 waves x RPW rows per block
   // the first weight loads are issued BEFORE the activation prologue (which needs two block-wide syncs): HBM latency overlaps it
-  uint4 wcur[RPW];
+  uint4 wcur[UNR][RPW];
   if (!FP8) {
     const bf16_t* W = reinterpret_cast<const bf16_t*>(Wv);
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-      const i32x4 t = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(W + (long)min(row0 + r, N - 1) * ldw + min(lane, nch - 1) * 8));
-      wcur[r] = make_uint4((unsigned)t[0], (unsigned)t[1], (unsigned)t[2], (unsigned)t[3]);
-    }
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        const i32x4 t = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(W + (long)min(row0 + r, N - 1) * ldw + min(lane + 64 * u, nch - 1) * 8));
+        wcur[u][r] = make_uint4((unsigned)t[0], (unsigned)t[1], (unsigned)t[2], (unsigned)t[3]);
+      }
   }
   for (int b = 0; b < NB; ++b) {
     if (PRO == 2) {
@@ -72,26 +76,37 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
     for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
   if (!FP8) {
     const bf16_t* W = reinterpret_cast<const bf16_t*>(Wv);
-    for (int c = lane; c < nch; c += 64) {  // software pipeline: the loads of chunk c + 64 fly while chunk c is multiplied
-      uint4 wnext[RPW];
-      const int cn = min(c + 64, nch - 1);
+    for (int c = lane; c < nch; c += 64 * UNR) {  // software pipeline: the loads of the next UNR chunks fly while these are multiplied
+      uint4 wnext[UNR][RPW];
 #pragma unroll
-      for (int r = 0; r < RPW; ++r) {
-        const i32x4 t = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(W + (long)min(row0 + r, N - 1) * ldw + cn * 8));
-        wnext[r] = make_uint4((unsigned)t[0], (unsigned)t[1], (unsigned)t[2], (unsigned)t[3]);
+      for (int u = 0; u < UNR; ++u) {
+        const int cn = min(c + 64 * (UNR + u), nch - 1);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+          const i32x4 t = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(W + (long)min(row0 + r, N - 1) * ldw + cn * 8));
+          wnext[u][r] = make_uint4((unsigned)t[0], (unsigned)t[1], (unsigned)t[2], (unsigned)t[3]);
+        }
       }
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const uint4 xv = *reinterpret_cast<const uint4*>(xs + b * K + c * 8);
-        const float x0 = bflo(xv.x), x1 = bfhi(xv.x), x2 = bflo(xv.y), x3 = bfhi(xv.y), x4 = bflo(xv.z), x5 = bfhi(xv.z), x6 = bflo(xv.w),
-                    x7 = bfhi(xv.w);
+      for (int u = 0; u < UNR; ++u) {
+        const int cc = c + 64 * u;
+        if (cc < nch) {
 #pragma unroll
-        for (int r = 0; r < RPW; ++r)
-          acc[r][b] += bflo(wcur[r].x) * x0 + bfhi(wcur[r].x) * x1 + bflo(wcur[r].y) * x2 + bfhi(wcur[r].y) * x3 + bflo(wcur[r].z) * x4 +
-                       bfhi(wcur[r].z) * x5 + bflo(wcur[r].w) * x6 + bfhi(wcur[r].w) * x7;
+          for (int b = 0; b < NB; ++b) {
+            const uint4 xv = *reinterpret_cast<const uint4*>(xs + b * K + cc * 8);
+            const float x0 = bflo(xv.x), x1 = bfhi(xv.x), x2 = bflo(xv.y), x3 = bfhi(xv.y), x4 = bflo(xv.z), x5 = bfhi(xv.z), x6 = bflo(xv.w),
+                        x7 = bfhi(xv.w);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+              acc[r][b] += bflo(wcur[u][r].x) * x0 + bfhi(wcur[u][r].x) * x1 + bflo(wcur[u][r].y) * x2 + bfhi(wcur[u][r].y) * x3 +
+                           bflo(wcur[u][r].z) * x4 + bfhi(wcur[u][r].z) * x5 + bflo(wcur[u][r].w) * x6 + bfhi(wcur[u][r].w) * x7;
+          }
+        }
       }
 #pragma unroll
-      for (int r = 0; r < RPW; ++r) wcur[r] = wnext[r];
+      for (int u = 0; u < UNR; ++u)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) wcur[u][r] = wnext[u][r];
     }
   } else {
     const uint8_t* W = reinterpret_cast<const uint8_t*>(Wv);
@@ -655,20 +670,39 @@ extern "C" int lhrs_decode_emit(const long* next_ids, int* tok32, long* out_ids,
   return 0;
 }
 
+static int g_gemv_rpw = 0, g_gemv_unr = 0;  // kernel A/B tests only (lhrs_gemv_set_tuning); 0 = the shape rule below
+
 // y[B, N] = x[B, K] . W[N, K]^T (+ residual[B, N]);  B <= 8, K % 8 == 0
 template <int PRO, bool FP8>
 static int gemv_chunk(const void* W, long ldw, const float* wscale, const bf16_t* x, long ldx, const bf16_t* norm_w, float eps,
                       const bf16_t* residual, long ldr, void* y, long ldy, int B, int N, int K, int out_f32, hipStream_t s) {
   const dim3 blk(256);
   const size_t sm = (size_t)B * K * 2;
-#define GEMV_LAUNCH(NB, RPW)                                                                                            \
+#define GEMV_LAUNCH(NB, RPW, UNR)                                                                                       \
   do {                                                                                                                  \
-    if (sm > 65536) (void)hipFuncSetAttribute((const void*)gemv_kernel<NB, PRO, FP8, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-    hipLaunchKernelGGL((gemv_kernel<NB, PRO, FP8, RPW>), dim3(cdiv(N, 4 * RPW)), blk, sm, s, W, ldw, wscale, x, ldx, norm_w, eps, residual, ldr, y, ldy, N, K, out_f32); \
+    if (sm > 65536) (void)hipFuncSetAttribute((const void*)gemv_kernel<NB, PRO, FP8, RPW, UNR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+    hipLaunchKernelGGL((gemv_kernel<NB, PRO, FP8, RPW, UNR>), dim3(cdiv(N, 4 * RPW)), blk, sm, s, W, ldw, wscale, x, ldx, norm_w, eps, residual, ldr, y, ldy, N, K, out_f32); \
   } while (0)
-  // one row per wave for the smallest matrix (o_proj, 4096 x 4096: 1024 blocks instead of 256 - measured 9.1 vs 11.1 us), else four
-  if (B == 1 && !FP8 && (long)N * K <= 4096L * 4096L) { GEMV_LAUNCH(1, 1); LHRS_CHECK_LAUNCH("gemv"); return 0; }
-#define GEMV_CASE(NB) case NB: GEMV_LAUNCH(NB, 4); break;
+  if (B == 1 && !FP8) {
+    // HBM needs ~16 MB in flight chip-wide: few-row matrices (o_proj, down_proj: 4096 rows) get one row per wave (1024 blocks) and a
+    // 4-chunk K pipeline (down_proj 24.4 -> 20.6 us); the tall ones four rows per wave, two chunks deep (tools/gemv_bench.py sweep)
+    int rpw = N <= 4096 ? 1 : 4, unr = N <= 4096 ? 4 : 2;
+    if (g_gemv_rpw) { rpw = g_gemv_rpw; unr = g_gemv_unr; }
+    const int key = rpw * 10 + unr;
+    switch (key) {
+      case 11: GEMV_LAUNCH(1, 1, 1); break;
+      case 12: GEMV_LAUNCH(1, 1, 2); break;
+      case 14: GEMV_LAUNCH(1, 1, 4); break;
+      case 18: GEMV_LAUNCH(1, 1, 8); break;
+      case 22: GEMV_LAUNCH(1, 2, 2); break;
+      case 24: GEMV_LAUNCH(1, 2, 4); break;
+      case 42: GEMV_LAUNCH(1, 4, 2); break;
+      default: GEMV_LAUNCH(1, 4, 1); break;
+    }
+    LHRS_CHECK_LAUNCH("gemv");
+    return 0;
+  }
+#define GEMV_CASE(NB) case NB: GEMV_LAUNCH(NB, 4, 1); break;
   switch (B) { GEMV_CASE(1) GEMV_CASE(2) GEMV_CASE(3) GEMV_CASE(4) GEMV_CASE(5) GEMV_CASE(6) GEMV_CASE(7) GEMV_CASE(8) }
 #undef GEMV_CASE
 #undef GEMV_LAUNCH
@@ -715,6 +749,12 @@ extern "C" int lhrs_gemv(const void* W, long ldw, const float* wscale, int w_fp8
 #undef GO
     if (rc) return -1;
   }
+  return 0;
+}
+
+extern "C" int lhrs_gemv_set_tuning(int rows_per_wave, int chunks_per_iteration) {
+  g_gemv_rpw = rows_per_wave;
+  g_gemv_unr = chunks_per_iteration;
   return 0;
 }
 
