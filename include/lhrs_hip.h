@@ -218,12 +218,15 @@ int lhrs_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_
  * y[B, N] = xscale[b] * wscale[n] * (x8 . W8^T) (+ residual); B <= 16, K % 128 == 0; x8 / xscale from lhrs_quant_fp8_rows,
  * lhrs_rmsnorm_fwd_q or lhrs_swiglu_fwd_q */
 int lhrs_gemv_fp8_mfma(const void* W8, long ldw, const float* wscale, const void* x8, long ldx, const float* xscale,
-                       const void* residual, long ldr, void* y, long ldy, int B, int N, int K, int out_f32, void* stream);
+                       const void* residual, long ldr, void* y, long ldy, int B, int N, int K, int out_f32, int w_packed, void* stream);
 /* the same with bf16 activations and B <= 2: prologue (0 none, 1 RMSNorm, 2 SwiGLU over x = [B, 2K]) and the per-row e4m3 quantisation of
  * x happen inside the kernel (five launches per layer for a batch-1 token) */
 int lhrs_gemv_fp8_mfma_fused(const void* W8, long ldw, const float* wscale, const void* x, long ldx, int prologue, const void* norm_w,
                              float eps, const void* residual, long ldr, void* y, long ldy, int B, int N, int K, int out_f32,
-                             void* stream);
+                             int w_packed, void* stream);
+/* w_packed != 0 in the two calls above: W8 is the copy this makes - the e4m3 rows re-tiled into the MFMA operand order
+ * [N/16][K/128][2][64 lanes][16 B] (ceil(N/16)*16*K bytes), so that the decode weight stream is read as consecutive 1-KiB lines */
+int lhrs_repack_fp8_mfma(const void* W8, long ldw, void* out, int N, int K, void* stream);
 /* single-token attention for generate() (HF LlamaAttention with a KV cache at q_len = 1, reached from TextModal.generate,
  * lhrs/models/text_modal.py:586-627): RoPE of the new q / k row at device-resident position pos[b], append of (k, v) to the caches
  * [B * max_ctx, H*128] and attention over keys 0..pos[b] (optionally AND an HF attention_mask byte row), in ONE launch. */

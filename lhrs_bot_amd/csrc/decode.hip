@@ -247,110 +247,129 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
 
 // ------------------------------------------------------------------------------------------------------------------
 // gemv_fp8_mfma_kernel: e4m3 weights x e4m3 activations on the block-scaled MFMA (BASELINE configs[4]: "fp8 MFMA weights").
-// y[b][n] = sx[b] * sw[n] * sum_k x8[b][k] * W8[n][k] (+ residual) for 1..16 sequences.  16 output rows per block, the four waves
-// split the 128-k steps of K; a weight row is read as whole 128-B lines (lane (r, g) holds bytes [32g, 32g+32) of row r of the step)
-// straight into the A operand of v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales); x8 comes from L2 in the same layout.  The
-// VALU e4m3 GEMV spends ~2.5 instructions per weight byte and tops out at 1.2x the bf16 kernel; this one is one MFMA per 2 KiB.
+// y[b][n] = sx[b] * sw[n] * sum_k x8[b][k] * W8[n][k] (+ residual) for 1..16 sequences.  16 output rows per block; the eight waves
+// split the 128-k steps of K, four steps (8 KiB per wave) in flight, so that even the 4096-row projections (256 blocks) keep
+// ~16 MB outstanding chip-wide.  Lane (r, g) holds bytes [16g, 16g+16) and [64+16g, 64+16g+16) of row r of a step - a k permutation
+// applied to BOTH operands of v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales), which makes every load instruction read whole
+// 64-B segments of the 16 rows.  The VALU e4m3 GEMV spends ~2.5 instructions per weight byte; this one is one MFMA per 2 KiB.
+// PK: the weights were re-tiled by lhrs_repack_fp8_mfma into [N/16][K/128][2][64 lanes][16 B] - the operand order itself - so a wave
+// instruction reads 1 KiB of consecutive bytes and a wave's k-slice is one contiguous run (row-strided 64-B segments reach ~3.5 TB/s,
+// and a 4096-B row stride additionally camps on few channels; the tiled stream matches the bf16 GEMV's contiguous rows).
 // ------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+constexpr int GF_WAVES = 8, GF_THREADS = GF_WAVES * 64, GF_MAXC = 3;  // fused prologue: K <= GF_THREADS * GF_MAXC * 8 = 12288
 
 // PRO < 0: x8 / xscale come from global memory (already quantised; any batch <= 16).
 // PRO 0 / 1 / 2 (batch <= 2): x is bf16; the block applies the prologue (copy / RMSNorm / SwiGLU) AND the per-row e4m3 quantisation
-// itself while the first weight lines are in flight - every block recomputes the same few KB, which keeps the decode step at five
-// launches per layer (launch gaps, not bytes, dominate a batch-1 token).
-template <int PRO>
-__global__ __launch_bounds__(256) void gemv_fp8_mfma_kernel(const uint8_t* __restrict__ W, long ldw, const float* __restrict__ wscale,
-                                                            const void* __restrict__ xin, long ldx, const float* __restrict__ xscale,
-                                                            const bf16_t* __restrict__ norm_w, float eps, const bf16_t* res, long ldr,
-                                                            void* y, long ldy, int NB, int N, int K, int out_f32) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // PRO >= 0: [NB][K] bf16 staging, then [NB][K] e4m3 bytes
-  __shared__ float part[4][16][17];
-  __shared__ float red[4];
+// itself while the first weight lines are in flight - the row stays in registers between the reductions, only the e4m3 bytes go to
+// LDS.  Every block recomputes the same few KB, which keeps the decode step at five launches per layer.
+template <int PRO, bool PK>
+__global__ __launch_bounds__(GF_THREADS) void gemv_fp8_mfma_kernel(const uint8_t* __restrict__ W, long ldw, const float* __restrict__ wscale,
+                                                                   const void* __restrict__ xin, long ldx, const float* __restrict__ xscale,
+                                                                   const bf16_t* __restrict__ norm_w, float eps, const bf16_t* res, long ldr,
+                                                                   void* y, long ldy, int NB, int N, int K, int out_f32) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // PRO >= 0: [NB][K] e4m3 bytes
+  __shared__ float part[GF_WAVES][16][17];
+  __shared__ float red[GF_WAVES];
   __shared__ float s_scale[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
   const int row0 = blockIdx.x * 16;
-  const int nsteps = K / 128, per = (nsteps + 3) / 4;
-  const int s_begin = wave * per, s_end = min(nsteps, s_begin + per);
-  const uint8_t* wp = W + (long)min(row0 + fr, N - 1) * ldw + fg * 32;
-  constexpr int U = 2;  // 128-k steps in flight per wave (2 x 32 B of weights per lane each)
+  const int nsteps = K / 128, per = (nsteps + GF_WAVES - 1) / GF_WAVES;
+  const int s_begin = min(wave * per, nsteps), s_end = min(nsteps, s_begin + per);
+  const uint8_t* wp = PK ? W + (long)blockIdx.x * nsteps * 2048 + lane * 16 : W + (long)min(row0 + fr, N - 1) * ldw + fg * 16;
+  constexpr long WSTEP = PK ? 2048 : 128, WHALF = PK ? 1024 : 64;
+  constexpr int U = 4;  // 128-k steps in flight per wave (2 x 16 B of weights per lane each)
   i32x4 wlo[U], whi[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {  // first weight lines before the prologue
-    const long o = (long)min(s_begin + u, max(s_end - 1, s_begin)) * 128;
+    const long o = (long)min(s_begin + u, max(s_end - 1, 0)) * WSTEP;
     wlo[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + o));
-    whi[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + o + 16));
+    whi[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + o + WHALF));
   }
   const uint8_t* xp;
-  float my_xscale = 1.f;
   if (PRO >= 0) {
-    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
-    uint8_t* x8s = reinterpret_cast<uint8_t*>(smem) + (size_t)NB * K * 2;
+    uint8_t* x8s = reinterpret_cast<uint8_t*>(smem);
     const bf16_t* x = reinterpret_cast<const bf16_t*>(xin);
     const int nch = K / 8;
     for (int b = 0; b < NB; ++b) {
+      float v[GF_MAXC][8], g[GF_MAXC][8];
       float q = 0.f;
-      for (int c = tid; c < nch; c += 256) {
-        uint4 v = *reinterpret_cast<const uint4*>(x + b * ldx + c * 8);
-        if (PRO == 2) {
-          const uint4 u = *reinterpret_cast<const uint4*>(x + b * ldx + K + c * 8);
-          v.x = pack2bf(silu(bflo(v.x)) * bflo(u.x), silu(bfhi(v.x)) * bfhi(u.x));
-          v.y = pack2bf(silu(bflo(v.y)) * bflo(u.y), silu(bfhi(v.y)) * bfhi(u.y));
-          v.z = pack2bf(silu(bflo(v.z)) * bflo(u.z), silu(bfhi(v.z)) * bfhi(u.z));
-          v.w = pack2bf(silu(bflo(v.w)) * bflo(u.w), silu(bfhi(v.w)) * bfhi(u.w));
-        }
-        *reinterpret_cast<uint4*>(xs + b * K + c * 8) = v;
-        if (PRO == 1)
-          q += bflo(v.x) * bflo(v.x) + bfhi(v.x) * bfhi(v.x) + bflo(v.y) * bflo(v.y) + bfhi(v.y) * bfhi(v.y) + bflo(v.z) * bflo(v.z) +
-               bfhi(v.z) * bfhi(v.z) + bflo(v.w) * bflo(v.w) + bfhi(v.w) * bfhi(v.w);
-      }
-      float rstd = 1.f;
-      if (PRO == 1) rstd = rsqrtf(block_sum<4>(q, red) / (float)K + eps);
-      __syncthreads();
-      float m = 0.f;  // final bf16 values of the row (same rounding as the stand-alone kernels) and their |max|
-      for (int c = tid; c < nch; c += 256) {
-        float v[8];
-        unpack8(*reinterpret_cast<const uint4*>(xs + b * K + c * 8), v);
-        if (PRO == 1) {
-          float g[8];
-          unpack8(*reinterpret_cast<const uint4*>(norm_w + c * 8), g);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(g[e] * bf2f(f2bf(v[e] * rstd))));
-          *reinterpret_cast<uint4*>(xs + b * K + c * 8) = pack8(v);
-        }
+      for (int i = 0; i < GF_MAXC; ++i) {
+        const int c = tid + i * GF_THREADS;
+        if (c < nch) {
+          uint4 t = *reinterpret_cast<const uint4*>(x + b * ldx + c * 8);
+          if (PRO == 2) {
+            const uint4 u = *reinterpret_cast<const uint4*>(x + b * ldx + K + c * 8);
+            t.x = pack2bf(silu(bflo(t.x)) * bflo(u.x), silu(bfhi(t.x)) * bfhi(u.x));
+            t.y = pack2bf(silu(bflo(t.y)) * bflo(u.y), silu(bfhi(t.y)) * bfhi(u.y));
+            t.z = pack2bf(silu(bflo(t.z)) * bflo(u.z), silu(bfhi(t.z)) * bfhi(u.z));
+            t.w = pack2bf(silu(bflo(t.w)) * bflo(u.w), silu(bfhi(t.w)) * bfhi(u.w));
+          }
+          unpack8(t, v[i]);
+          if (PRO == 1) {
+            unpack8(*reinterpret_cast<const uint4*>(norm_w + c * 8), g[i]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+            for (int e = 0; e < 8; ++e) q += v[i][e] * v[i][e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        }
       }
-      m = block_max<4>(m, red);
+      if (PRO == 1) {
+        const float rstd = rsqrtf(block_sum<GF_WAVES>(q, red) / (float)K + eps);
+#pragma unroll
+        for (int i = 0; i < GF_MAXC; ++i)
+          if (tid + i * GF_THREADS < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = bf2f(f2bf(g[i][e] * bf2f(f2bf(v[i][e] * rstd))));  // HF LlamaRMSNorm roundings
+          }
+      }
+      float m = 0.f;
+#pragma unroll
+      for (int i = 0; i < GF_MAXC; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[i][e]));
+      m = block_max<GF_WAVES>(m, red);
       const float sc = m > 0.f ? m / 448.f : 1.f;
       if (tid == 0) s_scale[b] = sc;
       const float inv = 1.f / sc;
-      for (int c = tid; c < nch; c += 256) {
-        float v[8];
-        unpack8(*reinterpret_cast<const uint4*>(xs + b * K + c * 8), v);
-        int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, 0, false);
-        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, lo, true);
-        int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, 0, false);
-        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, hi, true);
-        *reinterpret_cast<int2*>(x8s + (size_t)b * K + c * 8) = make_int2(lo, hi);
+#pragma unroll
+      for (int i = 0; i < GF_MAXC; ++i) {
+        const int c = tid + i * GF_THREADS;
+        if (c < nch) {
+          int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][0] * inv, v[i][1] * inv, 0, false);
+          lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][2] * inv, v[i][3] * inv, lo, true);
+          int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][4] * inv, v[i][5] * inv, 0, false);
+          hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][6] * inv, v[i][7] * inv, hi, true);
+          *reinterpret_cast<int2*>(x8s + (size_t)b * K + c * 8) = make_int2(lo, hi);
+        }
       }
     }
     __syncthreads();
-    xp = x8s + (size_t)min(fr, NB - 1) * K + fg * 32;
+    xp = x8s + (size_t)min(fr, NB - 1) * K + fg * 16;
   } else {
-    xp = reinterpret_cast<const uint8_t*>(xin) + (long)min(fr, NB - 1) * ldx + fg * 32;
+    xp = reinterpret_cast<const uint8_t*>(xin) + (long)min(fr, NB - 1) * ldx + fg * 16;
   }
   const bool live = fr < NB;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int s0 = s_begin; s0 < s_end; s0 += U) {
+    const bool more = s0 + U < s_end;  // wave-uniform
     i32x4 wnlo[U], wnhi[U], xlo[U], xhi[U];
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long on = (long)min(s0 + U + u, s_end - 1) * WSTEP;
+        wnlo[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + on));
+        wnhi[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + on + WHALF));
+      }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long on = (long)min(s0 + U + u, s_end - 1) * 128;
-      wnlo[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + on));
-      wnhi[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + on + 16));
       const long o = (long)min(s0 + u, s_end - 1) * 128;
       xlo[u] = *reinterpret_cast<const i32x4*>(xp + o);
-      xhi[u] = *reinterpret_cast<const i32x4*>(xp + o + 16);
+      xhi[u] = *reinterpret_cast<const i32x4*>(xp + o + 64);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -361,21 +380,42 @@ __global__ __launch_bounds__(256) void gemv_fp8_mfma_kernel(const uint8_t* __res
         acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
       }
     }
+    if (more) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) { wlo[u] = wnlo[u]; whi[u] = wnhi[u]; }
+      for (int u = 0; u < U; ++u) { wlo[u] = wnlo[u]; whi[u] = wnhi[u]; }
+    }
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) part[wave][fg * 4 + r][fr] = acc[r];
   __syncthreads();
   const int i = tid >> 4, b = tid & 15;
   const int row = row0 + i;
-  if (b < NB && row < N) {
+  if (tid < 256 && b < NB && row < N) {
     const float xs_b = PRO >= 0 ? s_scale[b] : xscale[b];
-    float v = (part[0][i][b] + part[1][i][b] + part[2][i][b] + part[3][i][b]) * wscale[row] * xs_b;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < GF_WAVES; ++w) v += part[w][i][b];
+    v *= wscale[row] * xs_b;
     if (res) v += bf2f(res[b * ldr + row]);
     if (out_f32) reinterpret_cast<float*>(y)[b * ldy + row] = v;
     else reinterpret_cast<bf16_t*>(y)[b * ldy + row] = f2bf(v);
   }
+}
+
+// e4m3 [N, ldw] rows -> the tiled operand order of gemv_fp8_mfma_kernel<*, true>: piece p = ((rg * K/128 + step) * 2 + half) * 64 + lane
+// holds bytes [64 half + 16 (lane >> 4), +16) of step `step` of row 16 rg + (lane & 15); rows past N are zero.
+__global__ __launch_bounds__(256) void repack_fp8_mfma_kernel(const uint8_t* __restrict__ W, long ldw, uint8_t* __restrict__ out, int N, int K) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  const int nsteps = K / 128;
+  const long total = (long)((N + 15) / 16) * nsteps * 128;
+  if (p >= total) return;
+  const int lane = (int)(p & 63), half = (int)((p >> 6) & 1);
+  const long t = p >> 7;
+  const int step = (int)(t % nsteps);
+  const long row = (t / nsteps) * 16 + (lane & 15);
+  i32x4 v = {0, 0, 0, 0};
+  if (row < N) v = *reinterpret_cast<const i32x4*>(W + row * ldw + (long)step * 128 + half * 64 + (lane >> 4) * 16);
+  *reinterpret_cast<i32x4*>(out + p * 16) = v;
 }
 
 // per-row e4m3 quantisation: scale[n] = max|W[n,:]| / 448, W8 = round(W / scale).  One block per row, 16-B loads; the row stays in
@@ -836,13 +876,18 @@ extern "C" int lhrs_decode_attn(const void* qkv, long ld, void* kcache, void* vc
 }
 
 // y[B, N] = sx[b] * sw[n] * (x8[B, K] . W8[N, K]^T) (+ residual[B, N]): e4m3 weights AND activations (lhrs_quant_fp8_rows /
-// lhrs_rmsnorm_fwd_q / lhrs_swiglu_fwd_q) on the block-scaled MFMA; B <= 16, K % 128 == 0.
+// lhrs_rmsnorm_fwd_q / lhrs_swiglu_fwd_q) on the block-scaled MFMA; B <= 16, K % 128 == 0.  w_packed: W8 is the tiled copy
+// lhrs_repack_fp8_mfma made (ldw unused).
 extern "C" int lhrs_gemv_fp8_mfma(const void* W8, long ldw, const float* wscale, const void* x8, long ldx, const float* xscale,
-                                  const void* residual, long ldr, void* y, long ldy, int B, int N, int K, int out_f32, void* stream) {
+                                  const void* residual, long ldr, void* y, long ldy, int B, int N, int K, int out_f32, int w_packed,
+                                  void* stream) {
   LHRS_REQUIRE(B >= 1 && B <= 16 && N > 0 && K >= 128 && K % 128 == 0, "gemv_fp8_mfma: B=%d N=%d K=%d", B, N, K);
-  LHRS_REQUIRE(ldw % 16 == 0 && ldx % 16 == 0 && wscale && xscale, "gemv_fp8_mfma: strides / scales");
-  hipLaunchKernelGGL((gemv_fp8_mfma_kernel<-1>), dim3(cdiv(N, 16)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)W8, ldw, wscale, x8, ldx,
-                     xscale, (const bf16_t*)nullptr, 0.f, (const bf16_t*)residual, ldr, y, ldy, B, N, K, out_f32);
+  LHRS_REQUIRE((w_packed || ldw % 16 == 0) && ldx % 16 == 0 && wscale && xscale, "gemv_fp8_mfma: strides / scales");
+#define GOP(PK)                                                                                                                      \
+  hipLaunchKernelGGL((gemv_fp8_mfma_kernel<-1, PK>), dim3(cdiv(N, 16)), dim3(GF_THREADS), 0, (hipStream_t)stream, (const uint8_t*)W8, ldw, \
+                     wscale, x8, ldx, xscale, (const bf16_t*)nullptr, 0.f, (const bf16_t*)residual, ldr, y, ldy, B, N, K, out_f32)
+  if (w_packed) GOP(true); else GOP(false);
+#undef GOP
   LHRS_CHECK_LAUNCH("gemv_fp8_mfma");
   return 0;
 }
@@ -851,21 +896,33 @@ extern "C" int lhrs_gemv_fp8_mfma(const void* W8, long ldw, const float* wscale,
 // inside the kernel; B <= 2 (every block redoes it: the batch-1 decode step stays at five launches per layer)
 extern "C" int lhrs_gemv_fp8_mfma_fused(const void* W8, long ldw, const float* wscale, const void* x, long ldx, int prologue, const void* norm_w,
                                         float eps, const void* residual, long ldr, void* y, long ldy, int B, int N, int K, int out_f32,
-                                        void* stream) {
+                                        int w_packed, void* stream) {
   LHRS_REQUIRE(B >= 1 && B <= 2 && N > 0 && K >= 128 && K % 128 == 0, "gemv_fp8_mfma_fused: B=%d (1..2) N=%d K=%d", B, N, K);
-  LHRS_REQUIRE(ldw % 16 == 0 && ldx % 8 == 0 && wscale && prologue >= 0 && prologue <= 2 && (prologue != 1 || norm_w), "gemv_fp8_mfma_fused: args");
-  const size_t sm = (size_t)B * K * 3;
-  LHRS_REQUIRE(sm <= 150 * 1024, "gemv_fp8_mfma_fused: B * K * 3 = %zu bytes of LDS", sm);
-  const dim3 grid(cdiv(N, 16)), blk(256);
+  LHRS_REQUIRE((w_packed || ldw % 16 == 0) && ldx % 8 == 0 && wscale && prologue >= 0 && prologue <= 2 && (prologue != 1 || norm_w),
+               "gemv_fp8_mfma_fused: args");
+  LHRS_REQUIRE(K <= GF_THREADS * GF_MAXC * 8, "gemv_fp8_mfma_fused: K=%d exceeds the %d values the prologue keeps in registers", K, GF_THREADS * GF_MAXC * 8);
+  const size_t sm = (size_t)B * K;
+  const dim3 grid(cdiv(N, 16)), blk(GF_THREADS);
   hipStream_t s = (hipStream_t)stream;
-#define GOF(P)                                                                                                                        \
+#define GOF(P, PK)                                                                                                                    \
   do {                                                                                                                                \
-    if (sm > 65536) (void)hipFuncSetAttribute((const void*)gemv_fp8_mfma_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-    hipLaunchKernelGGL((gemv_fp8_mfma_kernel<P>), grid, blk, sm, s, (const uint8_t*)W8, ldw, wscale, x, ldx, (const float*)nullptr,  \
+    if (sm > 65536) (void)hipFuncSetAttribute((const void*)gemv_fp8_mfma_kernel<P, PK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+    hipLaunchKernelGGL((gemv_fp8_mfma_kernel<P, PK>), grid, blk, sm, s, (const uint8_t*)W8, ldw, wscale, x, ldx, (const float*)nullptr, \
                        (const bf16_t*)norm_w, eps, (const bf16_t*)residual, ldr, y, ldy, B, N, K, out_f32);                          \
   } while (0)
-  if (prologue == 0) GOF(0); else if (prologue == 1) GOF(1); else GOF(2);
+  if (w_packed) { if (prologue == 0) GOF(0, true); else if (prologue == 1) GOF(1, true); else GOF(2, true); }
+  else { if (prologue == 0) GOF(0, false); else if (prologue == 1) GOF(1, false); else GOF(2, false); }
 #undef GOF
   LHRS_CHECK_LAUNCH("gemv_fp8_mfma_fused");
+  return 0;
+}
+
+// W8 [N, ldw] e4m3 rows -> out: ceil(N/16) * 16 * K bytes in the operand order of the MFMA GEMV (see repack_fp8_mfma_kernel)
+extern "C" int lhrs_repack_fp8_mfma(const void* W8, long ldw, void* out, int N, int K, void* stream) {
+  LHRS_REQUIRE(N > 0 && K >= 128 && K % 128 == 0 && ldw % 16 == 0, "repack_fp8_mfma: N=%d K=%d ldw=%ld", N, K, ldw);
+  const long total = (long)cdiv(N, 16) * (K / 128) * 128;
+  hipLaunchKernelGGL(repack_fp8_mfma_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)W8, ldw,
+                     (uint8_t*)out, N, K);
+  LHRS_CHECK_LAUNCH("repack_fp8_mfma");
   return 0;
 }

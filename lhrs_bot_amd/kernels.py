@@ -514,23 +514,46 @@ def gemv_fused(W, x, out, K, *, wscale=None, prologue=PRO_NONE, norm_w=None, eps
     return out
 
 
+class PackedFp8:
+    """e4m3 weight [N, K] re-tiled by `repack_fp8_mfma` into the operand order of the MFMA GEMV (decode weight stream)."""
+
+    def __init__(self, data, N, K):
+        self.data, self.N, self.K = data, N, K
+        self.shape = (N, K)
+
+
+def repack_fp8_mfma(W8) -> PackedFp8:
+    N, K = W8.shape
+    out = torch.empty((N + 15) // 16 * 16 * K, device=W8.device, dtype=torch.uint8)
+    _lib.check(_L().lhrs_repack_fp8_mfma(W8.data_ptr(), W8.stride(0), out.data_ptr(), N, K, _stream()), "repack_fp8_mfma")
+    return PackedFp8(out, N, K)
+
+
+def _w8(W8):  # -> (ptr, ldw, N, packed)
+    if isinstance(W8, PackedFp8):
+        return W8.data.data_ptr(), 0, W8.N, 1
+    return W8.data_ptr(), W8.stride(0), W8.shape[0], 0
+
+
 def gemv_fp8_mfma(W8, wscale, x8, xscale, out, *, residual=None, out_f32=False):
-    """out[B, N] = xscale[:, None] * wscale[None, :] * (x8 @ W8^T) (+ residual): e4m3 weights and activations on the scaled MFMA."""
+    """out[B, N] = xscale[:, None] * wscale[None, :] * (x8 @ W8^T) (+ residual): e4m3 weights and activations on the scaled MFMA.
+    W8: uint8 [N, K] rows or a PackedFp8."""
     B, K = x8.shape
-    N = W8.shape[0]
-    st = _L().lhrs_gemv_fp8_mfma(W8.data_ptr(), W8.stride(0), wscale.data_ptr(), x8.data_ptr(), x8.stride(0), xscale.data_ptr(),
+    wp, ldw, N, pk = _w8(W8)
+    st = _L().lhrs_gemv_fp8_mfma(wp, ldw, wscale.data_ptr(), x8.data_ptr(), x8.stride(0), xscale.data_ptr(),
                                  _p(residual), residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0), B, N, K,
-                                 int(out_f32), _stream())
+                                 int(out_f32), pk, _stream())
     _lib.check(st, "gemv_fp8_mfma")
     return out
 
 
 def gemv_fp8_mfma_fused(W8, wscale, x, out, K, *, prologue=PRO_NONE, norm_w=None, eps=1e-5, residual=None, out_f32=False):
     """batch <= 2: out = (e4m3(pro(x)) @ W8^T) * scales (+ residual), prologue and activation quantisation inside the kernel."""
-    B, N = x.shape[0], W8.shape[0]
-    st = _L().lhrs_gemv_fp8_mfma_fused(W8.data_ptr(), W8.stride(0), wscale.data_ptr(), x.data_ptr(), x.stride(0), prologue, _p(norm_w),
+    B = x.shape[0]
+    wp, ldw, N, pk = _w8(W8)
+    st = _L().lhrs_gemv_fp8_mfma_fused(wp, ldw, wscale.data_ptr(), x.data_ptr(), x.stride(0), prologue, _p(norm_w),
                                        float(eps), _p(residual), residual.stride(0) if residual is not None else 0, out.data_ptr(),
-                                       out.stride(0), B, N, K, int(out_f32), _stream())
+                                       out.stride(0), B, N, K, int(out_f32), pk, _stream())
     _lib.check(st, "gemv_fp8_mfma_fused")
     return out
 

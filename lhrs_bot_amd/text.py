@@ -452,6 +452,17 @@ class TextModal:
                 L[k + "8"], L[k + "8s"] = hk.quant_fp8_rows(L[k])
         self.p["lm_head8"], self.p["lm_head8s"] = hk.quant_fp8_rows(self.p["lm_head"])
 
+    def pack_fp8_decode(self):
+        """Decode-only copies of the e4m3 weights in the MFMA GEMV's operand order (hk.repack_fp8_mfma): the batch-1 weight stream then
+        reads consecutive 1-KiB lines instead of 64-B segments of 16 strided rows (+6.7 GB of HBM next to the row-major copies that
+        the prefill / training GEMMs use)."""
+        if "qkv_w8" not in self.p["layers"][0]:
+            self.quantize_fp8()
+        for L in self.p["layers"]:
+            for k in ("qkv_w", "o_w", "gu_w", "down_w"):
+                L[k + "8p"] = hk.repack_fp8_mfma(L[k + "8"])
+        self.p["lm_head8p"] = hk.repack_fp8_mfma(self.p["lm_head8"])
+
     def quantize_base(self, bits: int = 8):
         """`bits: 8` of Config/multi_modal_stage{2,3}.yaml (text_modal.py:91-131: the reference loads the frozen LLaMA through
         bitsandbytes LLM.int8 for stages 2/3).  MI355X-native equivalent: every decoder linear (lm_head stays bf16, as bitsandbytes
@@ -493,11 +504,11 @@ class TextModal:
         scale = 1.0 / math.sqrt(hd)
 
         fp8 = weights == "fp8"
-        if fp8 and "qkv_w8" not in self.p["layers"][0]:
-            self.quantize_fp8()
+        if fp8 and "qkv_w8p" not in self.p["layers"][0]:
+            self.pack_fp8_decode()
 
         def W(L, name):  # (weight, per-row scale or None)
-            return (L[name + "8"], L[name + "8s"]) if fp8 else (L[name], None)
+            return (L[name + "8p"], L[name + "8s"]) if fp8 else (L[name], None)
 
         batched = B >= 4 and not fp8  # the MFMA weight stream reads x from L2: norm / SwiGLU run once, not once per block (pays from batch 4)
         if batched:
@@ -543,7 +554,7 @@ class TextModal:
                 lin(*W(L, "o_w"), s.o, x2, d, residual=x)
                 lin(*W(L, "gu_w"), x2, s.gu, d, hk.PRO_RMSNORM, L["ln2_w"])
                 lin(*W(L, "down_w"), s.gu, x, ff, hk.PRO_SWIGLU, residual=x2)
-            w, sc = (self.p["lm_head8"], self.p["lm_head8s"]) if fp8 else (self.p["lm_head"], None)
+            w, sc = (self.p["lm_head8p"], self.p["lm_head8s"]) if fp8 else (self.p["lm_head"], None)
             lin(w, sc, x, s.logits, d, hk.PRO_RMSNORM, self.p["norm_w"], out_f32=True)
 
         s.enqueue = enqueue

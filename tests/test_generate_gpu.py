@@ -140,9 +140,15 @@ def test_fp8_weight_decode_and_fused_prologues():
         hk.gemv_fp8_mfma(w8, ws, a8, as_, out, residual=rs, out_f32=True)
         ref = (a8.view(torch.float8_e4m3fn).float() * as_[:, None]) @ (w8.view(torch.float8_e4m3fn).float() * ws[:, None]).t() + rs.float()
         assert rel(out, ref) < 1e-4, Bn
+        w8p = hk.repack_fp8_mfma(w8)  # tiled operand order of the decode weight stream: same products, same order
+        outp = torch.empty_like(out)
+        hk.gemv_fp8_mfma(w8p, ws, a8, as_, outp, residual=rs, out_f32=True)
+        assert torch.equal(outp, out), Bn
         if Bn <= 2:  # in-kernel quantisation == stand-alone quantisation, bit for bit
             out2 = torch.empty_like(out)
             hk.gemv_fp8_mfma_fused(w8, ws, xs, out2, 11008, residual=rs, out_f32=True)
+            assert torch.equal(out2, out)
+            hk.gemv_fp8_mfma_fused(w8p, ws, xs, out2.zero_(), 11008, residual=rs, out_f32=True)
             assert torch.equal(out2, out)
 
 

@@ -16,4 +16,4 @@ t0 = time.perf_counter()
 out = model.generate(ids, images=rgb, do_sample=False, max_new_tokens=new, weights=weights)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print(f"[{weights}, batch {B}] {B}x{new} new tokens in {dt:.3f}s = {B*new/dt:.1f} tok/s (incl. ViT+pooler+prefill of {60-1+144} positions); HBM roofline 13.5 GB/token @ 8 TB/s = 590 tok/s")
+print(f"[{weights}, batch {B}] {B}x{new} new tokens in {dt:.3f}s = {B*new/dt:.1f} tok/s (incl. ViT+pooler+prefill of {60-1+144} positions); HBM roofline " + ("6.74 GB/token @ 8 TB/s = 1190 tok/s" if weights == "fp8" else "13.5 GB/token @ 8 TB/s = 590 tok/s") + " per sequence")
