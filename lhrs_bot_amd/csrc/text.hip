@@ -142,28 +142,48 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__
   if (threadIdx.x == 0) *out = s * scale;
 }
 
-// greedy pick: index of the first maximum of each fp32 row (HF argmax tie rule: lowest index)
-__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, long ld, long* __restrict__ out, int V) {
-  __shared__ float sv[4];
-  __shared__ int si[4];
+// greedy pick: index of the first maximum of each fp32 row (HF argmax tie rule: lowest index).  One 16-wave block per row; a thread
+// requests eight 16-B pieces before comparing any (the row was just written by other CUs: a dependent-load loop pays one L2 round trip
+// per element - 39 us for 32000 logits - instead of one for all of them).
+constexpr int AM_THREADS = 1024, AM_UNROLL = 8;
+__device__ __forceinline__ void am_take(float v, int i, float& best, int& bi) {
+  if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+}
+__global__ __launch_bounds__(AM_THREADS) void argmax_rows_kernel(const float* __restrict__ x, long ld, long* __restrict__ out, int V, int vec) {
+  __shared__ float sv[AM_THREADS / 64];
+  __shared__ int si[AM_THREADS / 64];
   const float* row = x + (long)blockIdx.x * ld;
   float best = -__builtin_huge_valf();
   int bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < V; i += 256) {
-    const float v = row[i];
-    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  if (vec) {
+    const int nv = V / 4;
+    for (int c0 = threadIdx.x; c0 < nv; c0 += AM_THREADS * AM_UNROLL) {
+      float4 t[AM_UNROLL];
+#pragma unroll
+      for (int u = 0; u < AM_UNROLL; ++u) {
+        const int c = c0 + u * AM_THREADS;
+        t[u] = c < nv ? *reinterpret_cast<const float4*>(row + (long)c * 4) : make_float4(best, best, best, best);
+      }
+#pragma unroll
+      for (int u = 0; u < AM_UNROLL; ++u) {
+        const int i = (c0 + u * AM_THREADS) * 4;
+        if (i < V) { am_take(t[u].x, i, best, bi); am_take(t[u].y, i + 1, best, bi); am_take(t[u].z, i + 2, best, bi); am_take(t[u].w, i + 3, best, bi); }
+      }
+    }
+    for (int i = nv * 4 + threadIdx.x; i < V; i += AM_THREADS) am_take(row[i], i, best, bi);
+  } else {
+    for (int i = threadIdx.x; i < V; i += AM_THREADS) am_take(row[i], i, best, bi);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const float ov = __shfl_xor(best, o, 64);
     const int oi = __shfl_xor(bi, o, 64);
-    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    am_take(ov, oi, best, bi);
   }
   if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; ++w)
-      if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+    for (int w = 1; w < AM_THREADS / 64; ++w) am_take(sv[w], si[w], best, bi);
     out[blockIdx.x] = bi;
   }
 }
@@ -172,7 +192,8 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
 
 extern "C" int lhrs_argmax_rows(const float* x, long ld, long* out, int n, int V, void* stream) {
   LHRS_REQUIRE(n > 0 && V > 0, "argmax_rows: n=%d V=%d", n, V);
-  hipLaunchKernelGGL(argmax_rows_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, x, ld, out, V);
+  const int vec = ld % 4 == 0 && ((uintptr_t)x & 15) == 0;  // 16-B aligned rows
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(n), dim3(AM_THREADS), 0, (hipStream_t)stream, x, ld, out, V, vec);
   LHRS_CHECK_LAUNCH("argmax_rows");
   return 0;
 }

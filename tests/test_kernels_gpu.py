@@ -433,3 +433,18 @@ def test_gemm_nt_skinny_split_k(M, N, K):
     y = hk.gemm_nt_skinny(a, b, alpha=2.0)
     ref = 2.0 * (a.float() @ b.float().t())
     assert y.shape == (M, N) and rel_err(y, ref) < 4e-3
+
+
+@pytest.mark.parametrize("V,ld", [(32000, 32000), (32003, 32003), (32000, 32004), (257, 260), (5, 5)])
+def test_argmax_rows_first_maximum(V, ld):
+    """HF greedy pick: the LOWEST index among equal maxima; aligned (16-B vector loads) and unaligned rows, ties across threads."""
+    g = torch.Generator().manual_seed(V)
+    n = 3
+    buf = torch.randn(n, ld, generator=g)
+    x = buf[:, :V]
+    x[0, [V - 1, V // 2, 3 % V]] = 9.0        # three equal maxima: the first one wins
+    x[1, :] = -1.5                             # a constant row: index 0
+    x[2, V - 1] = 50.0                         # the very last element
+    want = torch.from_numpy(x.numpy().argmax(-1))
+    got = hk.argmax_rows(buf.to("cuda")[:, :V])
+    assert torch.equal(got.cpu(), want), (got, want)
