@@ -82,6 +82,13 @@ int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int ldw, const
                          int K2, void* gu, int ld_gu, void* act, int ld_act, int M, int ff, int K, void* stream);
 int lhrs_gemm_swiglu_bwd(const void* dY, int ldy, const void* WdT, int ldw, const void* A2, int lda2, const void* B2, int ldb2,
                          int K2, const void* gu, void* dgu, int ld_gu, void* dact_scratch, int M, int ff, int K, void* stream);
+/* qkv projection with the RoPE of its q / k heads in the GEMM epilogue (HF LlamaAttention.forward: apply_rotary_pos_emb on
+ * q_proj / k_proj outputs, rotate_half convention; text_modal.py:258-294): C[M, N] = X.W^T (+ A2.B2^T); the heads of width
+ * head_dim in columns [0, rope_cols) are rotated with position m %% pos_mod + pos0 of their row (cos / sin fp32 [pos][head_dim/2]),
+ * the other columns are stored as computed.  Bit-identical to lhrs_gemm_bf16_nt(_lora) + lhrs_rope, which is also the fallback. */
+int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw, const void* A2, int lda2, const void* B2, int ldb2, int K2,
+                       void* C, int ldc, int M, int N, int K, const float* cos_t, const float* sin_t, int pos_mod, int pos0,
+                       int rope_cols, int head_dim, void* stream);
 /* peft lora_dropout (lora.Linear.forward: lora_B(lora_A(dropout(x))); p = 0.05 in Config/multi_modal_stage2.yaml, train mode only).
  * out = dropout(x) with a counter-based mask over the element index (regenerated identically by the backward), and the masked product
  * C = mask * (alpha * A.B^T) / (1 - p) + residual the dX path needs (dx = dy.W + mask * (s dy B A) / (1 - p)). */

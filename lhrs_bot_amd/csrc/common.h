@@ -89,6 +89,13 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return t;
 }
 
+// HF rotate_half RoPE of one (x[d], x[d + D/2]) pair; separately rounded products so that every kernel that rotates agrees bit for bit
+__device__ __forceinline__ void rope_pair(float a, float b, float co, float si, float& o1, float& o2) {
+#pragma clang fp contract(off)
+  o1 = a * co - b * si;
+  o2 = b * co + a * si;
+}
+
 // ---- activations --------------------------------------------------------------------------------
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }

@@ -69,9 +69,7 @@ __global__ void rope_kernel(bf16_t* x, long ld, int rows, int nheads, int D, con
     const float* sn = sin_t + (long)pos * half + c * 8;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float co = cs[i], si = sn[i] * sin_sign;
-      o1[i] = a[i] * co - b[i] * si;
-      o2[i] = b[i] * co + a[i] * si;
+      rope_pair(a[i], b[i], cs[i], sn[i] * sin_sign, o1[i], o2[i]);
     }
     *reinterpret_cast<uint4*>(p1) = pack8(o1);
     *reinterpret_cast<uint4*>(p2) = pack8(o2);

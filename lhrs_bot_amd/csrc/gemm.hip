@@ -55,6 +55,11 @@ struct GemmArgs {
   // dropout mask on alpha * A.B^T BEFORE bias / residual (LoRA dX path: dx = dy.W + mask * (U.A) / (1 - p)); drop_thresh = 0 -> off
   float drop_scale;
   unsigned drop_seed, drop_thresh;
+  // EPI 3 (fused RoPE of the q / k heads of a qkv projection, head_dim 128): fp32 cos / sin tables [pos][64], position of row m =
+  // m % rope_mod + rope_pos0, columns [0, rope_cols) are rotated (rope_cols % 256 == 0), the rest stored as computed
+  const float* rope_cos;
+  const float* rope_sin;
+  int rope_mod, rope_pos0, rope_cols;
   // split-K of the small-tile kernel (skinny-N products): block (x, y) reduces K-slice y of length ksplit into f32 slab y of C
   int ksplit;
 };
@@ -827,6 +832,10 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256r_kernel(GemmArgs g) {
       const int r = ridx * 8 + (lane >> 3);
       row = ((r >> 5) & 1) * g.ff + tn * 128 + (r >> 6) * 32 + (r & 31);
     }
+    if (EPI == 3 && !isA && tn * BN < g.rope_cols) {  // B tile row r = 64*wn + 32*half + i  <-  head 2*tn + (wn >> 1), dim 64*half + 32*(wn & 1) + i
+      const int r = ridx * 8 + (lane >> 3);
+      row = tn * BN + ((r >> 7) << 7) + ((r >> 5) & 1) * 64 + ((r >> 6) & 1) * 32 + (r & 31);
+    }
     off1[j] = (unsigned)(((long)row * ld1 + lchunk * 8) * 2);
     off2[j] = g.K2 > 0 ? (unsigned)(((long)row * ld2 + lchunk * 8) * 2) : 0u;
   }
@@ -925,7 +934,30 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256r_kernel(GemmArgs g) {
   }
   __builtin_amdgcn_s_barrier();
   char* reg = smem + wave * 8192;  // [64 rows][64 cols] bf16, wave private
-  {
+  const bool rope_tile = EPI == 3 && tn * BN < g.rope_cols;
+  if (rope_tile) {
+    // acc[mi][0] holds dims d = 32*(wn & 1) + j of the head, acc[mi][1] their rotate_half partners d + 64: rotate the bf16-rounded
+    // projections exactly like the stand-alone rope kernel does on the stored q / k rows
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int row = mi * 32 + fr;
+      const int pos = (tm * BM + wm * 64 + row) % g.rope_mod + g.rope_pos0;
+      const float* cs = g.rope_cos + (long)pos * 64 + (wn & 1) * 32 + fh * 4;
+      const float* sn = g.rope_sin + (long)pos * 64 + (wn & 1) * 32 + fh * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 c4 = *reinterpret_cast<const float4*>(cs + q * 8), s4 = *reinterpret_cast<const float4*>(sn + q * 8);
+        const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w};
+        float o1[4], o2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          rope_pair(bf2f(f2bf(acc[mi][0][4 * q + i] * g.alpha)), bf2f(f2bf(acc[mi][1][4 * q + i] * g.alpha)), cv[i], sv[i], o1[i], o2[i]);
+        const int u = q * 2 + fh;
+        *reinterpret_cast<uint2*>(reg + row * 128 + ((u ^ ((row & 7) << 1)) << 3)) = make_uint2(pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3]));
+        *reinterpret_cast<uint2*>(reg + row * 128 + (((8 + u) ^ ((row & 7) << 1)) << 3)) = make_uint2(pack2bf(o2[0], o2[1]), pack2bf(o2[2], o2[3]));
+      }
+    }
+  } else {
     float bias_v[2][4][4];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
@@ -963,7 +995,9 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256r_kernel(GemmArgs g) {
   {
     const int rsub = lane >> 3, c = lane & 7;
     // EPI 1: chunks 0-3 are gate columns, 4-7 the matching up columns of the [M, 2*ff] output
-    const int n = EPI == 1 ? (c < 4 ? 0 : g.ff) + tn * 128 + wn * 32 + (c & 3) * 8 : tn * BN + wn * 64 + c * 8;
+    const int n = EPI == 1   ? (c < 4 ? 0 : g.ff) + tn * 128 + wn * 32 + (c & 3) * 8
+                  : rope_tile ? tn * BN + (wn >> 1) * 128 + (c < 4 ? 0 : 64) + (wn & 1) * 32 + (c & 3) * 8
+                              : tn * BN + wn * 64 + c * 8;
     const int nlim = EPI == 2 ? g.ff : g.N;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -1460,6 +1494,8 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
 // stores them).  Shapes the 16-wave 256x256 kernel does not take (K % 64, < 160 tiles, ff % 128) fall back to the unfused sequence.
 extern "C" int lhrs_swiglu_fwd(const void* gate_up, void* act, long rows, int F, void* stream);
 extern "C" int lhrs_swiglu_bwd(const void* dact, const void* gate_up, void* dgate_up, long rows, int F, void* stream);
+extern "C" int lhrs_rope(void* x, long ld, int rows, int nheads, int D, const float* cos_t, const float* sin_t, const int* pos_ids, int pos_mod,
+                         int pos0, int inverse, void* stream);
 
 static bool swiglu_fusable(long tiles, int ff, int K, int K2, int lda, int ldb) {
   return (g_gemm_allow_256 == 2 || g_gemm_allow_256 == 5) && ff % 256 == 0 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128 && tiles >= 160 &&
@@ -1496,6 +1532,35 @@ extern "C" int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int
   prof_count(M, 2 * ff, K + K2);
   hipLaunchKernelGGL((gemm_nt_256r_kernel<0, 1>), dim3(g.tilesM * g.tilesN), dim3(1024), 0, s, g);
   LHRS_CHECK_LAUNCH("gemm_swiglu_fwd");
+  return 0;
+}
+
+// qkv = x . Wqkv^T (+ fused LoRA pair) with the RoPE of the q / k heads (HF apply_rotary_pos_emb, rotate_half convention, head_dim 128)
+// applied in the GEMM epilogue: columns [0, rope_cols) are heads of 128 that get rotated with the position m % pos_mod + pos0 of
+// their row, the remaining columns (v) are stored as computed.  Bit-identical to lhrs_gemm_bf16_nt(_lora) followed by lhrs_rope; that
+// pair is also the fallback when the 256-tile kernel does not apply.
+extern "C" int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw, const void* A2, int lda2, const void* B2, int ldb2, int K2,
+                                  void* C, int ldc, int M, int N, int K, const float* cos_t, const float* sin_t, int pos_mod, int pos0,
+                                  int rope_cols, int head_dim, void* stream) {
+  LHRS_REQUIRE(M > 0 && N > 0 && K > 0 && head_dim % 16 == 0 && rope_cols >= 0 && rope_cols <= N && rope_cols % head_dim == 0 && pos_mod > 0 &&
+                   cos_t && sin_t && ldc % 8 == 0,
+               "gemm_rope_fwd: M=%d N=%d K=%d rope_cols=%d head_dim=%d pos_mod=%d", M, N, K, rope_cols, head_dim, pos_mod);
+  const long tiles = (long)cdiv(M, 256) * cdiv(N, 256);
+  const bool fused = (g_gemm_allow_256 == 2 || g_gemm_allow_256 == 5) && head_dim == 128 && rope_cols % 256 == 0 && N % 8 == 0 && K % 64 == 0 &&
+                     K2 % 64 == 0 && K + K2 >= 128 && tiles >= 160 && ldx % 8 == 0 && ldw % 8 == 0;
+  if (!fused) {
+    if (gemm_launch(X, ldx, W, ldw, C, ldc, M, N, K, nullptr, nullptr, 0, 0, 0, 0, 1.f, A2, lda2, B2, ldb2, K2, stream)) return -1;
+    if (rope_cols == 0) return 0;
+    return lhrs_rope(C, ldc, M, rope_cols / head_dim, head_dim, cos_t, sin_t, nullptr, pos_mod, pos0, 0, stream);
+  }
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  g.A = (const bf16_t*)X; g.B = (const bf16_t*)W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = ldw; g.ldc = ldc;
+  g.alpha = 1.f; g.A2 = (const bf16_t*)A2; g.B2 = (const bf16_t*)B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
+  g.epi = 3; g.rope_cos = cos_t; g.rope_sin = sin_t; g.rope_mod = pos_mod; g.rope_pos0 = pos0; g.rope_cols = rope_cols;
+  g.tilesM = cdiv(M, 256); g.tilesN = cdiv(N, 256);
+  prof_count(M, N, K + K2);
+  hipLaunchKernelGGL((gemm_nt_256r_kernel<0, 3>), dim3(g.tilesM * g.tilesN), dim3(1024), 0, (hipStream_t)stream, g);
+  LHRS_CHECK_LAUNCH("gemm_rope_fwd");
   return 0;
 }
 

@@ -80,6 +80,20 @@ def gemm_swiglu_fwd(x, w_gu, ff, a2=None, b2=None):
     return gu, act
 
 
+def gemm_rope_fwd(x, w, cos_t, sin_t, *, pos_mod, pos0=0, rope_cols, head_dim, a2=None, b2=None, out=None):
+    """out [M, N] = x @ w^T (+ a2 @ b2^T) with RoPE applied to the heads in columns [0, rope_cols) inside the GEMM epilogue (one launch;
+    bit-identical to gemm_nt(+lora) followed by rope_)."""
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), device=x.device, dtype=torch.bfloat16) if out is None else out
+    K2 = a2.shape[1] if a2 is not None else 0
+    st = _L().lhrs_gemm_rope_fwd(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _p(a2), a2.stride(0) if K2 else 0, _p(b2),
+                                 b2.stride(0) if K2 else 0, K2, out.data_ptr(), out.stride(0), M, N, K, cos_t.data_ptr(), sin_t.data_ptr(),
+                                 int(pos_mod), int(pos0), int(rope_cols), int(head_dim), _stream())
+    _lib.check(st, "gemm_rope_fwd")
+    return out
+
+
 def gemm_swiglu_bwd(dy, w_down_t, gu, ff, a2=None, b2=None, out=None):
     """dgu [M, 2ff] = swiglu'(gu) * (dy @ w_down_t^T (+ a2 @ b2^T)) in ONE launch; out defaults to gu (in place)."""
     M, K = dy.shape

@@ -11,6 +11,7 @@ Activation memory per layer and token: x_in, x_mid, o (3 x 4096), qkv (12288), g
 from __future__ import annotations
 
 import math
+import os
 import types
 from typing import Dict, List, Optional
 
@@ -246,9 +247,10 @@ class TextModal:
         """(e4m3 weight, per-row scales) of L[name] when the base weights are 8-bit (quantize_base), else None."""
         return (L[name + "8"], L[name + "8s"]) if self.base8 else None
 
-    def _lin(self, li, gname, x, W, residual=None, save=None, q8=None, xq=None):
+    def _lin(self, li, gname, x, W, residual=None, save=None, q8=None, xq=None, rope=None):
         """y = x W^T (+ s (x A^T) B^T when the group carries adapters) (+ residual).  q8 = (W8, scales): the frozen base product runs
-        on the e4m3 MFMA path (x quantised per row on the fly), the adapter update stays bf16 and rides on the same accumulators (lhrs_gemm_fp8_nt_lora)."""
+        on the e4m3 MFMA path (x quantised per row on the fly), the adapter update stays bf16 and rides on the same accumulators (lhrs_gemm_fp8_nt_lora).
+        rope = (pos_mod, pos0): the qkv projection - RoPE of the q / k heads in the bf16 GEMM's epilogue, a separate launch after the e4m3 one."""
         lo = self.lora
         has_lora = lo is not None and gname in lo.groups
         if has_lora:
@@ -264,8 +266,15 @@ class TextModal:
         if q8 is not None:
             x8, sx = xq if xq is not None else hk.quant_fp8_rows(x)  # xq: the producer already emitted the e4m3 operand
             if has_lora:
-                return hk.gemm_fp8_nt(x8, sx, q8[0], q8[1], residual=residual, a2=T, b2=lo.derived[(li, gname, "Bfull")])
-            return hk.gemm_fp8_nt(x8, sx, q8[0], q8[1], residual=residual)
+                y = hk.gemm_fp8_nt(x8, sx, q8[0], q8[1], residual=residual, a2=T, b2=lo.derived[(li, gname, "Bfull")])
+            else:
+                y = hk.gemm_fp8_nt(x8, sx, q8[0], q8[1], residual=residual)
+            if rope is not None:
+                hk.rope_(y, y.shape[0], 2 * self.heads, self.hd, self.cos, self.sin, pos_mod=rope[0], pos0=rope[1])
+            return y
+        if rope is not None:
+            return hk.gemm_rope_fwd(x, W, self.cos, self.sin, pos_mod=rope[0], pos0=rope[1], rope_cols=2 * self.d, head_dim=self.hd,
+                                    a2=T if has_lora else None, b2=lo.derived[(li, gname, "Bfull")] if has_lora else None)
         if not has_lora:
             return hk.gemm_nt(x, W, residual=residual)
         return hk.gemm_nt_lora(x, W, T, lo.derived[(li, gname, "Bfull")], residual=residual)
@@ -365,8 +374,7 @@ class TextModal:
             h, hq = hk.rmsnorm_fwd_q(x, L["ln1_w"], self.eps, want_bf16=lo is not None and "qkv" in lo.groups)
         else:
             h = hk.rmsnorm_fwd(x, L["ln1_w"], self.eps)
-        qkv = self._lin(li, "qkv", h, L["qkv_w"], save=rec, q8=self._q8(L, "qkv_w"), xq=hq)
-        hk.rope_(qkv, M, 2 * H, hd, self.cos, self.sin, pos_mod=S)
+        qkv = self._lin(li, "qkv", h, L["qkv_w"], save=rec, q8=self._q8(L, "qkv_w"), xq=hq, rope=(S, 0))
         o = torch.empty((M, d), device=self.device, dtype=torch.bfloat16)
         lse = torch.empty((B, H, LT), device=self.device, dtype=torch.float32)
         hk.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, desc, B, H, hd, S, S, LT, True, 1.0 / math.sqrt(hd))
@@ -430,8 +438,7 @@ class TextModal:
         d, H, hd, ff = self.d, self.heads, self.hd, self.ff
         M = x.shape[0]
         h = hk.rmsnorm_fwd(x, L["ln1_w"], self.eps)
-        qkv = hk.gemm_nt(h, L["qkv_w"])
-        hk.rope_(qkv, M, 2 * H, hd, self.cos, self.sin, pos_mod=S_new, pos0=ctx)
+        qkv = hk.gemm_rope_fwd(h, L["qkv_w"], self.cos, self.sin, pos_mod=S_new, pos0=ctx, rope_cols=2 * d, head_dim=hd)
         kc, vc = cache
         row_b = d * 2
         for b in range(B):  # append the new K / V rows of sequence b at position ctx of its cache

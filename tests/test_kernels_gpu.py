@@ -448,3 +448,26 @@ def test_argmax_rows_first_maximum(V, ld):
     want = torch.from_numpy(x.numpy().argmax(-1))
     got = hk.argmax_rows(buf.to("cuda")[:, :V])
     assert torch.equal(got.cpu(), want), (got, want)
+
+
+@pytest.mark.parametrize("M,S,pos0,lora", [(8190, 273, 0, False), (8190, 273, 0, True), (4095, 195, 7, False), (300, 100, 0, True)])
+def test_gemm_fused_rope_bit_identical_to_unfused(M, S, pos0, lora):
+    """lhrs_gemm_rope_fwd == GEMM (+ LoRA pair) followed by lhrs_rope, bit for bit: q / k heads rotated in the epilogue of the 16-wave
+    kernel (M >= 4095), v columns untouched; the small case takes the documented fallback."""
+    g = torch.Generator().manual_seed(M + S + lora)
+    d, hd, KP = 4096, 128, 64
+    x = torch.randn(M, d, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(3 * d, d, generator=g) * 0.02).to(DEV, torch.bfloat16)
+    a2 = b2 = None
+    if lora:
+        a2 = (torch.randn(M, KP, generator=g) * 0.1).to(DEV, torch.bfloat16)
+        b2 = (torch.randn(3 * d, KP, generator=g) * 0.05).to(DEV, torch.bfloat16)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    fr = torch.outer(torch.arange(512).float(), inv)
+    cos, sin = fr.cos().to(DEV).contiguous(), fr.sin().to(DEV).contiguous()
+    got = hk.gemm_rope_fwd(x, w, cos, sin, pos_mod=S, pos0=pos0, rope_cols=2 * d, head_dim=hd, a2=a2, b2=b2)
+    ref = hk.gemm_nt_lora(x, w, a2, b2) if lora else hk.gemm_nt(x, w)
+    plain = ref.clone()
+    hk.rope_(ref, M, 2 * d // hd, hd, cos, sin, pos_mod=S, pos0=pos0)
+    assert torch.equal(got, ref)
+    assert torch.equal(got[:, 2 * d:], plain[:, 2 * d:]) and not torch.equal(got[:, :2 * d], plain[:, :2 * d])

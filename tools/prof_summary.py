@@ -1,0 +1,25 @@
+"""Condense a `rocprofv3 --kernel-trace --stats --output-format csv` run of bench.py into the files kept under profiles/:
+    python tools/prof_summary.py <rocprof output dir> <steps> <warmup> <tag>
+writes profiles/<tag>_kernel_stats.csv (copy of the stats table) and profiles/<tag>_gemm_launch_summary.json (dominant kernel:
+launch counts, average over all launches and over the launches of the timed steps only)."""
+import csv, glob, json, os, shutil, sys
+
+src, steps, warmup, tag = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+stats = sorted(glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True))[-1]
+trace = sorted(glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True))[-1]
+shutil.copy(stats, os.path.join(root, "profiles", f"{tag}_kernel_stats.csv"))
+rows = list(csv.DictReader(open(trace)))
+name_key = "Kernel_Name" if "Kernel_Name" in rows[0] else "Name"
+dom = [r for r in rows if "gemm_nt_256r_kernel<0, 0>" in r[name_key]]
+dom.sort(key=lambda r: int(r["Start_Timestamp"]))
+per_step = len(dom) // (steps + warmup)
+timed = dom[-per_step * steps:]
+avg = lambda rs: sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs) / len(rs) / 1e3
+out = {"kernel": "gemm_nt_256r_kernel<0, 0>",
+       "command": f"rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps {steps} --warmup {warmup} --no-cpu-baseline",
+       "launches_total": len(dom), "launches_per_step": per_step, "avg_us_all_launches": avg(dom), "avg_us_timed_steps_only": avg(timed),
+       "note": "the *_kernel_stats.csv average covers warm-up (first-touch) launches too; the timed-steps average is the one bench.py "
+               "measures live with HIP events"}
+json.dump(out, open(os.path.join(root, "profiles", f"{tag}_gemm_launch_summary.json"), "w"), indent=1)
+print(json.dumps(out))
