@@ -97,17 +97,21 @@ class GradReducer:
 
     def finish(self) -> None:
         """Make the compute stream (or the host, on CPU) wait for every outstanding bucket."""
-        for w, low, buf in self.pending:
-            w.wait()
-            if low is not None:
-                if self.cuda:
-                    with torch.cuda.stream(self.comm_stream):
+        if self.cuda:
+            # Work.wait() orders the CURRENT stream behind the collective (RCCL runs it on its own stream): wait from the comm stream,
+            # so that the widening copy below cannot read a bucket that is still being reduced, then chain the compute stream behind it
+            with torch.cuda.stream(self.comm_stream):
+                for w, low, buf in self.pending:
+                    w.wait()
+                    if low is not None:
                         buf.copy_(low)
-                else:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        else:
+            for w, low, buf in self.pending:
+                w.wait()
+                if low is not None:
                     buf.copy_(low)
         self.pending.clear()
-        if self.cuda:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
 
 
 class _TrainStore:
