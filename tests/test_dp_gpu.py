@@ -70,3 +70,45 @@ def test_two_rank_step_equals_single_process_on_averaged_gradients(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port), timeout=800)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+RCCL_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from lhrs_bot_amd.engine import GradReducer
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)   # RCCL, one rank: the collective is a copy
+g = torch.Generator().manual_seed(0)
+for comm in (torch.bfloat16, torch.float32):
+    flat = torch.randn(3 * 1024 * 1024 + 64, generator=g).to(dev)
+    want = flat.to(comm).float()                       # what a sum over one rank in the comm dtype leaves behind
+    n = flat.numel()
+    red = GradReducer(flat, [("a", 0, n // 3), ("b", n // 3, n // 2), ("c", n // 2, n)], None, comm)
+    for rep in range(3):                                # buckets become final while "compute" keeps the stream busy
+        src = flat.clone()
+        for key in ("c", "b", "a"):
+            x = torch.randn(2048, 2048, device=dev) @ torch.randn(2048, 2048, device=dev)
+            red.ready(key)
+        red.finish()
+        torch.cuda.synchronize()
+        assert torch.equal(flat, src.to(comm).float()), (comm, rep)
+    assert torch.equal(flat, want)
+torch.distributed.barrier(); torch.distributed.destroy_process_group()
+open(os.path.join(sys.argv[2], "ok_rccl"), "w").write("ok")
+'''
+
+
+@pytest.mark.timeout(600)
+def test_grad_reducer_on_rccl_single_rank(tmp_path):
+    """The bucketed reducer through the REAL RCCL backend ("nccl"), one rank on the box's single GPU: async collectives issued from
+    the comm stream, bf16 wire dtype with the widening copy, finish() ordering - what the driver's multi-GPU runs execute."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), ROOT, str(tmp_path)], capture_output=True, text=True, env=env, timeout=500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert (tmp_path / "ok_rccl").exists()
