@@ -190,8 +190,11 @@ int lhrs_cross_entropy(const void* logits, long ld, const int* target, float* ro
  * context length on the device so that one captured hipGraph (lhrs_graph_*) replays for every generated token.        */
 int lhrs_gemv_bf16(const void* W, long ldw, const void* x, long ldx, const void* residual, long ldr, void* y, long ldy, int B,
                    int N, int K, int out_f32, void* stream);
-int lhrs_gemv(const void* W, long ldw, const float* wscale, int w_fp8, const void* x, long ldx, int prologue, const void* norm_w,
+/* w_format: 0 = bf16 rows [N, ldw]; 1 = e4m3 rows + per-row wscale; 2 = bf16 re-tiled by lhrs_repack_bf16_mfma into the MFMA operand
+ * order [N/16][K/32][64 lanes][8] (batch >= 2, K % 128 == 0; ldw unused) - the batched-evaluation weight stream as consecutive 1-KiB lines */
+int lhrs_gemv(const void* W, long ldw, const float* wscale, int w_format, const void* x, long ldx, int prologue, const void* norm_w,
               float eps, const void* residual, long ldr, void* y, long ldy, int B, int N, int K, int out_f32, void* stream);
+int lhrs_repack_bf16_mfma(const void* W, long ldw, void* out, int N, int K, void* stream);
 /* kernel A/B tests only: rows per wave / 1-KiB chunks per iteration of the batch-1 bf16 GEMV (0, 0 = the built-in shape rule) */
 int lhrs_gemv_set_tuning(int rows_per_wave, int chunks_per_iteration);
 int lhrs_quant_fp8_rows(const void* W, long ldw, void* W8, long ld8, float* scale, int N, int K, void* stream);

@@ -161,26 +161,31 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
 //   layout: lane (r, g) holds W[row0 + r][k0 + 8g .. +8]); x rows sit in LDS after the RMSNorm / SwiGLU prologue and feed the B
 //   operand (batch columns >= B read zeros); the 4 partial 16x16 tiles are summed through LDS.
 // ------------------------------------------------------------------------------------------------------------------
-template <int PRO>
-__global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict__ W, long ldw, const bf16_t* __restrict__ x, long ldx,
+// PK: W is the copy lhrs_repack_bf16_mfma made - [N/16][K/32][64 lanes][8 bf16], the A-operand order - so every wave instruction reads
+// 1 KiB of consecutive bytes and a wave's K quarter is one contiguous run (row-major: 16 rows x 64-B segments at the row stride).
+// NW waves per block split K (8 when K % 256 == 0: the 4096-row projections are 256 blocks - one per CU - and need the loads of 8 waves in flight)
+template <int PRO, bool PK, int NW>
+__global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __restrict__ W, long ldw, const bf16_t* __restrict__ x, long ldx,
                                                         const bf16_t* __restrict__ norm_w, float eps, const bf16_t* res, long ldr, void* y,
                                                         long ldy, int NB, int N, int K, int out_f32) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ float red[4];
-  __shared__ float part[4][16][17];
+  __shared__ float red[NW];
+  __shared__ float part[NW][16][17];
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);  // [NB][K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
   const int nch = K / 8;
   const int row0 = blockIdx.x * 16;
-  const int kq = K / 4;                      // this wave's quarter of K (K % 128 == 0)
-  const bf16_t* wp = W + (long)min(row0 + fr, N - 1) * ldw + wave * kq + fg * 8;
+  const int kq = K / NW;                     // this wave's slice of K (K % (32 NW) == 0)
+  const bf16_t* wp = PK ? W + ((long)blockIdx.x * (K / 32) + wave * (kq / 32)) * 512 + lane * 8
+                        : W + (long)min(row0 + fr, N - 1) * ldw + wave * kq + fg * 8;
+  constexpr int WSTEP = PK ? 512 : 32;       // elements between consecutive 32-k steps of this lane
   constexpr int U = 4;                       // k-steps (of 32) in flight per wave
   i32x4 wreg[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) wreg[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + u * 32));  // kq >= 128
+  for (int u = 0; u < U; ++u) wreg[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + u * WSTEP));  // kq >= 128
   for (int b = 0; b < (PRO == 0 ? 0 : NB); ++b) {  // PRO 0: x is read straight from L2 into the B fragments, nothing to stage
     if (PRO == 2) {
-      for (int c = tid; c < nch; c += 256) {
+      for (int c = tid; c < nch; c += NW * 64) {
         const uint4 g = *reinterpret_cast<const uint4*>(x + b * ldx + c * 8);
         const uint4 u = *reinterpret_cast<const uint4*>(x + b * ldx + K + c * 8);
         uint4 o;
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
       }
     } else {
       float q = 0.f;
-      for (int c = tid; c < nch; c += 256) {
+      for (int c = tid; c < nch; c += NW * 64) {
         const uint4 v = *reinterpret_cast<const uint4*>(x + b * ldx + c * 8);
         *reinterpret_cast<uint4*>(xs + b * K + c * 8) = v;
         if (PRO == 1)
@@ -200,9 +205,9 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
                bfhi(v.z) * bfhi(v.z) + bflo(v.w) * bflo(v.w) + bfhi(v.w) * bfhi(v.w);
       }
       if (PRO == 1) {
-        const float rstd = rsqrtf(block_sum<4>(q, red) / (float)K + eps);
+        const float rstd = rsqrtf(block_sum<NW>(q, red) / (float)K + eps);
         __syncthreads();
-        for (int c = tid; c < K; c += 256) xs[b * K + c] = f2bf(bf2f(norm_w[c]) * bf2f(f2bf(bf2f(xs[b * K + c]) * rstd)));
+        for (int c = tid; c < K; c += NW * 64) xs[b * K + c] = f2bf(bf2f(norm_w[c]) * bf2f(f2bf(bf2f(xs[b * K + c]) * rstd)));
       }
     }
   }
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int sn = min(s0 + U + u, nsteps - 1);
-      wnext[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + sn * 32));
+      wnext[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + (long)sn * WSTEP));
       xfrag[u] = *reinterpret_cast<const bf16x8*>(xq + min(s0 + u, nsteps - 1) * 32);
     }
 #pragma unroll
@@ -235,10 +240,12 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
 #pragma unroll
   for (int r = 0; r < 4; ++r) part[wave][fg * 4 + r][fr] = acc[r];
   __syncthreads();
-  const int i = tid >> 4, b = tid & 15;  // 256 threads = 16 rows x 16 batch columns
+  const int i = tid >> 4, b = tid & 15;  // the first 256 threads = 16 rows x 16 batch columns
   const int row = row0 + i;
-  if (b < NB && row < N) {
-    float v = part[0][i][b] + part[1][i][b] + part[2][i][b] + part[3][i][b];
+  if (tid < 256 && b < NB && row < N) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += part[w][i][b];
     if (res) v += bf2f(res[b * ldr + row]);
     if (out_f32) reinterpret_cast<float*>(y)[b * ldy + row] = v;
     else reinterpret_cast<bf16_t*>(y)[b * ldy + row] = f2bf(v);
@@ -416,6 +423,22 @@ __global__ __launch_bounds__(256) void repack_fp8_mfma_kernel(const uint8_t* __r
   i32x4 v = {0, 0, 0, 0};
   if (row < N) v = *reinterpret_cast<const i32x4*>(W + row * ldw + (long)step * 128 + half * 64 + (lane >> 4) * 16);
   *reinterpret_cast<i32x4*>(out + p * 16) = v;
+}
+
+// bf16 [N, ldw] rows -> the tiled operand order of gemv_mfma_kernel<*, true>: piece p = (rg * K/32 + step) * 64 + lane holds
+// W[16 rg + (lane & 15)][32 step + 8 (lane >> 4) .. +8]; rows past N are zero.
+__global__ __launch_bounds__(256) void repack_bf16_mfma_kernel(const bf16_t* __restrict__ W, long ldw, bf16_t* __restrict__ out, int N, int K) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  const int nsteps = K / 32;
+  const long total = (long)((N + 15) / 16) * nsteps * 64;
+  if (p >= total) return;
+  const int lane = (int)(p & 63);
+  const long t = p >> 6;
+  const int step = (int)(t % nsteps);
+  const long row = (t / nsteps) * 16 + (lane & 15);
+  i32x4 v = {0, 0, 0, 0};
+  if (row < N) v = *reinterpret_cast<const i32x4*>(W + row * ldw + (long)step * 32 + (lane >> 4) * 8);
+  *reinterpret_cast<i32x4*>(out + p * 8) = v;
 }
 
 // per-row e4m3 quantisation: scale[n] = max|W[n,:]| / 448, W8 = round(W / scale).  One block per row, 16-B loads; the row stays in
@@ -751,13 +774,16 @@ static int gemv_chunk(const void* W, long ldw, const float* wscale, const bf16_t
 }
 
 // y[B, N] = pro(x)[B, K] . W[N, K]^T (+ residual[B, N]);  B <= 8.  prologue: 0 none, 1 RMSNorm(norm_w, eps), 2 SwiGLU (x is [B, 2K]).
-// w_fp8 != 0: W is e4m3 bytes [N, ldw] with per-row scales `wscale` (lhrs_quant_fp8_rows).  Batches exceeding the LDS are split.
-extern "C" int lhrs_gemv(const void* W, long ldw, const float* wscale, int w_fp8, const void* x, long ldx, int prologue,
+// w_format 1: W is e4m3 bytes [N, ldw] with per-row scales `wscale` (lhrs_quant_fp8_rows).  Batches exceeding the LDS are split.
+// w_format: 0 bf16 rows, 1 e4m3 rows + wscale, 2 bf16 tiles of lhrs_repack_bf16_mfma (batch >= 2 only: the MFMA weight stream).
+extern "C" int lhrs_gemv(const void* W, long ldw, const float* wscale, int w_format, const void* x, long ldx, int prologue,
                          const void* norm_w, float eps, const void* residual, long ldr, void* y, long ldy, int B, int N, int K,
                          int out_f32, void* stream) {
+  const int w_fp8 = w_format == 1, w_packed = w_format == 2;
+  LHRS_REQUIRE(w_format >= 0 && w_format <= 2 && (!w_packed || (B >= 2 && K % 128 == 0)), "gemv: weight format %d (tiles need batch >= 2, K %% 128 == 0)", w_format);
   LHRS_REQUIRE(B >= 1 && B <= 16 && N > 0 && K % 16 == 0 && ldx % 8 == 0, "gemv: B=%d (1..16) N=%d K=%d", B, N, K);
   LHRS_REQUIRE(B <= 8 || (!w_fp8 && K % 128 == 0), "gemv: batches above 8 need bf16 weights and K %% 128 == 0");
-  LHRS_REQUIRE(w_fp8 ? (ldw % 16 == 0 && wscale != nullptr) : (ldw % 8 == 0), "gemv: weight stride / scales");
+  LHRS_REQUIRE(w_fp8 ? (ldw % 16 == 0 && wscale != nullptr) : (w_packed || ldw % 8 == 0), "gemv: weight stride / scales");
   LHRS_REQUIRE(prologue >= 0 && prologue <= 2 && (prologue != 1 || norm_w != nullptr), "gemv: prologue %d", prologue);
   int bmax = (int)((152L * 1024) / ((long)K * 2));
   if (!w_fp8 && prologue == 0 && B >= 2 && K % 128 == 0) bmax = 16;  // the MFMA kernel reads x from L2: no LDS limit
@@ -770,15 +796,23 @@ extern "C" int lhrs_gemv(const void* W, long ldw, const float* wscale, int w_fp8
     const bf16_t* rb = residual ? (const bf16_t*)residual + b0 * ldr : nullptr;
     void* yb = (char*)y + b0 * ldy * esz;
     int rc;
+    LHRS_REQUIRE(!w_packed || nb >= 2, "gemv: a batch chunk of %d row(s) cannot read tiled weights (B=%d, chunks of %d)", nb, B, bmax);
     if (!w_fp8 && nb >= 2 && K % 128 == 0) {  // batched: MFMA weight stream
       const size_t sm = prologue == 0 ? 0 : (size_t)nb * K * 2;
-      const dim3 grid(cdiv(N, 16)), blk(256);
+      const int nw = K % 256 == 0 ? 8 : 4;
+      const dim3 grid(cdiv(N, 16)), blk(nw * 64);
+#define GOM1(P, PK, NW)                                                                                                             \
+  do {                                                                                                                             \
+    if (sm > 65536) (void)hipFuncSetAttribute((const void*)gemv_mfma_kernel<P, PK, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+    hipLaunchKernelGGL((gemv_mfma_kernel<P, PK, NW>), grid, blk, sm, s, (const bf16_t*)W, ldw, xb, ldx, (const bf16_t*)norm_w, eps, rb, ldr, yb, ldy, nb, N, K, out_f32); \
+  } while (0)
 #define GOM(P)                                                                                                                     \
   do {                                                                                                                             \
-    if (sm > 65536) (void)hipFuncSetAttribute((const void*)gemv_mfma_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-    hipLaunchKernelGGL((gemv_mfma_kernel<P>), grid, blk, sm, s, (const bf16_t*)W, ldw, xb, ldx, (const bf16_t*)norm_w, eps, rb, ldr, yb, ldy, nb, N, K, out_f32); \
+    if (w_packed) { if (nw == 8) GOM1(P, true, 8); else GOM1(P, true, 4); }                                                        \
+    else { if (nw == 8) GOM1(P, false, 8); else GOM1(P, false, 4); }                                                               \
   } while (0)
       if (prologue == 0) GOM(0); else if (prologue == 1) GOM(1); else GOM(2);
+#undef GOM1
 #undef GOM
       LHRS_CHECK_LAUNCH("gemv_mfma");
       continue;
@@ -914,6 +948,16 @@ extern "C" int lhrs_gemv_fp8_mfma_fused(const void* W8, long ldw, const float* w
   else { if (prologue == 0) GOF(0, false); else if (prologue == 1) GOF(1, false); else GOF(2, false); }
 #undef GOF
   LHRS_CHECK_LAUNCH("gemv_fp8_mfma_fused");
+  return 0;
+}
+
+// W [N, ldw] bf16 rows -> out: ceil(N/16) * 16 * K bf16 in the operand order of the batched MFMA GEMV (see repack_bf16_mfma_kernel)
+extern "C" int lhrs_repack_bf16_mfma(const void* W, long ldw, void* out, int N, int K, void* stream) {
+  LHRS_REQUIRE(N > 0 && K >= 128 && K % 128 == 0 && ldw % 8 == 0, "repack_bf16_mfma: N=%d K=%d ldw=%ld", N, K, ldw);
+  const long total = (long)cdiv(N, 16) * (K / 32) * 64;
+  hipLaunchKernelGGL(repack_bf16_mfma_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W, ldw,
+                     (bf16_t*)out, N, K);
+  LHRS_CHECK_LAUNCH("repack_bf16_mfma");
   return 0;
 }
 

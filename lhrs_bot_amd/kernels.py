@@ -518,10 +518,30 @@ def gemv(W, x, out, residual=None, out_f32=False):
 PRO_NONE, PRO_RMSNORM, PRO_SWIGLU = 0, 1, 2
 
 
+class PackedBf16:
+    """bf16 weight [N, K] re-tiled by `repack_bf16_mfma` into the operand order of the batched MFMA GEMV (batch >= 2 decode)."""
+
+    def __init__(self, data, N, K):
+        self.data, self.N, self.K = data, N, K
+        self.shape = (N, K)
+
+
+def repack_bf16_mfma(W) -> PackedBf16:
+    N, K = W.shape
+    out = torch.empty((N + 15) // 16 * 16 * K, device=W.device, dtype=torch.bfloat16)
+    _lib.check(_L().lhrs_repack_bf16_mfma(W.data_ptr(), W.stride(0), out.data_ptr(), N, K, _stream()), "repack_bf16_mfma")
+    return PackedBf16(out, N, K)
+
+
 def gemv_fused(W, x, out, K, *, wscale=None, prologue=PRO_NONE, norm_w=None, eps=1e-5, residual=None, out_f32=False):
-    """out[B, N] = pro(x)[B, K] @ W[N, K]^T (+ residual).  W: bf16 [N, K] or (wscale given) e4m3 bytes [N, K] with per-row scales."""
+    """out[B, N] = pro(x)[B, K] @ W[N, K]^T (+ residual).  W: bf16 [N, K], (wscale given) e4m3 bytes [N, K] with per-row scales, or a
+    PackedBf16 (batch >= 2)."""
     B, N = x.shape[0], W.shape[0]
-    st = _L().lhrs_gemv(W.data_ptr(), W.stride(0), _p(wscale), int(wscale is not None), x.data_ptr(), x.stride(0), prologue, _p(norm_w),
+    if isinstance(W, PackedBf16):
+        wp, ldw, fmt = W.data.data_ptr(), 0, 2
+    else:
+        wp, ldw, fmt = W.data_ptr(), W.stride(0), int(wscale is not None)
+    st = _L().lhrs_gemv(wp, ldw, _p(wscale), fmt, x.data_ptr(), x.stride(0), prologue, _p(norm_w),
                         float(eps), _p(residual), residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0), B, N, K,
                         int(out_f32), _stream())
     _lib.check(st, "gemv")

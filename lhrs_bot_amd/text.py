@@ -470,6 +470,14 @@ class TextModal:
                 L[k + "8p"] = hk.repack_fp8_mfma(L[k + "8"])
         self.p["lm_head8p"] = hk.repack_fp8_mfma(self.p["lm_head8"])
 
+    def pack_bf16_decode(self):
+        """Decode-only copies of the bf16 weights in the batched MFMA GEMV's operand order (hk.repack_bf16_mfma; +13.5 GB of HBM): from
+        batch 2 the shared weight stream of generate() reads consecutive 1-KiB lines instead of 64-B segments of 16 strided rows."""
+        for L in self.p["layers"]:
+            for k in ("qkv_w", "o_w", "gu_w", "down_w"):
+                L[k + "p"] = hk.repack_bf16_mfma(L[k])
+        self.p["lm_headp"] = hk.repack_bf16_mfma(self.p["lm_head"])
+
     def quantize_base(self, bits: int = 8):
         """`bits: 8` of Config/multi_modal_stage{2,3}.yaml (text_modal.py:91-131: the reference loads the frozen LLaMA through
         bitsandbytes LLM.int8 for stages 2/3).  MI355X-native equivalent: every decoder linear (lm_head stays bf16, as bitsandbytes
@@ -514,8 +522,12 @@ class TextModal:
         if fp8 and "qkv_w8p" not in self.p["layers"][0]:
             self.pack_fp8_decode()
 
+        packed16 = not fp8 and B >= 2 and d % 128 == 0 and ff % 128 == 0  # batched bf16: the MFMA GEMV on re-tiled weights
+        if packed16 and "qkv_wp" not in self.p["layers"][0]:
+            self.pack_bf16_decode()
+
         def W(L, name):  # (weight, per-row scale or None)
-            return (L[name + "8p"], L[name + "8s"]) if fp8 else (L[name], None)
+            return (L[name + "8p"], L[name + "8s"]) if fp8 else (L[name + "p"] if packed16 else L[name], None)
 
         batched = B >= 4 and not fp8  # the MFMA weight stream reads x from L2: norm / SwiGLU run once, not once per block (pays from batch 4)
         if batched:
@@ -561,7 +573,7 @@ class TextModal:
                 lin(*W(L, "o_w"), s.o, x2, d, residual=x)
                 lin(*W(L, "gu_w"), x2, s.gu, d, hk.PRO_RMSNORM, L["ln2_w"])
                 lin(*W(L, "down_w"), s.gu, x, ff, hk.PRO_SWIGLU, residual=x2)
-            w, sc = (self.p["lm_head8p"], self.p["lm_head8s"]) if fp8 else (self.p["lm_head"], None)
+            w, sc = (self.p["lm_head8p"], self.p["lm_head8s"]) if fp8 else (self.p["lm_headp"] if packed16 else self.p["lm_head"], None)
             lin(w, sc, x, s.logits, d, hk.PRO_RMSNORM, self.p["norm_w"], out_f32=True)
 
         s.enqueue = enqueue

@@ -115,6 +115,15 @@ def test_fp8_weight_decode_and_fused_prologues():
     hk.gemv_fused(Wd, gu, y, 11008, prologue=hk.PRO_SWIGLU)
     hk.gemv(Wd, hk.swiglu_fwd(gu, 11008), y_ref)
     assert torch.equal(y, y_ref)
+    # re-tiled bf16 weights (batched decode): the same products in the same order, for every prologue and batch 2 / 16, ragged N
+    for Wt, K, pro, xin in ((W, 4096, hk.PRO_RMSNORM, x), (Wd, 11008, hk.PRO_SWIGLU, gu), (W[:4090], 4096, hk.PRO_NONE, x),
+                            (W, 4096, hk.PRO_NONE, torch.randn(16, 4096, generator=g).to(DEV, torch.bfloat16))):
+        Wp = hk.repack_bf16_mfma(Wt)
+        ya = torch.empty(xin.shape[0], Wt.shape[0], device=DEV, dtype=torch.float32)
+        yb = torch.empty_like(ya)
+        hk.gemv_fused(Wt, xin, ya, K, prologue=pro, norm_w=nw, out_f32=True)
+        hk.gemv_fused(Wp, xin, yb, K, prologue=pro, norm_w=nw, out_f32=True)
+        assert torch.equal(ya, yb), (K, pro)
     # e4m3 weights: quantisation error only (per-row scaled): ~2^-4 relative per element, averaged down by the dot product
     W8, sc = hk.quant_fp8_rows(W)
     deq = W8.view(torch.float8_e4m3fn).float() * sc[:, None]
