@@ -96,6 +96,9 @@ int lhrs_dropout_bf16(const void* x, long ldx, void* out, long ldo, long rows, i
 int lhrs_gemm_bf16_nt_dropmask(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                                const void* residual, int ldr, float alpha, float p, unsigned seed, void* stream);
 int lhrs_gemm_set_policy(int allow_256);
+/* kernel A/B tests only: 0 disables the tail-row rule (a product whose last round of 256x256 tiles would be nearly empty is cut into
+ * whole tile rows for the 16-wave kernel + the remaining rows for the small-tile kernel); default 1 */
+int lhrs_gemm_set_tail_split(int on);
 int lhrs_gemm_profile_enable(int max_samples);
 int lhrs_gemm_profile_read(double* out5_host);
 

@@ -1359,6 +1359,9 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
 // epilogue dropout mask of the NEXT gemm_launch on this host thread: set and cleared by lhrs_gemm_bf16_nt_dropmask only (keeps the
 // 21-argument launcher signature out of every other call site); thresh = 0 means no mask
 static thread_local struct { float scale; unsigned seed, thresh; } t_drop = {1.f, 0u, 0u};
+static thread_local bool t_split_ok = true;  // false inside the two launches of a row-split product (see the tail-row rule in gemm_launch)
+static int g_gemm_tail_split = 1;            // kernel A/B tests only (lhrs_gemm_set_tail_split)
+extern "C" int lhrs_gemm_set_tail_split(int on) { g_gemm_tail_split = on; return 0; }
 
 // C = mask * (alpha * A.B^T) / (1 - p) + residual, mask = the counter-based LoRA dropout mask over the [M, N] result (see common.h)
 extern "C" int lhrs_gemm_bf16_nt_dropmask(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
@@ -1433,6 +1436,32 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
                        nullptr, 0, nullptr, 0, 0, stream);
   }
   LHRS_REQUIRE(use256 || K % 64 == 0, "gemm: K=%d must be a multiple of 64 for this problem size (zero-pad the reduction dim)", K);
+  // Tail rows: T = tilesM * tilesN 256x256 tiles run as ceil(T / 256) rounds of the 256 CUs, and a nearly empty last round costs as
+  // much as a full one (M = 8736, N = 4096: 560 tiles = 2.19 rounds -> 3).  When the tile rows that spill over the last full round
+  // are cheaper as a separate small-tile launch (~2.5x the time per FLOP, but no idle CUs), the row range is cut there: whole
+  // 256-row tile rows for the 16-wave kernel, the remaining rows for the 64x128 / 128x128 kernel.  Disjoint rows of C, no partials.
+  if (use256 && t_split_ok && g_gemm_tail_split && (g_gemm_allow_256 == 2 || g_gemm_allow_256 == 5) && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128 &&
+      !g.drop_thresh) {
+    const int tm = cdiv(M, 256), tn = cdiv(N, 256);
+    const long T = (long)tm * tn, rounds = (T + 255) / 256, full = T / 256;
+    const int tm_main = (int)(full * 256 / tn);
+    if (full >= 1 && T % 256 != 0 && tm_main >= 1 && tm_main < tm) {
+      const long t_main = (long)tm_main * tn, t_tail = T - t_main;
+      const double split_cost = (double)((t_main + 255) / 256) + 2.5 * (double)t_tail / 256.0 + 0.05;
+      if (split_cost < (double)rounds) {
+        const int M_main = tm_main * 256, M_tail = M - M_main;
+        const long esz = out_f32 ? 4 : 2;
+        t_split_ok = false;
+        int rc = gemm_launch(A, lda, B, ldb, C, ldc, M_main, N, K, bias, residual, ldr, act, out_f32, accumulate, alpha, A2, lda2, B2, ldb2, K2, stream);
+        if (!rc)
+          rc = gemm_launch((const bf16_t*)A + (long)M_main * lda, lda, B, ldb, (char*)C + (long)M_main * ldc * esz, ldc, M_tail, N, K, bias,
+                           residual ? (const bf16_t*)residual + (long)M_main * ldr : nullptr, ldr, act, out_f32, accumulate, alpha,
+                           A2 ? (const bf16_t*)A2 + (long)M_main * lda2 : nullptr, lda2, B2, ldb2, K2, stream);
+        t_split_ok = true;
+        return rc;
+      }
+    }
+  }
   const bool big = t128 >= 384;
   int slot = -1;
   if (g_prof.on) {

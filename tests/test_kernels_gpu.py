@@ -471,3 +471,31 @@ def test_gemm_fused_rope_bit_identical_to_unfused(M, S, pos0, lora):
     hk.rope_(ref, M, 2 * d // hd, hd, cos, sin, pos_mod=S, pos0=pos0)
     assert torch.equal(got, ref)
     assert torch.equal(got[:, 2 * d:], plain[:, 2 * d:]) and not torch.equal(got[:, :2 * d], plain[:, :2 * d])
+
+
+@pytest.mark.parametrize("M,N,K,lora", [(8736, 4096, 4096, False), (8736, 4096, 11008, True), (4368, 4096, 4096, False), (8736, 2048, 1024, False)])
+def test_gemm_tail_rows_take_the_small_tile_kernel(M, N, K, lora):
+    """A nearly empty last round of 256x256 tiles (560 tiles = 2.19 rounds of the 256 CUs) is cut off: whole tile rows on the 16-wave
+    kernel, the spill-over rows on the small-tile kernel.  Same result as the single launch (and as the fp32 reference)."""
+    from lhrs_bot_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
+    b = (torch.randn(N, K, generator=g) * 0.02).to(DEV, torch.bfloat16)
+    r = torch.randn(M, N, generator=g).to(DEV, torch.bfloat16)
+    a2 = b2 = None
+    if lora:
+        a2 = (torch.randn(M, 64, generator=g) * 0.1).to(DEV, torch.bfloat16)
+        b2 = (torch.randn(N, 64, generator=g) * 0.05).to(DEV, torch.bfloat16)
+    run = (lambda: hk.gemm_nt_lora(a, b, a2, b2, residual=r)) if lora else (lambda: hk.gemm_nt(a, b, residual=r))
+    try:
+        lib.lhrs_gemm_set_tail_split(0)
+        whole = run()
+    finally:
+        lib.lhrs_gemm_set_tail_split(1)
+    split = run()
+    ref = a.float() @ b.float().t() + r.float() + ((a2.float() @ b2.float().t()) if lora else 0)
+    assert rel_err(split.float(), ref) < 1e-2 and rel_err(whole.float(), ref) < 1e-2
+    assert rel_err(split.float(), whole.float()) < 2e-3
+    f32 = hk.gemm_nt(a, b, out_f32=True)
+    assert rel_err(f32, a.float() @ b.float().t()) < 2e-3
