@@ -1614,6 +1614,133 @@ extern "C" int lhrs_gemm_swiglu_bwd(const void* dY, int ldy, const void* WdT, in
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Small-tile sibling of gemm_fp8_256_kernel (64x128 tile, 4 waves, the 2-stage DMA skeleton of gemm_nt_kernel; a stage row is 128 e4m3
+// bytes = one v_mfma_scale_f32_16x16x128_f8f6f4 step per fragment pair).  Takes the tail rows that the 256x256 kernel would run as a
+// nearly empty last round (see the tail-row rule in gemm_launch).  Same arithmetic and roundings as the big kernel: scale the e4m3 sum by
+// sa[m] * sb[n], add the optional bf16 pair (LoRA) on the same accumulators, * alpha, round to bf16, then add the bf16 residual.
+// ------------------------------------------------------------------------------------------------
+template <int WM_FR, int WN_FR>
+__global__ __launch_bounds__(256) void gemm_fp8_small_kernel(GemmArgs g) {
+  constexpr int BM = WM_FR * 32, BN = WN_FR * 32, ROWB = 128;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  int tm, tn;
+  tile_coords(g, tm, tn);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int A_INSTR = BM / 32, B_INSTR = BN / 32;  // 1-KiB pieces (8 rows x 128 B) per wave
+  const int lrow = lane >> 3;
+  const int lchunk = (lane & 7) ^ lrow;
+  const char *a_src[A_INSTR], *b_src[B_INSTR], *a2_src[A_INSTR], *b2_src[B_INSTR];
+#pragma unroll
+  for (int i = 0; i < A_INSTR; ++i) {
+    const int row = min(tm * BM + (wave * A_INSTR + i) * 8 + lrow, g.M - 1);
+    a_src[i] = reinterpret_cast<const char*>(g.A) + (long)row * g.lda + lchunk * 16;
+    a2_src[i] = reinterpret_cast<const char*>(g.A2) + ((long)row * g.lda2 + lchunk * 8) * 2;
+  }
+#pragma unroll
+  for (int i = 0; i < B_INSTR; ++i) {
+    const int row = min(tn * BN + (wave * B_INSTR + i) * 8 + lrow, g.N - 1);
+    b_src[i] = reinterpret_cast<const char*>(g.B) + (long)row * g.ldb + lchunk * 16;
+    b2_src[i] = reinterpret_cast<const char*>(g.B2) + ((long)row * g.ldb2 + lchunk * 8) * 2;
+  }
+  const int nk1 = g.K / 128, nk = nk1 + g.K2 / 64;
+  auto issue = [&](int kt) {
+    char* sa = smem + (kt & 1) * STAGE;
+    char* sb = sa + A_BYTES;
+    const bool e4 = kt < nk1;  // wave-uniform
+    const long ko = (long)(e4 ? kt : kt - nk1) * ROWB;
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)((e4 ? a_src[i] : a2_src[i]) + ko), (lptr_t)(sa + (wave * A_INSTR + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)((e4 ? b_src[i] : b2_src[i]) + ko), (lptr_t)(sb + (wave * B_INSTR + i) * 1024), 16, 0, 0);
+  };
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int a_row0 = wm * (WM_FR * 16) + fr, b_row0 = wn * (WN_FR * 16) + fr;
+  f32x4 acc[WM_FR][WN_FR];
+#pragma unroll
+  for (int i = 0; i < WM_FR; ++i)
+#pragma unroll
+    for (int j = 0; j < WN_FR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  issue(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) issue(kt + 1);
+    const char* sa = smem + (kt & 1) * STAGE;
+    const char* sb = sa + A_BYTES;
+    if (kt < nk1) {  // 128 e4m3 k per row: lane (r, g) feeds bytes [32g, 32g + 32) = chunks 2g, 2g + 1
+      const int c0 = ((2 * fg) ^ (fr & 7)) * 16, c1 = ((2 * fg + 1) ^ (fr & 7)) * 16;
+      i32x8 af[WM_FR], bfr[WN_FR];
+#pragma unroll
+      for (int mi = 0; mi < WM_FR; ++mi) {
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(sa + (a_row0 + mi * 16) * ROWB + c0), hi = *reinterpret_cast<const i32x4*>(sa + (a_row0 + mi * 16) * ROWB + c1);
+        af[mi] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int ni = 0; ni < WN_FR; ++ni) {
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(sb + (b_row0 + ni * 16) * ROWB + c0), hi = *reinterpret_cast<const i32x4*>(sb + (b_row0 + ni * 16) * ROWB + c1);
+        bfr[ni] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int mi = 0; mi < WM_FR; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN_FR; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+      if (kt + 1 == nk1 && g.K2 > 0) {  // the bf16 pair rides on the SCALED sums
+#pragma unroll
+        for (int mi = 0; mi < WM_FR; ++mi) {
+          const float sam = g.sa[min(tm * BM + wm * (WM_FR * 16) + mi * 16 + fr, g.M - 1)];
+#pragma unroll
+          for (int ni = 0; ni < WN_FR; ++ni) {
+            const float4 s4 = *reinterpret_cast<const float4*>(g.sb + min(tn * BN + wn * (WN_FR * 16) + ni * 16 + fg * 4, g.N - 4));
+            acc[mi][ni][0] *= sam * s4.x; acc[mi][ni][1] *= sam * s4.y; acc[mi][ni][2] *= sam * s4.z; acc[mi][ni][3] *= sam * s4.w;
+          }
+        }
+      }
+    } else {  // 64 bf16 k per row, exactly gemm_nt_kernel's stage
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ko = ((kk * 4 + fg) ^ (fr & 7)) * 16;
+        bf16x8 af[WM_FR], bfr[WN_FR];
+#pragma unroll
+        for (int mi = 0; mi < WM_FR; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(sa + (a_row0 + mi * 16) * ROWB + ko);
+#pragma unroll
+        for (int ni = 0; ni < WN_FR; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(sb + (b_row0 + ni * 16) * ROWB + ko);
+#pragma unroll
+        for (int mi = 0; mi < WM_FR; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < WN_FR; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+      }
+    }
+  }
+  const bool scaled = g.K2 > 0;
+#pragma unroll
+  for (int mi = 0; mi < WM_FR; ++mi) {
+    const int m = tm * BM + wm * (WM_FR * 16) + mi * 16 + fr;
+    if (m >= g.M) continue;
+    const float sam = (scaled ? 1.f : g.sa[m]) * g.alpha;
+#pragma unroll
+    for (int ni = 0; ni < WN_FR; ++ni) {
+      const int n = tn * BN + wn * (WN_FR * 16) + ni * 16 + fg * 4;
+      if (n >= g.N) continue;
+      float4 s4 = scaled ? make_float4(1.f, 1.f, 1.f, 1.f) : *reinterpret_cast<const float4*>(g.sb + n);
+      uint2 o = make_uint2(pack2bf(acc[mi][ni][0] * sam * s4.x, acc[mi][ni][1] * sam * s4.y), pack2bf(acc[mi][ni][2] * sam * s4.z, acc[mi][ni][3] * sam * s4.w));
+      if (g.res) {
+        const uint2 r = *reinterpret_cast<const uint2*>(g.res + (long)m * g.ldr + n);
+        o.x = pack2bf(bflo(o.x) + bflo(r.x), bfhi(o.x) + bfhi(r.x));
+        o.y = pack2bf(bflo(o.y) + bflo(r.y), bfhi(o.y) + bfhi(r.y));
+      }
+      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n) = o;
+    }
+  }
+}
+
 // C[M, N] (bf16) = alpha * sa[m] * sb[n] * (A8[M, K] . B8[N, K]^T) (+ residual): e4m3 operands with per-row fp32 scales
 // (lhrs_quant_fp8_rows).  K % 128 == 0, N % 8 == 0; lda / ldb in BYTES (>= K, multiples of 16).
 static int gemm_fp8_launch(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, const void* A2, int lda2,
@@ -1624,6 +1751,32 @@ static int gemm_fp8_launch(const void* A8, long lda, const float* sa, const void
   LHRS_REQUIRE(N % 8 == 0 && ldc % 8 == 0 && ldc >= N && (residual == nullptr || ldr % 8 == 0), "gemm_fp8: N=%d ldc=%d ldr=%d", N, ldc, ldr);
   LHRS_REQUIRE(K2 == 0 || (A2 && B2 && K2 % 64 == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && lda2 >= K2 && ldb2 >= K2),
                "gemm_fp8: bad bf16 pair (K2=%d lda2=%d ldb2=%d)", K2, lda2, ldb2);
+  // tail-row rule (see gemm_launch): the tile rows that spill over the last full round of the 256 CUs go to the small-tile kernel
+  if (t_split_ok && g_gemm_tail_split) {
+    const int tm = cdiv(M, 256), tn = cdiv(N, 256);
+    const long T = (long)tm * tn, rounds = (T + 255) / 256, full = T / 256;
+    const int tm_main = (int)(full * 256 / tn);
+    if (full >= 1 && T % 256 != 0 && tm_main >= 1 && tm_main < tm) {
+      const long t_main = (long)tm_main * tn, t_tail = T - t_main;
+      if ((double)((t_main + 255) / 256) + 2.5 * (double)t_tail / 256.0 + 0.05 < (double)rounds) {
+        const int M_main = tm_main * 256;
+        t_split_ok = false;
+        int rc = gemm_fp8_launch(A8, lda, sa, B8, ldb, sb, A2, lda2, B2, ldb2, K2, C, ldc, M_main, N, K, residual, ldr, alpha, stream);
+        t_split_ok = true;
+        if (rc) return rc;
+        GemmArgs h; memset(&h, 0, sizeof(h));
+        h.A = (const bf16_t*)((const char*)A8 + (long)M_main * lda); h.B = (const bf16_t*)B8; h.C = (bf16_t*)C + (long)M_main * ldc;
+        h.res = residual ? (const bf16_t*)residual + (long)M_main * ldr : nullptr;
+        h.M = M - M_main; h.N = N; h.K = K; h.lda = (int)lda; h.ldb = (int)ldb; h.ldc = ldc; h.ldr = ldr; h.alpha = alpha; h.sa = sa + M_main; h.sb = sb;
+        h.A2 = A2 ? (const bf16_t*)A2 + (long)M_main * lda2 : nullptr; h.B2 = (const bf16_t*)B2; h.lda2 = lda2; h.ldb2 = ldb2; h.K2 = K2;
+        h.tilesM = cdiv(h.M, 64); h.tilesN = cdiv(N, 128);
+        if (g_prof.on) { g_prof.launches_all++; g_prof.total_flops_all += 2.0 * h.M * N * (K + K2); }
+        hipLaunchKernelGGL((gemm_fp8_small_kernel<2, 4>), dim3(h.tilesM * h.tilesN), dim3(256), 0, (hipStream_t)stream, h);
+        LHRS_CHECK_LAUNCH("gemm_fp8_nt (tail rows)");
+        return 0;
+      }
+    }
+  }
   GemmArgs g; memset(&g, 0, sizeof(g));
   g.A = (const bf16_t*)A8; g.B = (const bf16_t*)B8; g.C = C; g.res = (const bf16_t*)residual;
   g.M = M; g.N = N; g.K = K; g.lda = (int)lda; g.ldb = (int)ldb; g.ldc = ldc; g.ldr = ldr; g.alpha = alpha; g.sa = sa; g.sb = sb;

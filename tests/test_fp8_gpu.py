@@ -18,7 +18,8 @@ def rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
-@pytest.mark.parametrize("M,N,K", [(8190, 4096, 4096), (300, 512, 256), (4095, 12288, 4096), (8190, 4096, 11008), (257, 1032, 384)])
+@pytest.mark.parametrize("M,N,K", [(8190, 4096, 4096), (300, 512, 256), (4095, 12288, 4096), (8190, 4096, 11008), (257, 1032, 384),
+                                   (8736, 4096, 4096), (4368, 4096, 11008), (8714, 4096, 4096)])  # the last three: tail rows on the small-tile kernel
 def test_gemm_fp8_matches_dequantised_product(M, N, K):
     g = torch.Generator().manual_seed(M + N)
     x = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
@@ -43,6 +44,15 @@ def test_gemm_fp8_matches_dequantised_product(M, N, K):
         b2 = (torch.randn(N, K2, generator=g) * 0.1).to(DEV, torch.bfloat16)
         y = hk.gemm_fp8_nt(x8, sx, w8, sw, residual=r, a2=a2, b2=b2)
         assert rel(y, ref + a2.float() @ b2.float().t() + r.float()) < 3e-3, K2
+    # tail-row rule on / off: the rows that move to the small-tile kernel keep their values (same products, same roundings)
+    from lhrs_bot_amd import _lib
+    lib = _lib.load()
+    try:
+        lib.lhrs_gemm_set_tail_split(0)
+        whole = hk.gemm_fp8_nt(x8, sx, w8, sw, residual=r, a2=a2, b2=b2)
+    finally:
+        lib.lhrs_gemm_set_tail_split(1)
+    assert rel(y, whole) < 1e-3 and rel(y[-200:], whole[-200:]) < 1e-3
 
 
 @pytest.mark.timeout(900)
