@@ -187,6 +187,8 @@ def main():
     lib = _lib.load()
     if a.gemm_policy is not None:
         lib.lhrs_gemm_set_policy(a.gemm_policy)
+    if os.environ.get("LHRS_GEMM_MIN_TILES"):  # kernel A/B tests only
+        lib.lhrs_gemm_set_min_tiles(int(os.environ["LHRS_GEMM_MIN_TILES"]))
     B, T = a.micro_batch, a.caption_tokens + 2
     S = T - 1 + 144
     model = UniBind(("rgb", "text"), None, device=dev, llama_layers=a.llama_layers).init_random(seed=0)  # same weights on every rank

@@ -99,6 +99,8 @@ int lhrs_gemm_set_policy(int allow_256);
 /* kernel A/B tests only: 0 disables the tail-row rule (a product whose last round of 256x256 tiles would be nearly empty is cut into
  * whole tile rows for the 16-wave kernel + the remaining rows for the small-tile kernel); default 1 */
 int lhrs_gemm_set_tail_split(int on);
+/* kernel A/B tests only: fewest 256x256 tiles for which lhrs_gemm_bf16_nt picks the big-tile kernel (default 128) */
+int lhrs_gemm_set_min_tiles(int n);
 int lhrs_gemm_profile_enable(int max_samples);
 int lhrs_gemm_profile_read(double* out5_host);
 

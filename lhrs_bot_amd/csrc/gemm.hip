@@ -1349,6 +1349,9 @@ extern "C" int lhrs_gemm_profile_read(double* out) {
 }
 
 static int g_gemm_allow_256 = 2;
+static int g_gemm_min256 = 128;  // fewest 256x256 tiles (half a round of the 256 CUs) for which the big-tile kernels are chosen: 2184 x 4096 (144
+                                 // tiles, the reference's micro-batch 8) runs 20 % faster there than on 576 small tiles; A/B: lhrs_gemm_set_min_tiles
+extern "C" int lhrs_gemm_set_min_tiles(int n) { g_gemm_min256 = n; return 0; }
 // tile policy switch for A/B measurements: 0 = never use a 256x256 kernel, 1 = simple ring kernel, 2 = pipelined (default)
 extern "C" int lhrs_gemm_set_policy(int allow_256) { g_gemm_allow_256 = allow_256; return 0; }
 
@@ -1427,7 +1430,7 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   } while (0)
   const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
   const bool al16 = out_f32 || (N % 8 == 0 && ldc % 8 == 0 && (residual == nullptr || ldr % 8 == 0));  // 16-B epilogue rows
-  bool use256 = g_gemm_allow_256 && t256 >= 160 && K >= 96 && K % 32 == 0 && al16;  // ring prologue needs >= 3 stages
+  bool use256 = g_gemm_allow_256 && t256 >= g_gemm_min256 && K >= 96 && K % 32 == 0 && al16;  // ring prologue needs >= 3 stages
   if (g.drop_thresh && !((g_gemm_allow_256 == 2 || g_gemm_allow_256 == 5) && K % 64 == 0 && K >= 128)) use256 = false;  // the mask lives in the r kernel and in store4
   if (K2 > 0 && !use256) {  // small problems: base GEMM, then the rank-K2 update accumulated on top of it
     if (gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, out_f32, accumulate, alpha, nullptr, 0, nullptr, 0, 0, stream))
@@ -1520,14 +1523,14 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
 // forward : gu[M, 2*ff] = x W_gu^T (+ LoRA pair), act[M, ff] = silu(gu[:, :ff]) * gu[:, ff:]     - one launch instead of GEMM + swiglu_fwd
 // backward: dgu[M, 2*ff] = swiglu'(gu) * (dy W_down) (+ LoRA pair); dgu may alias gu             - one launch instead of GEMM + swiglu_bwd
 // Results are bit-identical to the unfused sequence (the epilogue rounds gate / up / d_act to bf16 exactly where the unfused path
-// stores them).  Shapes the 16-wave 256x256 kernel does not take (K % 64, < 160 tiles, ff % 128) fall back to the unfused sequence.
+// stores them).  Shapes the 16-wave 256x256 kernel does not take (K % 64, fewer tiles than the big-tile threshold, ff % 128) fall back to the unfused sequence.
 extern "C" int lhrs_swiglu_fwd(const void* gate_up, void* act, long rows, int F, void* stream);
 extern "C" int lhrs_swiglu_bwd(const void* dact, const void* gate_up, void* dgate_up, long rows, int F, void* stream);
 extern "C" int lhrs_rope(void* x, long ld, int rows, int nheads, int D, const float* cos_t, const float* sin_t, const int* pos_ids, int pos_mod,
                          int pos0, int inverse, void* stream);
 
 static bool swiglu_fusable(long tiles, int ff, int K, int K2, int lda, int ldb) {
-  return (g_gemm_allow_256 == 2 || g_gemm_allow_256 == 5) && ff % 256 == 0 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128 && tiles >= 160 &&
+  return (g_gemm_allow_256 == 2 || g_gemm_allow_256 == 5) && ff % 256 == 0 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128 && tiles >= g_gemm_min256 &&
          lda % 8 == 0 && ldb % 8 == 0;
 }
 // 1 when lhrs_gemm_swiglu_fwd / _bwd will take the fused kernel for this problem (dense operands), else 0 (they fall back)
@@ -1576,7 +1579,7 @@ extern "C" int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw
                "gemm_rope_fwd: M=%d N=%d K=%d rope_cols=%d head_dim=%d pos_mod=%d", M, N, K, rope_cols, head_dim, pos_mod);
   const long tiles = (long)cdiv(M, 256) * cdiv(N, 256);
   const bool fused = (g_gemm_allow_256 == 2 || g_gemm_allow_256 == 5) && head_dim == 128 && rope_cols % 256 == 0 && N % 8 == 0 && K % 64 == 0 &&
-                     K2 % 64 == 0 && K + K2 >= 128 && tiles >= 160 && ldx % 8 == 0 && ldw % 8 == 0;
+                     K2 % 64 == 0 && K + K2 >= 128 && tiles >= g_gemm_min256 && ldx % 8 == 0 && ldw % 8 == 0;
   if (!fused) {
     if (gemm_launch(X, ldx, W, ldw, C, ldc, M, N, K, nullptr, nullptr, 0, 0, 0, 0, 1.f, A2, lda2, B2, ldb2, K2, stream)) return -1;
     if (rope_cols == 0) return 0;
