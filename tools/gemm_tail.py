@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lhrs_bot_amd import _lib, kernels as hk
 lib = _lib.load()
-for M, N, K in [(8736, 4096, 4096), (8736, 4096, 11008), (8736, 4096, 12288), (8736, 4096, 22016), (8736, 12288, 4096), (4368, 4096, 4096), (10000, 4096, 4096)]:
+for M, N, K in [(8736, 4096, 4096), (8736, 4096, 11008), (8736, 4096, 12288), (8736, 4096, 22016), (8736, 12288, 4096), (4368, 4096, 4096), (10000, 4096, 4096),
+                (2184, 4096, 4096), (2184, 4096, 11008), (2184, 4096, 22016), (7710, 1024, 1024), (7710, 1024, 4096), (7710, 3072, 1024), (4320, 1024, 4096), (4320, 4096, 1024)]:
     a = (torch.rand(M, K, device="cuda") * 2 - 1).to(torch.bfloat16)
     b = (torch.rand(N, K, device="cuda") * 2 - 1).to(torch.bfloat16)
     c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
