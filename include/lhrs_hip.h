@@ -73,6 +73,12 @@ int lhrs_swiglu_bwd_q(const void* dact, const void* gate_up, void* dgu, void* dg
 int lhrs_gemm_skinny_splits(int K, int N);
 int lhrs_gemm_bf16_nt_skinny(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, float alpha,
                              float* workspace, void* stream);
+/* Long-K product with few output tiles and f32 output - the projector weight gradients dW[out, in] = dY^T X accumulated over all
+ * tokens (what autograd computes for nn.Linear / nn.MultiheadAttention in common_arch.py:93-173,302-333): K split across blocks into
+ * f32 slabs of `workspace` (lhrs_gemm_splitk_splits(M, N, K) * M * N floats; may be NULL when that is 1), summed in a fixed order. */
+int lhrs_gemm_splitk_splits(int M, int N, int K);
+int lhrs_gemm_bf16_nt_splitk_f32(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                                 float* workspace, void* stream);
 /* LLaMA MLP with SwiGLU fused into the GEMM epilogues (HF LlamaMLP.forward: down(silu(gate(x)) * up(x)); text_modal.py:258-294).
  * fwd: gu[M, 2*ff] = X.Wgu^T (+ A2.B2^T), act[M, ff] = silu(gate) * up.  bwd: dgu[M, 2*ff] = swiglu'(gu) * (dY.WdT^T (+ A2.B2^T)),
  * dgu may alias gu; dact_scratch [M, ff] is only touched by the unfused fallback (may be NULL when lhrs_gemm_swiglu_fusable() == 1).

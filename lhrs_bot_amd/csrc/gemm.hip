@@ -1301,6 +1301,21 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, bf16_t* __r
   }
 }
 
+// sum of `splits` f32 slabs [M, N] -> f32 C[M, ldc]
+__global__ void splitk_reduce_f32_kernel(const float* __restrict__ part, float* __restrict__ C, long ldc, int M, int N, int splits) {
+  const long total = (long)M * (N / 4);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / (N / 4);
+    const int n = (int)(i % (N / 4)) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < splits; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(part + ((long)k * M + m) * N + n);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(C + m * ldc + n) = s;
+  }
+}
+
 }  // namespace
 
 // ---- optional live timing of the GEMM launches (bench.py roofline leg) -----------------------------------
@@ -1834,5 +1849,41 @@ extern "C" int lhrs_gemm_bf16_nt_skinny(const void* A, int lda, const void* B, i
   int rg = (int)((work + 255) / 256); if (rg > 8192) rg = 8192;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, s, workspace, (bf16_t*)C, (long)ldc, M, N, used, alpha);
   LHRS_CHECK_LAUNCH("gemm_skinny_reduce");
+  return 0;
+}
+
+
+// Long-K, few-tile product with f32 output (the projector's weight gradients dW = dY^T X over the token dimension: K = B * 912 = 27392
+// against 2048 x 1024 outputs = 128 tiles of 128^2 for 256 CUs): K is split `lhrs_gemm_splitk_splits` ways across blockIdx.y into f32 slabs
+// of the workspace (splits * M * N floats), then summed in a fixed order (deterministic).  splits == 1 -> one plain launch.
+extern "C" int lhrs_gemm_splitk_splits(int M, int N, int K) {
+  const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
+  long s = (512 + tiles / 2) / tiles;
+  if (s > K / 1024) s = K / 1024;
+  if (s > 8) s = 8;
+  return s < 1 ? 1 : (int)s;
+}
+
+extern "C" int lhrs_gemm_bf16_nt_splitk_f32(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                                            float* workspace, void* stream) {
+  LHRS_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 4 == 0 && ldc % 4 == 0 && ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K,
+               "gemm_splitk_f32: M=%d N=%d K=%d lda=%d ldb=%d ldc=%d", M, N, K, lda, ldb, ldc);
+  const int splits = lhrs_gemm_splitk_splits(M, N, K);
+  if (splits == 1) return gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, nullptr, nullptr, 0, 0, 1, 0, 1.f, nullptr, 0, nullptr, 0, 0, stream);
+  LHRS_REQUIRE(workspace != nullptr, "gemm_splitk_f32: %d splits need a workspace of splits * M * N floats", splits);
+  const int ks = cdiv(K / 64, splits) * 64;
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = workspace; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = N;
+  g.alpha = 1.f; g.out_f32 = 1; g.ksplit = ks;
+  g.tilesM = cdiv(M, 128); g.tilesN = cdiv(N, 128);
+  const int used = cdiv(K, ks);
+  hipStream_t s = (hipStream_t)stream;
+  if (g_prof.on) { g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * K; }
+  hipLaunchKernelGGL((gemm_nt_kernel<4, 4, 0>), dim3(g.tilesM * g.tilesN, used), dim3(256), 0, s, g);
+  LHRS_CHECK_LAUNCH("gemm_splitk_f32");
+  const long work = (long)M * (N / 4);
+  int rg = (int)((work + 255) / 256); if (rg > 8192) rg = 8192;
+  hipLaunchKernelGGL(splitk_reduce_f32_kernel, dim3(rg), dim3(256), 0, s, workspace, C, (long)ldc, M, N, used);
+  LHRS_CHECK_LAUNCH("gemm_splitk_f32 reduce");
   return 0;
 }

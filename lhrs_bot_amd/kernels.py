@@ -145,6 +145,19 @@ def gemm_nt_skinny(a, b, alpha=1.0):
     return out
 
 
+def gemm_nt_splitk_f32(a, b, out):
+    """out[M, N] fp32 = a[M, K] @ b[N, K]^T for a long K and few output tiles (weight gradients): split-K launch + ordered reduction."""
+    M, K = a.shape
+    N = b.shape[0]
+    L = _L()
+    splits = L.lhrs_gemm_splitk_splits(M, N, K)
+    ws = torch.empty(splits * M * N, device=a.device, dtype=torch.float32) if splits > 1 else None
+    st = L.lhrs_gemm_bf16_nt_splitk_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N, K,
+                                        _p(ws), _stream())
+    _lib.check(st, "gemm_bf16_nt_splitk_f32")
+    return out
+
+
 class BatchedTranspose:
     """out_i = in_i^T for a fixed list of (in, out) bf16 matrix pairs, refreshed by ONE launch (lhrs_transpose_batched)."""
 

@@ -190,7 +190,7 @@ class AttnPooler:
         dyT = hk.transpose(dy, rows_pad=Mp)
         xT = hk.transpose(x, rows_pad=Mp)
         g = self.g[name] if rows is None else self.g[name][rows[0]: rows[1]]
-        hk.gemm_nt(dyT, xT, out=g, out_f32=True)
+        hk.gemm_nt_splitk_f32(dyT, xT, g)  # K = padded token count (B * 912 for the kv projection): split across blocks, ordered sum
 
     def backward(self, d_out: torch.Tensor, on_ready=None) -> None:
         """d_out [B,144,4096] bf16 -> fills self.grad (fp32).  The ViT is frozen: no image gradient is produced.

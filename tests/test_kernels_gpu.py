@@ -499,3 +499,20 @@ def test_gemm_tail_rows_take_the_small_tile_kernel(M, N, K, lora):
     assert rel_err(split.float(), whole.float()) < 2e-3
     f32 = hk.gemm_nt(a, b, out_f32=True)
     assert rel_err(f32, a.float() @ b.float().t()) < 2e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 1024, 27392), (1024, 1024, 4352), (4096, 1024, 4352), (1024, 4096, 4352), (256, 128, 640)])
+def test_gemm_splitk_f32_weight_gradient_shapes(M, N, K):
+    """Long-K products with few output tiles (the projector's dW = dY^T X over the token dimension): split-K slabs + ordered sum."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * 0.1).to(DEV, torch.bfloat16)
+    b = (torch.randn(N, K, generator=g) * 0.1).to(DEV, torch.bfloat16)
+    buf = torch.zeros(M + 3, N, device=DEV, dtype=torch.float32)
+    out = buf[3:]                                   # a row range of a larger fp32 gradient buffer
+    hk.gemm_nt_splitk_f32(a, b, out)
+    ref = a.float() @ b.float().t()
+    assert rel_err(out, ref) < 1e-5 and float(buf[:3].abs().max()) == 0.0
+    again = torch.empty_like(out)
+    hk.gemm_nt_splitk_f32(a, b, again)
+    assert torch.equal(out, again)                  # fixed summation order: bit-reproducible
+    assert rel_err(out, hk.gemm_nt(a, b, out_f32=True)) < 1e-5
