@@ -123,15 +123,25 @@ class AttnPooler:
         self.refresh_transposed()
 
     def refresh_transposed(self) -> None:
+        """Transposed bf16 copies of the 31 weight matrices (dX = dY . W as an NT GEMM), rebuilt after every optimizer step: the first
+        call allocates them, every later one is ONE batched launch (lhrs_transpose_batched) over the fixed (weight view, copy) pairs."""
+        if getattr(self, "_bt", None) is not None:
+            self._bt.run()
+            return
         d = self.d
+        pairs = []
         for l in range(self.nl):
             b = f"layers.{l}."
             W = self.w[b + "attn.in_proj_weight"]
-            self.wT[b + "q"] = hk.transpose(W[:d], out=self.wT.get(b + "q"))          # [d, d]
-            self.wT[b + "kv"] = hk.transpose(W[d:], out=self.wT.get(b + "kv"))        # [d, 2d]
+            for key, src in ((b + "q", W[:d]), (b + "kv", W[d:])):                    # [d, d], [d, 2d]
+                self.wT[key] = hk.transpose(src, out=self.wT.get(key))
+                pairs.append((src, self.wT[key]))
             for key in ("attn.out_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight"):
                 self.wT[b + key] = hk.transpose(self.w[b + key], out=self.wT.get(b + key))
+                pairs.append((self.w[b + key], self.wT[b + key]))
         self.wT["out_proj.weight"] = hk.transpose(self.w["out_proj.weight"], out=self.wT.get("out_proj.weight"))
+        pairs.append((self.w["out_proj.weight"], self.wT["out_proj.weight"]))
+        self._bt = hk.BatchedTranspose(pairs)   # self.w are views of the flat bf16 shadow: same storage for the life of the projector
 
     def _desc(self, B: int) -> torch.Tensor:
         if B not in self._desc_cache:
