@@ -289,6 +289,15 @@ def rmsnorm_bwd_q(dy, x, w, rstd=None, add=None, eps=1e-5, out=None):
 
 
 # --------------------------------------------------------------------------------------------- attention
+def h2d(t: torch.Tensor, device) -> torch.Tensor:
+    """Small host tensor -> device without stalling the host: a pageable source makes the copy wait for everything already queued on
+    the stream (the launch queue drains, the GPU then idles until new work arrives); a pinned source with non_blocking=True is just
+    another item in the queue."""
+    if t.is_cuda:
+        return t
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def make_desc(entries, device) -> torch.Tensor:
     """entries: list of (q_off, q_len, kv_off, kv_len[, kv_rows[, causal_off]]) -> int32 [n, 8] on device."""
     rows = []
@@ -299,7 +308,7 @@ def make_desc(entries, device) -> torch.Tensor:
         if len(e) == 5:
             e.append(0)
         rows.append(e + [0, 0])
-    return torch.tensor(rows, dtype=torch.int32).to(device)
+    return h2d(torch.tensor(rows, dtype=torch.int32), device)
 
 
 def pad64(n: int) -> int:

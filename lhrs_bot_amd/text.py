@@ -390,12 +390,14 @@ class TextModal:
             save.append(rec)
         return x_out
 
-    def forward_hidden(self, embeds, mask_u8, save_ctx=True):
-        """embeds [B,S,d] bf16, mask [B,S] uint8 (right padding) -> final-norm hidden [B*S, d]."""
+    def forward_hidden(self, embeds, mask_u8, save_ctx=True, kv_len=None):
+        """embeds [B,S,d] bf16, mask [B,S] uint8 (right padding) -> final-norm hidden [B*S, d].  kv_len: the per-sequence key counts when
+        the caller already has them on the host (saves the device round trip of summing the mask)."""
         B, S, d = embeds.shape
         if S > self.cos.shape[0]:
             raise ValueError(f"sequence length {S} exceeds the {self.cos.shape[0]} positions of the RoPE table")
-        kv_len = mask_u8.to(torch.int32).sum(dim=1).tolist() if mask_u8 is not None else [S] * B
+        if kv_len is None:
+            kv_len = mask_u8.to(torch.int32).sum(dim=1).tolist() if mask_u8 is not None else [S] * B
         desc = hk.make_desc([(b * S, S, b * S, int(kv_len[b]), S, 0) for b in range(B)], self.device)
         LT = hk.pad64(S)
         saved: Optional[List] = [] if save_ctx else None
@@ -409,25 +411,74 @@ class TextModal:
             self._ctx = dict(B=B, S=S, desc=desc, LT=LT, layers=saved, x_last=x)
         return hidden
 
-    def decode(self, input_ids, image_embedding=None, attention_mask=None, labels=None, save_ctx=True):
-        """TextModal.decode: returns the scalar text loss (0-dim fp32 device tensor)."""
-        embeds, new_labels, new_mask, img_pos = self.prepare_inputs_for_multimodal(input_ids, attention_mask, labels, image_embedding)
-        B, S, d = embeds.shape
-        hidden = self.forward_hidden(embeds, new_mask, save_ctx)
+    @staticmethod
+    def splice_ints_host(ids, labels, mask, NI):
+        """Host mirror of the INTEGER outputs of `lhrs_splice_fwd` (text_modal.py:296-526: spliced length, labels, mask) on CPU tensors -
+        what the training step needs on the host anyway (attention descriptor, supervised rows), computed without asking the device.
+        -> (S, has_image [B] bool, new_labels [B,S] int64, new_mask [B,S] uint8); tests pin it to the device kernel."""
+        B, T = ids.shape
+        is_img = ids == IMAGE_TOKEN_INDEX
+        n_img = is_img.sum(dim=1)
+        if int(n_img.max()) > 1:
+            raise NotImplementedError("more than one <image> token per sample is not supported by the device splice")
+        has = n_img > 0
+        S = T - 1 + NI if bool(has.any()) else T
+        p = torch.where(has, is_img.to(torch.int64).argmax(dim=1), torch.full((B,), T, dtype=torch.int64))[:, None]
+        hasb = has[:, None]
+        j = torch.arange(S, dtype=torch.int64)[None, :]
+        new_len = torch.where(hasb, torch.full_like(p, T - 1 + NI), torch.full_like(p, T))
+        shift = new_len - T
+        src_tok = torch.where(~hasb | (j < p), j.expand(B, S), torch.where(j < p + NI, torch.full((B, S), -1, dtype=torch.int64), j - NI + 1))
+        src_tok = torch.where(j < new_len, src_tok, torch.full_like(src_tok, -1))
+        if labels is None:
+            new_labels = torch.full((B, S), IGNORE_INDEX, dtype=torch.int64)
+        else:
+            new_labels = torch.where(src_tok >= 0, labels.to(torch.int64).gather(1, src_tok.clamp(0, T - 1)), torch.full((B, S), IGNORE_INDEX, dtype=torch.int64))
+        m = torch.ones((B, T), dtype=torch.uint8) if mask is None else mask.to(torch.uint8)
+        new_mask = torch.where(j < new_len, torch.where(j < shift, torch.ones((B, S), dtype=torch.uint8), m.gather(1, (j - shift).clamp(0, T - 1))),
+                               torch.zeros((B, S), dtype=torch.uint8))
+        return S, has, new_labels, new_mask
+
+    def _ints_to_host(self, *ts):
+        """CPU views of the small integer inputs.  Host tensors (what a DataLoader delivers) pass through; device tensors cost ONE
+        synchronising copy for all of them."""
+        out = [None if t is None else (t if not t.is_cuda else t.to("cpu", non_blocking=True)) for t in ts]
+        if any(t is not None and t.is_cuda for t in ts):
+            torch.cuda.current_stream().synchronize()
+        return out
+
+    def decode(self, input_ids, image_embedding=None, attention_mask=None, labels=None, save_ctx=True, host_ints=None):
+        """TextModal.decode: returns the scalar text loss (0-dim fp32 device tensor).  All integer bookkeeping of the step (spliced
+        length, key counts, supervised rows, shifted targets) happens on the host from the host copies of ids / labels / mask, so the
+        launch queue is never drained in the middle of a step; the device splice only moves embedding rows.  host_ints: those copies
+        when the caller fetched them already (UniBind.forward does, before it enqueues the ViT)."""
+        if labels is None:
+            raise ValueError("decode() computes the training loss: labels are required")
+        ids_h, lab_h, msk_h = host_ints if host_ints is not None else self._ints_to_host(input_ids, labels, attention_mask)
+        B, T = ids_h.shape
+        if image_embedding is None:
+            if bool((ids_h == IMAGE_TOKEN_INDEX).any()):
+                raise ValueError("input_ids contain the <image> placeholder but no image embedding was given")
+            image_embedding = torch.zeros((B, 1, self.d), device=self.device, dtype=torch.bfloat16)
+        NI = image_embedding.shape[1]
+        S, _, new_labels, new_mask = self.splice_ints_host(ids_h, lab_h, msk_h, NI)
         # shifted targets: position j predicts label j+1 (HF LlamaForCausalLM.forward); ignore_index rows are skipped
         tgt = torch.full_like(new_labels, IGNORE_INDEX)
         tgt[:, :-1] = new_labels[:, 1:]
-        rows = torch.nonzero(tgt.reshape(-1) != IGNORE_INDEX).squeeze(1)
-        n = rows.numel()
-        if n == 0:
+        flat = tgt.reshape(-1)
+        rows = torch.nonzero(flat != IGNORE_INDEX).squeeze(1)
+        if rows.numel() == 0:
             raise ValueError("no valid target token in the micro-batch (loss would be NaN in the reference)")
-        rows32 = rows.to(torch.int32)
-        targets = tgt.reshape(-1)[rows].to(torch.int32)
+        rows32 = hk.h2d(rows.to(torch.int32), self.device)
+        targets = hk.h2d(flat[rows].to(torch.int32), self.device)
+        ids_d = input_ids if input_ids.is_cuda else hk.h2d(ids_h.contiguous(), self.device)
+        embeds, _, _, img_pos = hk.splice_fwd(ids_d, None, None, image_embedding.contiguous(), self.p["embed"], S)
+        hidden = self.forward_hidden(embeds, None, save_ctx, kv_len=new_mask.to(torch.int32).sum(dim=1).tolist())
         hv = hk.gather_rows(hidden, rows32)
         logits = hk.gemm_nt(hv, self.p["lm_head"])
         loss, dlogits = hk.cross_entropy(logits, targets, want_grad=save_ctx, inplace=True)
         if save_ctx:
-            self._ctx.update(rows=rows32, dlogits=dlogits, img_pos=img_pos, NI=image_embedding.shape[1])
+            self._ctx.update(rows=rows32, dlogits=dlogits, img_pos=img_pos, NI=NI)
         return loss
 
     __call__ = decode

@@ -114,9 +114,12 @@ class UniBind:
         """UniBind.forward: {"text_loss", "total_loss"} as 0-dim device tensors."""
         pool_grad = self.training and self.rgb_pooler.requires_grad
         grad = pool_grad or (self.training and self.text.lora is not None)
+        # host copies of the small integer inputs FIRST: if they live on the device this is the one synchronising copy of the step, and
+        # it happens while the queue is empty anyway (step boundary) instead of draining it behind the ViT
+        host_ints = self.text._ints_to_host(data["input_ids"], data["labels"], data.get("attention_mask"))
         image_embedding = self.rgb_pooler.forward(self.rgb.encode(data["rgb"]), save_ctx=pool_grad)
         loss = self.text.decode(data["input_ids"], image_embedding=image_embedding, attention_mask=data.get("attention_mask"),
-                                labels=data["labels"], save_ctx=grad)
+                                labels=data["labels"], save_ctx=grad, host_ints=host_ints)
         return {"text_loss": loss, "total_loss": loss}
 
     __call__ = forward

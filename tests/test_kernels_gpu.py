@@ -516,3 +516,30 @@ def test_gemm_splitk_f32_weight_gradient_shapes(M, N, K):
     hk.gemm_nt_splitk_f32(a, b, again)
     assert torch.equal(out, again)                  # fixed summation order: bit-reproducible
     assert rel_err(out, hk.gemm_nt(a, b, out_f32=True)) < 1e-5
+
+
+def test_host_splice_integers_equal_the_device_splice():
+    """TextModal.splice_ints_host (what the training step uses for its host-side bookkeeping) == the integer outputs of lhrs_splice_fwd
+    (pinned bit-exact to the reference): ragged right-padded batches, samples without an <image> token, missing mask / labels."""
+    from lhrs_bot_amd.text import TextModal
+    g = torch.Generator().manual_seed(11)
+    NI, dim, V = 7, 64, 500
+    embed = torch.randn(V, dim, generator=g).to(DEV, torch.bfloat16)
+    for trial in range(12):
+        B, T = int(torch.randint(1, 6, (1,), generator=g)), int(torch.randint(2, 19, (1,), generator=g))
+        ids = torch.randint(1, V, (B, T), generator=g)
+        labels = torch.randint(-1, V, (B, T), generator=g)
+        labels[labels < 0] = -100
+        lens = torch.randint(1, T + 1, (B,), generator=g)
+        mask = (torch.arange(T)[None, :] < lens[:, None])
+        with_img = torch.rand(B, generator=g) < (0.0 if trial == 0 else 0.75)
+        for b in range(B):
+            if with_img[b]:
+                ids[b, int(torch.randint(0, int(lens[b]), (1,), generator=g))] = -200
+        image = torch.randn(B, NI, dim, generator=g).to(DEV, torch.bfloat16)
+        for lab, msk in ((labels, mask), (None, mask), (labels, None)):
+            S, has, nl, nm = TextModal.splice_ints_host(ids, lab, msk, NI)
+            assert S == (T - 1 + NI if bool(with_img.any()) else T) and torch.equal(has, with_img)
+            _, dl, dm, pos = hk.splice_fwd(ids.to(DEV), None if lab is None else lab.to(DEV), None if msk is None else msk.to(DEV), image, embed, S)
+            assert torch.equal(dl.cpu(), nl) and torch.equal(dm.cpu(), nm), trial
+            assert torch.equal(pos.cpu() >= 0, with_img)
