@@ -142,6 +142,20 @@ class _SmiSampler:
         pw = [p for _, p in s if p is not None]
         return sum(c for c, _ in s) / len(s), (sum(pw) / len(pw) if pw else None)
 
+def spawn_ranks(n: int):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU, as the reference's
+    `deepspeed --num_gpus=8` does (Script/train_stage1.sh:6-17).  Rank 0 prints the JSON line; the exit status is the launcher's."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    os.execvpe(sys.executable, cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,18 +176,26 @@ def main():
                     help="stages 2/3 only: 8 = frozen decoder linears in e4m3 (the reference's `bits: 8` base weights)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a.gpus)  # does not return
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the LHRS hot path has no CPU fallback (cpu_baseline is only the checker)")
-    if os.environ.get("LHRS_SHARE_GPU") == "1":  # smoke test: every rank on GPU 0 (gloo backend only)
+    share = os.environ.get("LHRS_SHARE_GPU") == "1"  # smoke test on a 1-GPU box: every rank on GPU 0 (gloo backend only)
+    if world > torch.cuda.device_count() and not share:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} device(s) visible (LHRS_SHARE_GPU=1 runs the ranks on "
+                         "one device over gloo: a plumbing test, not a measurement)")
+    if share and world > torch.cuda.device_count():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("LHRS_DIST_BACKEND", "nccl")  # "nccl" = RCCL over xGMI; "gloo" only for single-GPU smoke tests
+        # "nccl" = RCCL over xGMI whenever every rank has its own device; gloo only for the shared-device smoke test
+        backend = os.environ.get("LHRS_DIST_BACKEND") or ("nccl" if world <= torch.cuda.device_count() else "gloo")
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -260,7 +282,8 @@ def main():
                        "micro_batch_per_gpu": B, "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
                        "optimizer": "adanp" if a.stage == 1 else "adamw", "stage": a.stage,
                        "lora": None if a.stage == 1 else ("r=8 on q,k,v,o, no dropout (text.eval())" if a.stage == 3 else "r=128 on all 7 linears, lora_dropout 0.05"),
-                       "grad_allreduce": a.comm_dtype if world > 1 else "none"},
+                       "grad_allreduce": a.comm_dtype if world > 1 else "none",
+                       "dist_backend": (torch.distributed.get_backend() if world > 1 else None)},
             "loss": round(final_loss, 4),
             "step_mfma_frac": round(sps / world * f_alg(S) / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 and a.stage == 1 else None,
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_256r_kernel<ACT, 0> (256x256 tile, 16 waves, BK=64 double-buffered LDS stages via global_load_lds DMA, v_mfma_f32_32x32x16_bf16; the two launches per layer with a fused SwiGLU epilogue are timed by rocprof only)", "achieved": round(ach, 1),

@@ -143,7 +143,7 @@ def _pooler_wd_ranges(pool):
 class LHRSEngine:
     def __init__(self, model, optimizer: str = "adanp", lr: float = 2e-4, weight_decay: float = 0.0,
                  max_grad_norm: float = 0.3, betas=None, eps: float = 1e-8, process_group=None, comm_dtype=torch.float32,
-                 gradient_accumulation_steps: int = 1):
+                 gradient_accumulation_steps: int = 1, broadcast_trainable: bool = True):
         self.module = self.model = model
         self.pool = model.rgb_pooler
         self.opt_name = optimizer.lower()
@@ -186,6 +186,65 @@ class LHRSEngine:
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(self.pg)
         self.reducers = {st.name: GradReducer(st.grad, st.buckets, self.pg, comm_dtype) for st in self.stores} if self.world > 1 else {}
+        if self.world > 1:
+            self.sync_replicas(broadcast_trainable)
+
+    # ------------------------------------------------------------------ replica consistency at start-up
+    def replica_checksums(self) -> torch.Tensor:
+        """fp64 [sum, sum of squares] of every frozen tensor group (ViT, LLaMA) and of every trainable master: what must be equal
+        on all ranks before the first step.  Pure reductions on the device (the LLaMA pass reads 13.5 GB once: ~3 ms)."""
+        dev = self.pool.device
+
+        def walk(o):
+            if torch.is_tensor(o):
+                yield o
+            elif isinstance(o, dict):
+                for k in sorted(o, key=str):
+                    if not (isinstance(k, str) and k.endswith("T")):  # transposed copies are derived from the tensors already visited
+                        yield from walk(o[k])
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    yield from walk(v)
+
+        rows = []
+        for part in (getattr(getattr(self.model, "rgb", None), "p", None), getattr(getattr(self.model, "text", None), "p", None)):
+            acc = torch.zeros(2, dtype=torch.float64, device=dev)
+            for t in walk(part or {}):
+                if t.is_floating_point():
+                    f = t.double() if t.numel() <= (1 << 24) else None
+                    if f is None:  # large tensors: chunked so the fp64 temporary stays small
+                        for c in t.reshape(-1).split(1 << 24):
+                            c = c.double()
+                            acc += torch.stack((c.sum(), (c * c).sum()))
+                    else:
+                        acc += torch.stack((f.sum(), (f * f).sum()))
+            rows.append(acc)
+        for st in self.stores:
+            f = st.master.double()
+            rows.append(torch.stack((f.sum(), (f * f).sum())))
+        return torch.stack(rows)
+
+    def sync_replicas(self, broadcast_trainable: bool = True) -> None:
+        """What DeepSpeed does inside `deepspeed.initialize` (main_pretrain_stage1.py:215-220: the engine broadcasts the module's
+        parameters from rank 0) plus a hard check the reference lacks: rank 0's trainable masters are broadcast (80 M fp32 = 320 MB over
+        xGMI, once), then a checksum of every frozen tensor group and of the masters is compared across ranks (MIN/MAX all-reduce of a
+        [groups, 2] fp64 table).  A mismatch - e.g. a checkpoint loaded on one rank only, or ranks seeded differently - is an error."""
+        dist = torch.distributed
+        if broadcast_trainable:
+            for st in self.stores:
+                dist.broadcast(st.master, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
+                hk.cast_f32_to_bf16(st.master, st.shadow) if st.master.is_cuda else st.shadow.copy_(st.master)
+                st.refresh()
+        cs = self.replica_checksums()
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.pg)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.pg)
+        if not torch.equal(lo, hi):
+            names = ["rgb (frozen ViT)", "text (frozen LLaMA)"] + [f"trainable:{st.name}" for st in self.stores]
+            bad = [n for n, a, b in zip(names, lo.tolist(), hi.tolist()) if a != b]
+            raise RuntimeError(f"data-parallel replicas differ at engine construction in {bad}: every rank must load / seed the same "
+                               "weights (rank-0 broadcast covers only the trainable parameters)")
+        self.replica_checksum = cs
 
     # back-compat accessors used by tests / tools (stage-1: the projector's optimizer state)
     @property

@@ -474,6 +474,7 @@ class TextModal:
         ids_d = input_ids if input_ids.is_cuda else hk.h2d(ids_h.contiguous(), self.device)
         embeds, _, _, img_pos = hk.splice_fwd(ids_d, None, None, image_embedding.contiguous(), self.p["embed"], S)
         hidden = self.forward_hidden(embeds, None, save_ctx, kv_len=new_mask.to(torch.int32).sum(dim=1).tolist())
+        self.last_hidden = hidden  # [B*S, d] final-norm output of this call (parity tests read it; the buffer exists anyway)
         hv = hk.gather_rows(hidden, rows32)
         logits = hk.gemm_nt(hv, self.p["lm_head"])
         loss, dlogits = hk.cross_entropy(logits, targets, want_grad=save_ctx, inplace=True)

@@ -20,7 +20,7 @@ torch.set_num_threads(8)
 NL = 8
 
 
-def main():
+def main(NL=NL, T=40, ids_seed=404, rgb_seed=405, name="unibind_e2e_8l.npz", with_hidden=False):
     cfg, CLIPVisionConfig, CLIPVisionModel, LlamaConfig = MG.import_reference_models()
     CLIPVisionModel.from_pretrained = staticmethod(lambda name, **kw: CLIPVisionModel(CLIPVisionConfig(
         hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=224,
@@ -57,31 +57,38 @@ def main():
     del llama
     model.text.tune_pooler = False
 
-    g = torch.Generator().manual_seed(404)
-    B, T = 2, 40
+    g = torch.Generator().manual_seed(ids_seed)
+    B = 2
     ids = torch.randint(3, 32000, (B, T), generator=g)
     ids[:, 0], ids[:, 1] = 1, -200
     labels = ids.clone()
     labels[:, :2] = -100
-    rgb = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(405))
+    rgb = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(rgb_seed))
     batch = dict(rgb=rgb, input_ids=ids, labels=labels, attention_mask=ids.ne(0))
     taps = {}
     h1 = model.rgb_pooler.register_forward_hook(lambda m, i, o: taps.update(image=o))
+    h2 = model.text.text_encoder.model.register_forward_hook(lambda m, i, o: taps.update(hidden=o[0].detach()))
     out = model(batch)
+    h2.remove()
     taps["image"].retain_grad()
     loss = out["total_loss"]
     loss.backward()
     h1.remove()
     grads = {n: q.grad for n, q in model.rgb_pooler.named_parameters()}
-    print("8-layer e2e loss", loss.item())
+    print(f"{NL}-layer T={T} e2e loss", loss.item())
+    extra = dict(hidden_sample=taps["hidden"][:, ::8, ::4].numpy().astype(np.float16)) if with_hidden else {}  # final-norm output rows
     np.savez_compressed(
-        os.path.join(HERE, "unibind_e2e_8l.npz"), ids_seed=np.array(404), rgb_seed=np.array(405), input_ids=ids.numpy(),
+        os.path.join(HERE, name), ids_seed=np.array(ids_seed), rgb_seed=np.array(rgb_seed), input_ids=ids.numpy(), **extra,
         rgb_checksum=np.array(rgb.double().sum().item()), loss=np.array(loss.item(), dtype=np.float64),
         d_image=taps["image"].grad.detach().numpy().astype(np.float32)[:, ::4, ::4],
         grad_names=np.array(list(grads.keys())), grad_norms=np.array([grads[n].norm().item() for n in grads], dtype=np.float64),
         g_out_proj_b=grads["out_proj.bias"].numpy().astype(np.float32), n_llama_layers=np.array(NL))
-    print(os.path.getsize(os.path.join(HERE, "unibind_e2e_8l.npz")) // 1024, "KiB")
+    print(os.path.getsize(os.path.join(HERE, name)) // 1024, "KiB")
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "s273":
+        # the HEADLINE shape (BASELINE configs[1]: T = 130 => S = 273) through the reference, 2 LLaMA-7B-width layers
+        main(NL=2, T=130, ids_seed=414, rgb_seed=415, name="unibind_e2e_s273.npz", with_hidden=True)
+    else:
+        main()

@@ -29,3 +29,24 @@ def test_bench_emits_the_contract_line():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["launches_timed"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "samples/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+
+
+@pytest.mark.timeout(1200)
+def test_bench_gpus2_self_spawns_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment (how the driver starts the N>1 lines) must spawn its own two
+    ranks and print ONE rank-0 line with n_gpus 2.  Backend: RCCL ("nccl") where two devices are visible; on a 1-GPU box the two
+    ranks share the device over gloo (LHRS_SHARE_GPU=1: plumbing only).  The replica checksum runs inside LHRSEngine.__init__."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    two = torch.cuda.device_count() >= 2
+    if not two:
+        env["LHRS_SHARE_GPU"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--llama-layers", "2",
+                          "--micro-batch", "4"], capture_output=True, text=True, timeout=1100, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["grad_allreduce"] == "bfloat16" and d["config"]["dist_backend"] == ("nccl" if two else "gloo")
+    assert d["value"] > 0 and "cpu_baseline" not in d

@@ -53,6 +53,26 @@ mine = eng.pool.master.cpu()
 other = [torch.empty_like(mine) for _ in range(world)]
 torch.distributed.all_gather(other, mine)
 assert all(torch.equal(o, other[0]) for o in other), "ranks diverged"
+# ---- replica consistency at construction (DeepSpeed broadcasts in deepspeed.initialize; here: rank-0 broadcast of the trainable
+# masters + a checksum of everything frozen).  (i) projector seeded differently per rank -> repaired by the broadcast;
+# (ii) frozen LLaMA differing on one rank -> hard error on every rank
+m2 = UniBind(("rgb", "text"), None, device="cuda:0", llama_layers=1).init_random(seed=0)
+m2.rgb_pooler.init_random(seed=100 + rank)
+m2.prepare_for_training()
+e2 = LHRSEngine(m2, optimizer="adanp")
+got = [torch.empty_like(mine) for _ in range(world)]
+torch.distributed.all_gather(got, e2.pool.master.cpu())
+assert all(torch.equal(o, got[0]) for o in got), "broadcast did not equalise the trainable masters"
+assert torch.equal(e2.pool.shadow.float().cpu(), got[0].to(torch.bfloat16).float()), "bf16 shadow not refreshed after the broadcast"
+m3 = UniBind(("rgb", "text"), None, device="cuda:0", llama_layers=1).init_random(seed=0)
+if rank == 1:
+    m3.text.p["layers"][0]["o_w"][5, 7] += 0.5
+m3.prepare_for_training()
+try:
+    LHRSEngine(m3, optimizer="adanp")
+    raise SystemExit("replica mismatch in the frozen LLaMA was not detected")
+except RuntimeError as e:
+    assert "text (frozen LLaMA)" in str(e) and "rgb" not in str(e).split("in [")[1], str(e)
 torch.distributed.barrier(); torch.distributed.destroy_process_group()
 open(os.path.join(sys.argv[2], f"ok{rank}"), "w").write(f"{err} {upd}")
 '''

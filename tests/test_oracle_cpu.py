@@ -108,6 +108,38 @@ def test_unibind_end_to_end_matches_reference():
     assert rel(P["pooler"]["out_proj_b"].grad, torch.from_numpy(z["g_out_proj_b"])) < 1e-2
 
 
+@pytest.mark.timeout(900)
+def test_unibind_headline_shape_s273_matches_reference():
+    """The HEADLINE sequence (BASELINE configs[1]: T = 130 => S = 273), 2 LLaMA-7B-width layers, reference fixture
+    tests/golden/unibind_e2e_s273.npz (make_golden_deep.py s273): loss, final-norm hidden rows, d loss / d image, projector grad norms."""
+    z = np.load(os.path.join(G, "unibind_e2e_s273.npz"))
+    nl = int(z["n_llama_layers"])
+    P = {"vit": OP.make_vit_params(seed=2), "pooler": OP.make_pooler_params(seed=1), "llama": OP.make_llama_params(seed=3, layers=nl)}
+    for L in [P["pooler"]] + P["pooler"]["layers"]:
+        for k, v in L.items():
+            if torch.is_tensor(v):
+                v.requires_grad_(True)
+    ids = torch.from_numpy(z["input_ids"])
+    assert ids.shape == (2, 130)
+    labels = ids.clone()
+    labels[:, :2] = -100
+    rgb = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(int(z["rgb_seed"])))
+    assert abs(rgb.double().sum().item() - float(z["rgb_checksum"])) < 1e-6
+    col = {}
+    loss = O.unibind_forward(P, dict(rgb=rgb, input_ids=ids, labels=labels, attention_mask=ids.ne(0)), col)
+    col["image"].retain_grad()
+    loss.backward()
+    assert col["hidden"].shape[1] == 273
+    assert abs(loss.item() - float(z["loss"])) < 1e-4 * float(z["loss"])
+    assert rel(col["hidden"][:, ::8, ::4].detach(), torch.from_numpy(z["hidden_sample"]).float()) < 2e-3  # fp16 storage
+    assert rel(col["image"].grad[:, ::4, ::4], torch.from_numpy(z["d_image"])) < 2e-3
+    norms = dict(zip(z["grad_names"].tolist(), z["grad_norms"].tolist()))
+    for name, leaf in (("out_proj.bias", P["pooler"]["out_proj_b"]), ("query", P["pooler"]["query"]),
+                       ("layers.2.mlp.c_fc.weight", P["pooler"]["layers"][2]["fc_w"])):
+        assert abs(leaf.grad.norm().item() - norms[name]) < 2e-3 * norms[name], name
+    assert rel(P["pooler"]["out_proj_b"].grad, torch.from_numpy(z["g_out_proj_b"])) < 2e-3
+
+
 def test_adamw_restatement_matches_torch():
     n = 1000
     g = torch.Generator().manual_seed(0)
