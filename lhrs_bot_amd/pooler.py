@@ -56,6 +56,7 @@ class AttnPooler:
         self.g = {n: self._view(self.grad, n) for n, _ in spec}       # fp32 gradient views
         self.wT: Dict[str, torch.Tensor] = {}                          # transposed bf16 weights for dX GEMMs
         self.requires_grad = True
+        self.initialised = False  # set by init_random / load_params / load_state_dict
         self._desc_cache: Dict[int, torch.Tensor] = {}
         self._ctx = None
 
@@ -116,9 +117,11 @@ class AttnPooler:
                 bound = (6.0 / (shape[0] + shape[1])) ** 0.5 if "in_proj" in n else (1.0 / shape[1]) ** 0.5
                 v.copy_((torch.rand(shape, device=self.device, generator=g) * 2 - 1) * bound)
         self.sync_shadow()
+        self.initialised = True
 
     def sync_shadow(self) -> None:
         """bf16 shadow + transposed copies after an optimizer step / load (HBM-bound, ~0.5 GB of traffic)."""
+        self.initialised = True
         hk.cast_f32_to_bf16(self.master, self.shadow)
         self.refresh_transposed()
 

@@ -86,6 +86,82 @@ class UniBind:
     def to(self, *a, **k):
         return self
 
+    def named_parameters(self):
+        """(name, fp32 master view) of every TRAINABLE tensor, named as the reference's modules name them (`rgb_pooler.layers.0.ln_1.weight`,
+        peft's `text.text_encoder...lora_A.default.weight`): what `build_optimizer` splits into decay / no-decay groups."""
+        from .checkpoint import PROJ_MODULE
+        out = []
+        if hasattr(self, "rgb_pooler") and self.rgb_pooler.requires_grad:
+            out += [("rgb_pooler." + n, t) for n, t in self.rgb_pooler.named_parameters()]
+        lo = getattr(getattr(self, "text", None), "lora", None)
+        if lo is not None:
+            for l in range(lo.nl):
+                for proj in lo.targets:
+                    A, B = lo.get_adapter(l, proj)
+                    base = f"text.text_encoder.base_model.model.model.layers.{l}.{PROJ_MODULE[proj]}"
+                    out += [(base + ".lora_A.default.weight", A), (base + ".lora_B.default.weight", B)]
+        return out
+
+    def parameters(self):
+        return [t for _, t in self.named_parameters()]
+
+    def load_base_weights(self, config=None, allow_random: bool = True, seed: int = 0):
+        """What the reference does inside `build_model` (VisionModal: `CLIPVisionModel.from_pretrained(config.rgb_vision.vit_name)`,
+        rgb_vision_modal.py:130-157; TextModal: `CustomLlamaForCausalLM.from_pretrained(config.text.path)` + `LlamaTokenizerFast`,
+        text_modal.py:79-131,191-197): load the frozen towers and the tokenizer from the paths the YAML names.  There is no hub access:
+        a path that is not a local directory leaves that tower RANDOM-initialised (LLaMA-2-7B / ViT-L/14 shapes) with a loud warning -
+        or raises when `allow_random` is off.  The projector keeps its fresh init (the reference's AttnPooler default init)."""
+        import logging
+        import os
+        from .checkpoint import load_hf_dir
+        log = logging.getLogger("train")
+        cfg = config if config is not None else self.config
+        done = {}
+        if hasattr(self, "rgb"):
+            vit = _get(cfg, "rgb_vision.vit_name", None)
+            if vit and os.path.isdir(str(vit)):
+                self.rgb.load_state_dict(load_hf_dir(str(vit)))
+                done["rgb"] = str(vit)
+            elif not self.rgb.p:
+                if not allow_random:
+                    raise FileNotFoundError(f"rgb_vision.vit_name = {vit!r} is not a local checkpoint directory")
+                log.warning("CLIP ViT weights %r are not on disk: the vision tower is RANDOM-initialised (synthetic run)", vit)
+                self.rgb.init_random(seed)
+                done["rgb"] = "random"
+            if not self.rgb_pooler.initialised:
+                self.rgb_pooler.init_random(seed + 1)
+        if hasattr(self, "text"):
+            path = _get(cfg, "text.path", None)
+            if path and os.path.isdir(str(path)):
+                self.text.from_pretrained(str(path), n_layers=self.text.nl)
+                done["text"] = str(path)
+                if any(os.path.exists(os.path.join(str(path), f)) for f in ("tokenizer.model", "tokenizer.json")):
+                    import transformers
+                    tok = transformers.AutoTokenizer.from_pretrained(str(path))
+                    tok.pad_token_id = tok.unk_token_id  # text_modal.py:196-197
+                    self.text.tokenizer = tok
+            elif not self.text.p:
+                if not allow_random:
+                    raise FileNotFoundError(f"text.path = {path!r} is not a local checkpoint directory")
+                log.warning("LLaMA weights %r are not on disk: the language model is RANDOM-initialised and the tokenizer is the synthetic "
+                            "word-hash stand-in (synthetic run)", path)
+                self.text.init_random(seed + 2)
+                done["text"] = "random"
+        self.base_weights = done
+        return self
+
+    def _pixels(self, rgb):
+        """`batch["rgb"]` as the loaders deliver it: float [B,3,224,224] (already CLIP-normalised) passes through; uint8 HWC pictures
+        (a [B,H,W,3] tensor or a list of [H,W,3] of different sizes, decoded by the DataLoader workers) are resized / cropped /
+        normalised here by `lhrs_clip_preprocess`, bit-exact with the reference's `CLIPImageProcessor` (lhrs_bot_amd/datasets.py)."""
+        is_list = isinstance(rgb, (list, tuple))
+        if not is_list and not (torch.is_tensor(rgb) and rgb.dtype == torch.uint8):
+            return rgb
+        if getattr(self, "_image_processor", None) is None:
+            from .data import CLIPImageProcessorHIP
+            self._image_processor = CLIPImageProcessorHIP(device=self.device)
+        return self._image_processor.preprocess(list(rgb))["pixel_values"]
+
     def init_random(self, seed: int = 0):
         if hasattr(self, "rgb"):
             self.rgb.init_random(seed)
@@ -107,7 +183,7 @@ class UniBind:
         return self.text.enable_lora(r=r, alpha=alpha, targets=targets or LORA_ALL, seed=seed, dropout=dropout)
 
     def encode_image(self, image, pool: bool = False):
-        emb = self.rgb_pooler.forward(self.rgb.encode(image), save_ctx=False)
+        emb = self.rgb_pooler.forward(self.rgb.encode(self._pixels(image)), save_ctx=False)
         return emb.float().mean(dim=1).to(emb.dtype) if pool else emb
 
     def forward(self, data: Dict) -> Dict[str, torch.Tensor]:
@@ -117,7 +193,7 @@ class UniBind:
         # host copies of the small integer inputs FIRST: if they live on the device this is the one synchronising copy of the step, and
         # it happens while the queue is empty anyway (step boundary) instead of draining it behind the ViT
         host_ints = self.text._ints_to_host(data["input_ids"], data["labels"], data.get("attention_mask"))
-        image_embedding = self.rgb_pooler.forward(self.rgb.encode(data["rgb"]), save_ctx=pool_grad)
+        image_embedding = self.rgb_pooler.forward(self.rgb.encode(self._pixels(data["rgb"])), save_ctx=pool_grad)
         loss = self.text.decode(data["input_ids"], image_embedding=image_embedding, attention_mask=data.get("attention_mask"),
                                 labels=data["labels"], save_ctx=grad, host_ints=host_ints)
         return {"text_loss": loss, "total_loss": loss}
@@ -158,6 +234,8 @@ class UniBind:
         stage > 2 and merged into the base weights when stage == 0 (evaluation)."""
         import os
         from .checkpoint import load_peft_dir, lora_from_peft
+        if os.path.isdir(path):  # the directory custom_save_checkpoint wrote (cli_qa's --model-path help text allows either)
+            path = os.path.join(path, "FINAL.pt")
         ckpt = torch.load(path, map_location="cpu")
         if "model" in ckpt:
             ckpt = ckpt["model"]
@@ -169,13 +247,24 @@ class UniBind:
         if os.path.isdir(text_path):
             cfg, targets, sd = load_peft_dir(text_path)
             if self.text.lora is None:
-                self.text.enable_lora(r=cfg["r"], alpha=cfg["lora_alpha"], targets=targets)
+                self.text.enable_lora(r=cfg["r"], alpha=cfg["lora_alpha"], targets=targets, dropout=float(cfg.get("lora_dropout", 0.0)))
             lora_from_peft(self.text.lora, sd)
             if self.stage == 0:
                 self.text.merge_lora()
         return None
 
 
-def build_model(config=None, activate_modal=("rgb", "text"), **kw) -> UniBind:
-    """lhrs.models.build_model (lhrs/models/build.py:16-22)."""
-    return UniBind(activate_modal, config, **kw)
+def build_model(config=None, activate_modal=("rgb", "text"), load_weights: Optional[bool] = None, **kw) -> UniBind:
+    """lhrs.models.build_model (lhrs/models/build.py:16-22).  With a config (the entry scripts' call) the frozen towers are loaded from
+    `config.text.path` / `config.rgb_vision.vit_name` as the reference does at construction (`load_base_weights`); `config=None` (tests,
+    tools) returns the empty module for `init_random` / `load_params`.  Engine knobs ride in the config too: `local_rank` picks the
+    device, `llama_layers` truncates the decoder (synthetic smoke runs)."""
+    if config is not None:
+        if "device" not in kw and torch.cuda.is_available():
+            kw["device"] = torch.device("cuda", int(_get(config, "local_rank", 0) or 0) if _get(config, "local_rank", 0) not in (None, -1) else 0)
+        if "llama_layers" not in kw and _get(config, "llama_layers", None):
+            kw["llama_layers"] = int(_get(config, "llama_layers", 32))
+    model = UniBind(activate_modal, config, **kw)
+    if load_weights if load_weights is not None else config is not None:
+        model.load_base_weights(config)
+    return model
