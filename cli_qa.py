@@ -8,9 +8,10 @@ flag-compatible (`-c Config/multi_modal_eval.yaml --model-path <FINAL.pt dir> --
 The prefill runs on the GEMM path, the per-token step is one captured hipGraph (lhrs_bot_amd/text.py `_decode_session`);
 `bits: 8` in the YAML (or `--opts bits 8`) streams e4m3 weights through the MFMA GEMV.
 
-No tokenizer files exist offline: `--tokenizer-path <dir with tokenizer.model>` enables the interactive loop; without it only
-`--synthetic-prompt T` runs (BASELINE.json configs[4]: one 224x224 image, a T-token prompt of random ids with the `<image>`
-placeholder, `--max-new-tokens` greedy tokens) and prints one JSON line with the decode rate.
+Imports and call order follow /root/reference cli_qa.py:10-22, 84-193 over the `lhrs.*` surface.  Weights / tokenizer come from the paths
+in the YAML (`text.path`, `rgb_vision.vit_name`); when they are not on disk the towers are random-initialised and the word-hash
+stand-in tokenizer is used (both announced).  `--synthetic-prompt T` is the non-interactive BASELINE.json configs[4] run: one 224x224
+image, a T-token prompt of random ids with the `<image>` placeholder, `--max-new-tokens` greedy tokens, one JSON line with the rate.
 """
 import json
 import os
@@ -20,12 +21,12 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from lhrs_bot_amd.data import (DEFAULT_IM_END_TOKEN, DEFAULT_IM_START_TOKEN, LLAMA_2_ROLES, LLAMA_2_SEP2, CLIPImageProcessorHIP,  # noqa: E402
-                               llama_2_prompt, tokenizer_image_token)
-from lhrs_bot_amd.eval_utils import KeywordsStoppingCriteria  # noqa: E402
-from lhrs_bot_amd.text import DEFAULT_IMAGE_TOKEN, IMAGE_TOKEN_INDEX  # noqa: E402
-from lhrs_bot_amd.trainer import ConfigArgumentParser, ConfigDict, str2bool  # noqa: E402
-from lhrs_bot_amd.unibind import build_model  # noqa: E402
+from lhrs.CustomTrainer.utils import ConfigArgumentParser, ConfigDict, str2bool  # noqa: E402
+from lhrs.Dataset.build_transform import build_vlp_transform  # noqa: E402
+from lhrs.Dataset.conversation import SeparatorStyle, default_conversation  # noqa: E402
+from lhrs.models import (DEFAULT_IM_END_TOKEN, DEFAULT_IM_START_TOKEN, DEFAULT_IMAGE_PATCH_TOKEN, DEFAULT_IMAGE_TOKEN, IMAGE_TOKEN_INDEX,  # noqa: E402,F401
+                         build_model, tokenizer_image_token)
+from lhrs.utils import KeywordsStoppingCriteria, type_dict  # noqa: E402
 
 
 def parse_option(args=None):
@@ -82,29 +83,39 @@ def main(config):
         raise RuntimeError("cli_qa.py drives the HIP engine: it needs --accelerator gpu and a visible MI355X (there is no CPU path)")
     device = torch.device("cuda", 0)
     torch.manual_seed(int(config.seed))
-    model = build_model(config, activate_modal=("rgb", "text"), device=device, llama_layers=int(config.get("llama_layers", 32)))
-    if config.get("model_path"):
-        print(model.custom_load_state_dict(config.model_path, strict=False))
-    else:
-        model.init_random(seed=0)  # offline: LLaMA-2 / CLIP weights are not on disk
+    # build_model loads the frozen towers + tokenizer from config.text.path / config.rgb_vision.vit_name (random-init with a warning when
+    # the paths are not on disk); --model-path adds the trained projector (FINAL.pt, or the directory holding it) and TextLoRA/
+    model = build_model(config, activate_modal=("rgb", "text"))
+    vision_processor = build_vlp_transform(config, is_train=False)
+    dtype = type_dict[config.get("dtype", "bfloat16")]
+    model.to(dtype)
+    conv = default_conversation.copy()
+    roles = conv.roles
+    if config.get("model_path") is not None:
+        print(model.custom_load_state_dict(config.model_path))
+    if config.get("tokenizer_path"):
+        import transformers
+        model.text.tokenizer = transformers.AutoTokenizer.from_pretrained(config.tokenizer_path, use_fast=False)
+    tokenizer = model.text.tokenizer
     model.eval()
     weights = "fp8" if int(config.get("bits", 16) or 16) == 8 else "bf16"
-    processor = CLIPImageProcessorHIP(device=device)
 
     if config.get("image_file"):
-        image_tensor = processor(load_image(config.image_file), return_tensors="pt")["pixel_values"]
+        image = load_image(config.image_file)
+        image_tensor = vision_processor(image, return_tensors="pt")["pixel_values"]
     elif config.synthetic_prompt:
         g = torch.Generator().manual_seed(int(config.seed))
-        image_tensor = processor(torch.randint(0, 256, (256, 256, 3), generator=g, dtype=torch.uint8))["pixel_values"]
+        image = True
+        image_tensor = vision_processor(torch.randint(0, 256, (256, 256, 3), generator=g, dtype=torch.uint8))["pixel_values"]
     else:
-        image_tensor = None
+        image, image_tensor = None, None
 
     if config.synthetic_prompt:
         T = int(config.synthetic_prompt)
         g = torch.Generator().manual_seed(int(config.seed))
         ids = torch.randint(3, 32000, (1, T), generator=g)
         ids[0, 0], ids[0, 1] = 1, IMAGE_TOKEN_INDEX
-        kw = dict(images=image_tensor, do_sample=False, use_cache=True, weights=weights)
+        kw = dict(images=image_tensor, do_sample=False, use_cache=True, weights=weights, eos_token_id=None)
         model.generate(ids, max_new_tokens=4, **kw)  # graph capture + allocator warm-up
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -116,13 +127,8 @@ def main(config):
                           "seconds": round(dt, 3)}))
         return out
 
-    if not config.get("tokenizer_path"):
-        raise RuntimeError("the interactive loop needs --tokenizer-path (no tokenizer files ship with this repo); "
-                           "use --synthetic-prompt T for the offline decode run")
-    import transformers
-    tokenizer = transformers.AutoTokenizer.from_pretrained(config.tokenizer_path, use_fast=False)
-    model.text.tokenizer = tokenizer
-    roles, messages, first = LLAMA_2_ROLES, [], image_tensor is not None
+    if getattr(tokenizer, "is_synthetic", False):
+        print("WARNING: no tokenizer files (config.text.path / --tokenizer-path): the word-hash stand-in is in use, the answers are not text")
     while True:
         try:
             inp = input(f"{roles[0]}: ")
@@ -132,20 +138,23 @@ def main(config):
             print("exit...")
             break
         print(f"{roles[1]}: ", end="")
-        if first:  # first message carries the image
+        if image is not None:  # first message carries the image
             tok = DEFAULT_IM_START_TOKEN + DEFAULT_IMAGE_TOKEN + DEFAULT_IM_END_TOKEN if config.get("tune_im_start", False) else DEFAULT_IMAGE_TOKEN
-            inp, first = tok + "\n" + inp, False
-        messages.append([roles[0], inp])
-        messages.append([roles[1], None])
-        prompt = llama_2_prompt(messages)
-        input_ids = tokenizer_image_token(prompt, tokenizer, IMAGE_TOKEN_INDEX, return_tensors="pt").unsqueeze(0)
-        stopping = KeywordsStoppingCriteria([LLAMA_2_SEP2], tokenizer, input_ids)
-        output_ids = model.generate(input_ids, images=image_tensor, do_sample=True, max_new_tokens=int(config.max_new_tokens), temperature=0.4,
-                                    streamer=_Streamer(tokenizer), use_cache=True, stopping_criteria=[stopping], weights=weights)
+            inp, image = tok + "\n" + inp, None
+        conv.append_message(conv.roles[0], inp)
+        conv.append_message(conv.roles[1], None)
+        prompt = conv.get_prompt()
+        input_ids = tokenizer_image_token(prompt, tokenizer, IMAGE_TOKEN_INDEX, return_tensors="pt").unsqueeze(0).to(device)
+        stop_str = conv.sep if conv.sep_style != SeparatorStyle.TWO else conv.sep2
+        stopping_criteria = KeywordsStoppingCriteria([stop_str], tokenizer, input_ids)
+        with torch.inference_mode():
+            output_ids = model.generate(input_ids, images=image_tensor, do_sample=True, max_new_tokens=int(config.max_new_tokens), temperature=0.4,
+                                        streamer=_Streamer(tokenizer), use_cache=True, stopping_criteria=[stopping_criteria], weights=weights)
         outputs = tokenizer.decode(output_ids[0]).strip().split("<s>")[-1].strip()
-        messages[-1][-1] = outputs
+        conv.messages[-1][-1] = outputs
         if config.debug:
             print("\n", {"prompt": prompt, "outputs": outputs}, "\n")
+    return conv
 
 
 if __name__ == "__main__":

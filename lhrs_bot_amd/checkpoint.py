@@ -146,7 +146,7 @@ def lora_from_peft(store, sd: Dict[str, torch.Tensor]) -> None:
 def save_peft_dir(store, path: str, base_model: str = "") -> None:
     os.makedirs(path, exist_ok=True)
     torch.save(lora_to_peft(store), os.path.join(path, "adapter_model.bin"))
-    cfg = {"peft_type": "LORA", "task_type": "CAUSAL_LM", "r": store.r, "lora_alpha": store.s * store.r, "lora_dropout": 0.05,
+    cfg = {"peft_type": "LORA", "task_type": "CAUSAL_LM", "r": store.r, "lora_alpha": store.s * store.r, "lora_dropout": float(getattr(store, "dropout", 0.0)),
            "bias": "none", "target_modules": sorted({PROJ_MODULE[t].split(".")[-1] for t in store.targets}),
            "base_model_name_or_path": base_model, "inference_mode": False}
     with open(os.path.join(path, "adapter_config.json"), "w") as f:

@@ -211,6 +211,11 @@ class DataCollatorForVGSupervisedDataset:
         return images, input_ids, [inst[2] for inst in instances], [inst[3] for inst in instances], input_ids.ne(pad)
 
 
+class _Features(dict):
+    """dict with attribute access: `processor(img, return_tensors="pt").pixel_values` (cli_qa.py:118-122) and `[...]` both work."""
+    __getattr__ = dict.__getitem__
+
+
 class CLIPImageProcessorHIP:
     """Drop-in for the transform `build_vlp_transform` returns for the ViT arch (lhrs/Dataset/build_transform.py:43-45, HF
     `CLIPImageProcessor`): `.preprocess(images, return_tensors="pt")["pixel_values"]` -> float32 [B, 3, 224, 224] ON THE DEVICE,
@@ -246,6 +251,6 @@ class CLIPImageProcessorHIP:
         out = torch.empty((len(images), 3, 224, 224), device=self.device, dtype=torch.float32)
         for b, im in enumerate(images):
             hk.clip_preprocess(self._to_u8(im), out=out[b])
-        return {"pixel_values": out}
+        return _Features(pixel_values=out)
 
     __call__ = preprocess

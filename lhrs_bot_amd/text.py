@@ -28,14 +28,45 @@ DEFAULT_IM_END_TOKEN = "<im_end>"
 
 
 class SyntheticTokenizer:
-    """Stands in for LlamaTokenizerFast when no tokenizer files exist offline (pad = unk = 0, bos = 1)."""
+    """Stands in for LlamaTokenizerFast when no tokenizer files exist offline (pad = unk = 0, bos = 1, eos = 2).  Text is split on
+    whitespace and every word hashed to a stable id in [3, 32000) ("\n" -> 13, "</s>" -> 2): enough to drive the data pipeline, the
+    prompt templates and the stopping criteria end to end in synthetic runs; it is NOT the LLaMA vocabulary and decoding is lossy
+    (`decode` prints `<id>` for ids it has never encoded)."""
     unk_token_id = pad_token_id = 0
     bos_token_id = 1
     eos_token_id = 2
     model_max_length = 2048
+    is_synthetic = True
+
+    def __init__(self):
+        self._words = {0: "<unk>", 1: "<s>", 2: "</s>", 13: "\n"}
 
     def __len__(self):
         return 32000
+
+    def _id(self, w: str) -> int:
+        if w == "\n":
+            return 13
+        if w == "</s>":
+            return 2
+        h = 2166136261
+        for ch in w.encode():
+            h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
+        i = 14 + h % (32000 - 14)
+        self._words.setdefault(i, w)
+        return i
+
+    def __call__(self, text, **_kw):
+        ids = [self.bos_token_id] + [self._id(w) for w in text.replace("\n", " \n ").split(" ") if w]
+        return types.SimpleNamespace(input_ids=ids)
+
+    def decode(self, ids, skip_special_tokens: bool = False, **_kw) -> str:
+        ids = ids.tolist() if hasattr(ids, "tolist") else list(ids)
+        words = [self._words.get(int(i), f"<{int(i)}>") for i in ids if not (skip_special_tokens and int(i) in (0, 1, 2))]
+        return " ".join(words).replace(" \n ", "\n")
+
+    def batch_decode(self, rows, skip_special_tokens: bool = False, **_kw):
+        return [self.decode(r, skip_special_tokens=skip_special_tokens) for r in rows]
 
 
 LORA_GROUPS = {  # fused GEMM group -> (sub-projections, in_features, out_features per projection)
@@ -632,16 +663,54 @@ class TextModal:
         s.graph = None
         return s
 
+    def _lora_merged_layers(self):
+        """Per-layer weight dicts with the CURRENT adapters folded in (W + (alpha/r) B A as one GEMM per fused group, like `merge_lora`)
+        WITHOUT touching the frozen base: generate() with un-merged adapters (stages >= 1 with a TextLoRA/ loaded or being trained)
+        must answer with the adapted model, as peft's wrapped forward does.  Only the tensors the inference path reads are produced
+        (+13.5 GB for the duration of the call at all-linear targets); decode-only repacks are rebuilt from them on demand."""
+        lo = self.lora
+        wname = {"qkv": "qkv_w", "o": "o_w", "gu": "gu_w", "down": "down_w"}
+        out = []
+        for li, L in enumerate(self.p["layers"]):
+            M = {k: L[k] for k in ("ln1_w", "ln2_w", "qkv_w", "o_w", "gu_w", "down_w")}
+            for gname in lo.groups:
+                W = L[wname[gname]]
+                M[wname[gname]] = hk.gemm_nt(lo.derived[(li, gname, "Bfull")], lo.derived[(li, gname, "AT")], residual=W, alpha=lo.s)
+            out.append(M)
+        return out
+
     @torch.no_grad()
     def generate(self, input_ids, image_embedding=None, attention_mask=None, do_sample=False, temperature=1.0, top_p=None,
-                 top_k=None, max_new_tokens=512, use_cache=True, stopping_criteria=None, streamer=None, eos_token_id=None,
+                 top_k=None, max_new_tokens=512, use_cache=True, stopping_criteria=None, streamer=None, eos_token_id="default",
                  return_logits=False, use_graph=True, weights="bf16", **_kw):
+        """See `_generate`.  Two things happen here first: (1) `eos_token_id` defaults to the tokenizer's EOS, as HF `generate` stops on
+        the generation config's EOS (pass None to disable); (2) if LoRA adapters are attached and not merged, the call runs on merged
+        COPIES of the affected weights (`_lora_merged_layers`) and the base weights come back untouched."""
+        if eos_token_id == "default":
+            eos_token_id = getattr(self.tokenizer, "eos_token_id", None)
+        kw = dict(image_embedding=image_embedding, attention_mask=attention_mask, do_sample=do_sample, temperature=temperature, top_p=top_p,
+                  top_k=top_k, max_new_tokens=max_new_tokens, use_cache=use_cache, stopping_criteria=stopping_criteria, streamer=streamer,
+                  eos_token_id=eos_token_id, return_logits=return_logits, use_graph=use_graph, weights=weights)
+        if self.lora is None:
+            return self._generate(input_ids, **kw)
+        base_layers, base8 = self.p["layers"], self.base8
+        self.p["layers"], self.base8 = self._lora_merged_layers(), False
+        try:
+            return self._generate(input_ids, **kw)
+        finally:
+            self.p["layers"], self.base8 = base_layers, base8
+
+    def _generate(self, input_ids, image_embedding=None, attention_mask=None, do_sample=False, temperature=1.0, top_p=None,
+                  top_k=None, max_new_tokens=512, use_cache=True, stopping_criteria=None, streamer=None, eos_token_id=None,
+                  return_logits=False, use_graph=True, weights="bf16", **_kw):
         """TextModal.generate (text_modal.py:528-627): prefill over the spliced embeddings, then one token at a time with
         a KV cache; returns only the NEW token ids [B, n_new] (HF generate started from inputs_embeds).  Greedy
         (do_sample=False, the evaluation scripts' mode) runs entirely in HIP kernels; with do_sample=True the HIP-computed
         fp32 logits go through HF's temperature / top-k / top-p warpers and one multinomial draw per token.  The
         single-token step is a captured hipGraph over static buffers (batch <= 16; from batch 2 the weight stream runs on MFMA); without eos / stopping criteria / streamer
         the host never synchronises inside the loop."""
+        if streamer is not None and getattr(streamer, "skip_prompt", False):
+            streamer.put(input_ids.cpu())  # transformers.TextStreamer protocol: the first put() is the prompt, which skip_prompt drops
         embeds, _, mask, _ = self.prepare_inputs_for_multimodal(input_ids, attention_mask, None, image_embedding)
         B, S0, d = embeds.shape
         max_ctx = S0 + max_new_tokens

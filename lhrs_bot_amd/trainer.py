@@ -298,7 +298,10 @@ class Trainer:
         self._log_t0, self._log_it0 = time.perf_counter(), self.cur_iter
 
     def put_input_to_device(self, batch):
-        return {k: v.to(self.device, non_blocking=True) for k, v in batch.items()}
+        """trainer.py:400-417.  `rgb` may be a list of uint8 [H,W,3] pictures of different sizes (decoded by the DataLoader workers, see
+        lhrs_bot_amd/datasets.py): each goes up as it is, the model's `_pixels` runs the CLIP transform on the device."""
+        move = lambda v: v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v  # noqa: E731
+        return {k: [move(x) for x in v] if isinstance(v, (list, tuple)) else move(v) for k, v in batch.items()}
 
     def train_on_iter(self):
         batch = self.put_input_to_device(next(self._data_iter))
@@ -345,6 +348,7 @@ class EpochBasedTrainer(Trainer):
 
     def sub_classes_train(self):
         for self.epoch in range(self.start_epoch, self.max_epochs):
+            self.model.train()  # EpochBasedTrainer.py:91 - every epoch; with adapters loaded from TextLoRA/ this re-arms lora_dropout
             self._call_hooks("before_epoch")
             for self.inner_iter in range(self.inner_iter, self.epoch_len):
                 self._call_hooks("before_iter")
@@ -374,6 +378,7 @@ class IterBasedTrainer(Trainer):
         self.inner_iter = value
 
     def sub_classes_train(self):
+        self.model.train()  # IterBasedTrainer.py:87
         self._call_hooks("before_epoch")
         for self.inner_iter in range(self.inner_iter, self._max_iters):
             self._call_hooks("before_iter")

@@ -229,11 +229,12 @@ class UniBind:
             save_peft_dir(self.text.lora, os.path.join(file_name, "TextLoRA"))
         return ckpt
 
-    def custom_load_state_dict(self, path: str, strict: bool = False):
+    def custom_load_state_dict(self, state_dict_path: str, strict: bool = False):
         """lhrs/models/UniBind.py:83-117: FINAL.pt (rgb encoder + projector) and a sibling TextLoRA/ adapter, trainable when
         stage > 2 and merged into the base weights when stage == 0 (evaluation)."""
         import os
         from .checkpoint import load_peft_dir, lora_from_peft
+        path = state_dict_path
         if os.path.isdir(path):  # the directory custom_save_checkpoint wrote (cli_qa's --model-path help text allows either)
             path = os.path.join(path, "FINAL.pt")
         ckpt = torch.load(path, map_location="cpu")

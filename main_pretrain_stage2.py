@@ -1,24 +1,7 @@
-"""Stage-2 entry point: the reference's main_pretrain_stage2.py differs from stage 1 only in the YAML it is given (`stage`, `lora`,
-`bits`, `optimizer: adamw`) and - stage 3 - in using IterBasedTrainer(max_iters=config.epochs); the shared driver reads all of that
-from the config (/root/reference main_pretrain_stage2.py:180-245)."""
-import json
-import logging
-import os
-
-import torch
-
+#!/usr/bin/env python
+"""Stage-2 entry point.  The reference's main_pretrain_stage2.py (/root/reference main_pretrain_stage2.py:180-245) repeats stage 1's call
+sequence with a different YAML (`stage`, `lora`, `bits`, `optimizer: adamw`, `betas`), a checkpoint period of 100 and the same `EpochBasedTrainer`; the shared driver in main_pretrain_stage1.py reads all of that from the config."""
 import main_pretrain_stage1 as drv
 
 if __name__ == "__main__":
-    logging.basicConfig(level=logging.INFO, format="%(asctime)s %(message)s")
-    config = drv.parse_option()
-    config.setdefault("stage", 2)
-    config.rank, config.local_rank, config.world_size = drv.init_distributed()
-    config.is_distribute = config.world_size > 1
-    config.seed = config.seed + config.rank
-    torch.manual_seed(config.seed)
-    os.makedirs(config.output, exist_ok=True)
-    if config.rank == 0:
-        with open(os.path.join(config.output, "config.json"), "w") as f:
-            json.dump({k: v for k, v in config.items() if not isinstance(v, torch.device)}, f, indent=1, default=str)
-    drv.main(config)
+    drv.run(2)

@@ -89,3 +89,34 @@ def test_interactive_loop(monkeypatch, capsys, tmp_path):
     # second turn: the history (first prompt + first answer) is a prefix-compatible longer prompt that still holds the placeholder
     assert ids2.shape[1] > ids1.shape[1] and int((ids2 == -200).sum()) == 1 and im2 is im1
     assert out1.shape[1] <= 6 and out2.shape[1] <= 6
+
+
+def test_model_path_round_trip_directory_and_lora(tmp_path, capsys):
+    """`--model-path` may be FINAL.pt or the directory custom_save_checkpoint wrote; the projector AND the sibling TextLoRA/ adapters are
+    loaded (un-merged at stage >= 1) and generate() answers with them: the tokens differ from the run without --model-path and equal
+    those of the model that wrote the checkpoint."""
+    from lhrs_bot_amd.unibind import UniBind
+    src = UniBind(("rgb", "text"), None, device="cuda", llama_layers=2).init_random(seed=0)   # same towers as build_model's random fallback
+    src.rgb_pooler.init_random(seed=77)
+    lora = src.enable_lora(r=8, alpha=16, targets=("q", "k", "v", "o"), seed=3, dropout=0.05)
+    g = torch.Generator().manual_seed(1)
+    for l in range(2):
+        for pr in ("q", "k", "v", "o"):
+            A, B = lora.get_adapter(l, pr)
+            lora.set_adapter(l, pr, A.cpu(), torch.randn(B.shape, generator=g) * 0.05)
+    lora.refresh()
+    src.custom_save_checkpoint(str(tmp_path / "ck"))
+    assert json.load(open(tmp_path / "ck" / "TextLoRA" / "adapter_config.json"))["lora_dropout"] == 0.05
+    args = ["--synthetic-prompt", "16", "--max-new-tokens", "8", "--llama-layers", "2"]
+    base = cli_qa.main(cli_qa.parse_option(args))
+    for path in (tmp_path / "ck", tmp_path / "ck" / "FINAL.pt"):
+        out = cli_qa.main(cli_qa.parse_option(args + ["--model-path", str(path)]))
+        assert tuple(out.shape) == (1, 8) and not torch.equal(out, base)
+    cfg = cli_qa.parse_option(args)
+    g2 = torch.Generator().manual_seed(int(cfg.seed))
+    px = torch.randint(0, 256, (256, 256, 3), generator=g2, dtype=torch.uint8)
+    g2 = torch.Generator().manual_seed(int(cfg.seed))
+    ids = torch.randint(3, 32000, (1, 16), generator=g2)
+    ids[0, 0], ids[0, 1] = 1, -200
+    want = src.eval().generate(ids, images=[px], do_sample=False, max_new_tokens=8, eos_token_id=None)
+    assert torch.equal(out, want)

@@ -193,7 +193,7 @@ def test_data_boundary_matches_reference_functions():
         r = D.preprocess(copy.deepcopy(mm), tok, has_image=True, sep_style="llama_2")
         assert r["input_ids"].tolist() == want["ids"] and r["labels"].tolist() == want["labels"]
     ToyTok.model_max_length = 40
-    r = D.preprocess(copy.deepcopy(z["l2"][1]["mm"]), tok, has_image=True)
+    r = D.preprocess(copy.deepcopy(z["l2"][1]["mm"]), tok, has_image=True, sep_style="llama_2")  # (the module default is re-bound by datasets)
     assert r["input_ids"].tolist() == z["l2_short_ctx"]["ids"] and r["labels"].tolist() == z["l2_short_ctx"]["labels"]
     # evaluation collator: LEFT padding, truncation, mask
     ToyTok.model_max_length = 24

@@ -134,3 +134,25 @@ def test_lora_dropout_matches_oracle_with_the_same_masks(bits):
         want = O.unibind_forward(P, batch).item()
     got = model(batch)["total_loss"].item()
     assert abs(got - want) < tol * want
+
+
+@pytest.mark.timeout(900)
+def test_generate_with_unmerged_adapters_uses_them_and_leaves_the_base_untouched():
+    """generate() while LoRA adapters are attached but NOT merged (stage >= 1 with a TextLoRA/ loaded, or mid-training evaluation): peft's
+    wrapped forward answers with W + (alpha/r) B A.  Logits vs the oracle WITH the adapters (teacher-forced), clearly different from the
+    base model's, base weights bit-identical afterwards, and equal to generate() after merge_lora (the stage-0 path)."""
+    model, lora, P, batch = make(("q", "k", "v", "o", "gate", "up", "down"), 16, False)
+    model.eval()
+    ids, rgb = batch["input_ids"][:1, :12], batch["rgb"][:1]
+    before = {k: v.clone() for k, v in model.text.p["layers"][1].items() if k in ("qkv_w", "down_w")}
+    new_ids, logits = model.generate(ids, images=rgb, do_sample=False, max_new_tokens=4, return_logits=True, eos_token_id=None)
+    assert all(torch.equal(model.text.p["layers"][1][k], v) for k, v in before.items()) and model.text.lora is lora
+    with torch.no_grad():
+        want = O.generate_logits(P, rgb, ids, new_ids.cpu())
+        Pb = dict(P, llama=dict(P["llama"], layers=[{k: v for k, v in L.items() if k != "lora"} for L in P["llama"]["layers"]]))
+        base = O.generate_logits(Pb, rgb, ids, new_ids.cpu())
+    assert rel(logits, want) < 3e-2 and rel(base, want) > 3 * rel(logits, want)
+    model.text.merge_lora()
+    assert model.text.lora is None
+    ids2, logits2 = model.generate(ids, images=rgb, do_sample=False, max_new_tokens=4, return_logits=True, eos_token_id=None)
+    assert torch.equal(ids2, new_ids) and torch.equal(logits2, logits)
