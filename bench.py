@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md: ~2.5 PF dense, 2495 TF measured)
+PEAK_HBM_GBS = 8000.0      # HBM3E peak (spec; ~6.3 TB/s achievable by a streaming copy)
 
 
 def f_alg(S: int) -> float:
@@ -94,9 +95,27 @@ def cpu_baseline(S: int, budget_s: float = 25.0):
                 break
     except OSError:
         pass
+    # BASELINE configs[0] (B = 4, T = 34 => S = 177) on the same oracle and threads: ViT + pooler scale with the
+    # sample count, the LLaMA part is re-timed at the shorter sequence on the same 4 layers
+    B1, S1 = 4, 177
+    x1 = torch.randn(B1, S1, 4096, generator=g).requires_grad_(True)
+    lab1 = torch.randint(3, 32000, (B1, S1), generator=g)
+    lab1[:, :146] = -100
+    t0 = time.perf_counter()
+    O.causal_lm_loss(P["llama"], O.llama_hidden(P["llama"], x1, None), lab1).backward()
+    t_l1c = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.causal_lm_loss(P["llama"], O._rms(x1.detach().requires_grad_(True), P["llama"]["norm_w"], 1e-5), lab1).backward()
+    t_h1c = time.perf_counter() - t0
+    t_c1 = (t_vit + t_pool) * B1 / NB + t_h1c + 32 * max(t_l1c - t_h1c, 1e-6) / NL
     return {"value": NB / t_full, "unit": "samples/s", "cores": threads, "kind": "port", "cpu_model": cpu_model,
+            "host_logical_cpus": os.cpu_count(),
+            "cores_note": "32 OpenMP threads: on these shapes torch's CPU GEMMs are slower with all hardware threads than with 32 (measured in round 1)",
             "sample": (f"{NB} samples, S={S}: ViT-L/14 fwd {t_vit:.2f}s + AttnPooler fwd+bwd {t_pool:.2f}s + lm_head/CE fwd+bwd {t_head:.2f}s "
-                       f"+ {NL} of 32 LLaMA-7B layers fwd+dX-bwd {NL * t_layer:.2f}s, per-layer time extrapolated x32 (oracle/lhrs_oracle.py, fp32 torch CPU)")}
+                       f"+ {NL} of 32 LLaMA-7B layers fwd+dX-bwd {NL * t_layer:.2f}s, per-layer time extrapolated x32 (oracle/lhrs_oracle.py, fp32 torch CPU)"),
+            "config1": {"value": B1 / t_c1, "unit": "samples/s", "cores": threads,
+                        "sample": f"BASELINE configs[0] (B=4, T=34, S=177): ViT + pooler scaled from the {NB}-sample timing, lm_head/CE {t_h1c:.2f}s, "
+                                  f"{NL} of 32 LLaMA layers {t_l1c - t_h1c:.2f}s extrapolated x32"}}
 
 
 
@@ -142,6 +161,51 @@ class _SmiSampler:
         pw = [p for _, p in s if p is not None]
         return sum(c for c, _ in s) / len(s), (sum(pw) / len(pw) if pw else None)
 
+LLAMA_LINEAR_PARAMS_PER_LAYER = 12288 * 4096 + 4096 * 4096 + 22016 * 4096 + 4096 * 11008  # qkv | o | gate,up | down
+
+
+def decode_probe(model, dev, weights="bf16", prompt_tokens=60, new_tokens=256, seed=322):
+    """BASELINE configs[4] / SURVEY §8d config 5: one 224x224 image, a 60-token prompt (S0 = 203 positions), greedy generate through the
+    captured hipGraph.  `value` = new tokens / wall time of the whole generate() call (ViT + projector + prefill included, as cli_qa.py
+    runs it); the roofline leg isolates the per-token step as the difference of two run lengths."""
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(3, 32000, (1, prompt_tokens), generator=g)
+    ids[0, 0], ids[0, 1] = 1, -200
+    rgb = torch.randn(1, 3, 224, 224, generator=g).to(dev)
+    kw = dict(images=rgb, do_sample=False, use_cache=True, weights=weights, eos_token_id=None)
+    was_training = model.training
+    model.eval()
+
+    def run(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = model.generate(ids, max_new_tokens=n, **kw)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, out.shape[1]
+
+    run(4)  # graph capture, weight repacks, allocator warm-up
+    n_short = max(8, new_tokens // 4)
+    t_short, _ = run(n_short)
+    t_full, n = run(new_tokens)
+    if was_training:
+        model.train()
+    nl = len(model.text.p["layers"])
+    esz = 1 if weights == "fp8" else 2
+    S0 = prompt_tokens - 1 + 144
+    per_tok = (t_full - t_short) / max(1, new_tokens - n_short)
+    ctx_mid = S0 + (n_short + new_tokens) / 2.0
+    w_bytes = (nl * LLAMA_LINEAR_PARAMS_PER_LAYER + 32000 * 4096) * esz          # every decoder linear + lm_head once per token
+    kv_bytes = 2 * nl * ctx_mid * 4096 * 2                                        # K and V of the context so far, bf16
+    ach = (w_bytes + kv_bytes) / per_tok / 1e9
+    return {"metric": "cli_qa single-image greedy generate tokens/s (ViT + projector + prefill included)", "value": round(n / t_full, 1),
+            "unit": "tokens/s", "new_tokens": n, "prompt_positions": S0, "weights": "e4m3 (fp8 MFMA weight stream)" if weights == "fp8" else "bf16",
+            "llama_layers": nl, "ms_per_token_step": round(1e3 * per_tok, 4),
+            "roofline": {"bound": "hbm", "kernel": "one captured hipGraph per token: 4 weight-streaming GEMVs + attention per layer, lm_head GEMV",
+                         "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_token": int(w_bytes + kv_bytes),
+                         "timing": f"wall clock (synchronised) of generate() at {n_short} and {new_tokens} new tokens; per-token = difference / {new_tokens - n_short}"}}
+
+
 def spawn_ranks(n: int):
     """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU, as the reference's
     `deepspeed --num_gpus=8` does (Script/train_stage1.sh:6-17).  Rank 0 prints the JSON line; the exit status is the launcher's."""
@@ -166,6 +230,11 @@ def main():
     ap.add_argument("--caption-tokens", type=int, default=128)
     ap.add_argument("--llama-layers", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the untimed extras (micro-batch-8 step rate, generate tokens/s) after the headline run")
+    ap.add_argument("--decode", action="store_true",
+                    help="make BASELINE configs[4] the line: cli_qa-shaped greedy generate (1 image, 60-token prompt), tokens/s with an HBM roofline")
+    ap.add_argument("--new-tokens", type=int, default=256, help="--decode: tokens generated per step")
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"], help="--decode: weight stream (fp8 = e4m3 MFMA weights)")
     ap.add_argument("--gemm-policy", type=int, default=None, help="kernel A/B tests only: lhrs_gemm_set_policy value")
     ap.add_argument("--stage", type=int, default=1, choices=[1, 2, 3],
                     help="1: projector-only + Adan (the headline metric, BASELINE configs[1..2]); 3: LoRA r=8 on q,k,v,o + AdamW, projector "
@@ -214,6 +283,20 @@ def main():
     B, T = a.micro_batch, a.caption_tokens + 2
     S = T - 1 + 144
     model = UniBind(("rgb", "text"), None, device=dev, llama_layers=a.llama_layers).init_random(seed=0)  # same weights on every rank
+    if a.decode:
+        if world > 1:
+            raise SystemExit("--decode is a single-sequence latency run (BASELINE configs[4]: 1xMI355X): replicas only, run it with --gpus 1")
+        res = None
+        for _ in range(max(1, a.steps)):  # a "step" = one whole generate() call; the best of them is reported
+            r = decode_probe(model, dev, a.weights, new_tokens=a.new_tokens)
+            res = r if res is None or r["value"] > res["value"] else res
+        res.update({"n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * res["new_tokens"] / res["value"], 3),
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.weights == "bf16" else "e4m3 weights, bf16 activations",
+                    "data": "synthetic", "config": {"workload": "BASELINE configs[4]: cli_qa.py single-image VQA generate, hipGraph-captured decode, "
+                                                                f"LLaMA2-7B ({a.llama_layers} layers) random-init, 60-token prompt + 144 image tokens, greedy",
+                                                    "batch": 1, "parallelism": "dp1"}})
+        print(json.dumps(res), flush=True)
+        return
     if a.stage == 1:
         model.prepare_for_training()
         engine = LHRSEngine(model, optimizer="adanp", lr=2e-4, weight_decay=0.0, max_grad_norm=0.3, comm_dtype=getattr(torch, a.comm_dtype))
@@ -239,7 +322,7 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     import ctypes
-    _lib.check(lib.lhrs_gemm_profile_enable(6000), "gemm_profile_enable")
+    _lib.check(lib.lhrs_gemm_profile_enable(16000), "gemm_profile_enable")
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -256,6 +339,8 @@ def main():
     sclk, watts = smi.stop() if smi is not None else (None, None)
     prof = (ctypes.c_double * 5)()
     _lib.check(lib.lhrs_gemm_profile_read(ctypes.addressof(prof)), "gemm_profile_read")
+    kinds = (ctypes.c_double * 12)()
+    _lib.check(lib.lhrs_gemm_profile_read_kinds(ctypes.addressof(kinds)), "gemm_profile_read_kinds")
     lib.lhrs_gemm_profile_enable(0)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
@@ -268,31 +353,71 @@ def main():
         n_samp, ms, fl = prof[0], prof[1], prof[2]
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         scale_layers = a.llama_layers / 32.0
-        traffic = None  # HBM-side bytes per launch of the dominant kernel come from the separate rocprofv3 --pmc passes
+        traffic, traffic_src = None, None  # L2-miss-side bytes per launch of the dominant kernel: separate rocprofv3 --pmc passes, NOT this run
         tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
-        if os.path.exists(tpath) and B == 30 and scale_layers == 1.0:
+        if os.path.exists(tpath) and B == 30 and scale_layers == 1.0 and a.stage == 1:
             traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
+            traffic_src = "profiles/r01_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command; a constant, not measured in this run)"
+        vnames = ("<ACT,0> plain", "<0,1> SwiGLU-fwd epilogue", "<0,2> SwiGLU-bwd epilogue", "<0,3> RoPE epilogue")
+        variants = {}
+        for k, nm in enumerate(vnames):
+            n_k, ms_k, fl_k = kinds[3 * k], kinds[3 * k + 1], kinds[3 * k + 2]
+            if n_k > 0 and ms_k > 0:
+                tf = fl_k / (ms_k * 1e-3) / 1e12
+                variants[nm] = {"launches": int(n_k), "avg_launch_us": round(1e3 * ms_k / n_k, 2), "achieved_tflops": round(tf, 1),
+                                "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
+        # FLOPs the step EXECUTES: F_alg counts lm_head forward + backward on all S positions; the engine runs it on the
+        # rows that have a target only (caption tokens), so the executed share is lower
+        tgt_rows = a.caption_tokens
+        f_exec = f_alg(S) - 2 * (S - tgt_rows) * 2 * 4096 * 32000
         res = {
             "metric": ("stage-1 pretrain samples/sec (224^2 image + 128-tok caption)" if a.stage == 1 else
                        f"stage-{a.stage} LoRA train samples/sec (224^2 image + 128-tok sequence)"), "value": round(sps, 3), "unit": "samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.bits == 16 or a.stage == 1 else "e4m3 base weights + bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: stage-1 projector-only, CLIP ViT-L/14@224 + AttnPooler + LLaMA2-7B "
-                                   f"({a.llama_layers} layers), S={S}, random-init weights",
+            "config": {"workload": (("BASELINE configs[1]: stage-1 projector-only" if world == 1 else "BASELINE configs[2]: stage-1 projector-only, DDP") if a.stage == 1
+                                    else ("BASELINE configs[3]: stage-3 SFT, LoRA r=8 on q,k,v,o" if a.stage == 3 else "stage-2 (Config/multi_modal_stage2.yaml): LoRA r=128 on all linears + projector"))
+                                   + f", CLIP ViT-L/14@224 + AttnPooler + LLaMA2-7B ({a.llama_layers} layers), S={S}, random-init weights",
                        "micro_batch_per_gpu": B, "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
                        "optimizer": "adanp" if a.stage == 1 else "adamw", "stage": a.stage,
-                       "lora": None if a.stage == 1 else ("r=8 on q,k,v,o, no dropout (text.eval())" if a.stage == 3 else "r=128 on all 7 linears, lora_dropout 0.05"),
+                       "lora": None if a.stage == 1 else ("r=8 on q,k,v,o, lora_dropout 0" if a.stage == 3 else "r=128 on all 7 linears, lora_dropout 0.05 (train mode)"),
                        "grad_allreduce": a.comm_dtype if world > 1 else "none",
                        "dist_backend": (torch.distributed.get_backend() if world > 1 else None)},
             "loss": round(final_loss, 4),
             "step_mfma_frac": round(sps / world * f_alg(S) / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 and a.stage == 1 else None,
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_256r_kernel<ACT, 0> (256x256 tile, 16 waves, BK=64 double-buffered LDS stages via global_load_lds DMA, v_mfma_f32_32x32x16_bf16; the two launches per layer with a fused SwiGLU epilogue are timed by rocprof only)", "achieved": round(ach, 1),
-                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "step_mfma_frac_executed": round(sps / world * f_exec / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 and a.stage == 1 else None,
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_256r_kernel<ACT, 0> (256x256 tile, 16 waves, BK=64 double-buffered LDS stages via global_load_lds DMA, v_mfma_f32_32x32x16_bf16; the two launches per layer with a fused SwiGLU epilogue are timed separately under `variants`)", "achieved": round(ach, 1),
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "variants": variants,
                          "launches_timed": int(n_samp), "avg_launch_us": round(1e3 * ms / max(n_samp, 1), 2),
                          "sclk_mhz_during_timed_region": round(sclk) if sclk else None, "package_power_w": round(watts) if watts else None,
                          "frac_of_peak_at_measured_clock": round(ach / (PEAK_BF16_TFLOPS * sclk / 2400.0), 4) if sclk else None,
                          "gemm_flops_share_of_step": round(prof[4] / a.steps / (B * f_alg(S)), 3) if scale_layers == 1.0 else None},
         }
+        if world == 1 and not a.no_extra and a.stage == 1:
+            extra = {}
+            try:  # the reference script's micro-batch (Script/train_stage1.sh:11), same engine, a few steps after the headline run
+                if B != 8:
+                    b8 = make_batch(8, T, dev, seed=322)
+                    for _ in range(2):
+                        out = engine(b8); engine.backward(out["total_loss"]); engine.step()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    n8 = 6
+                    for _ in range(n8):
+                        out = engine(b8); engine.backward(out["total_loss"]); engine.step()
+                    torch.cuda.synchronize()
+                    d8 = time.perf_counter() - t1
+                    extra["micro_batch_8"] = {"value": round(8 * n8 / d8, 2), "unit": "samples/s", "ms_per_step": round(1e3 * d8 / n8, 3), "steps": n8,
+                                              "step_mfma_frac": round(8 * n8 / d8 * f_alg(S) / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 else None,
+                                              "note": "the reference script's per-GPU batch (an 80 GB-GPU constraint): M = 2184 fills 56 % of one round of 256x256 tiles"}
+                del engine
+                torch.cuda.empty_cache()
+                extra["generate_bf16"] = decode_probe(model, dev, "bf16", new_tokens=128)
+                extra["generate_fp8"] = decode_probe(model, dev, "fp8", new_tokens=128)
+            except Exception as e:  # extras must never take the headline number down
+                extra["error"] = f"{type(e).__name__}: {e}"
+            res["extra"] = extra
         if world == 1 and not a.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(S)

@@ -40,7 +40,6 @@ int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, i
                       const void* bias, const void* residual, int ldr, int act, int out_f32, int accumulate,
                       float alpha, void* stream);
 
-/* live HIP-event timing of the dominant (128x128-tile) GEMM launches for bench.py's roofline leg; see gemm.hip */
 /* fused LoRA: C = alpha * (A.B^T + A2.B2^T) + bias + residual, A2 [M,K2] = (alpha_lora/r) * X.A_lora^T, B2 [N,K2] = B_lora
  * (peft lora.Linear.forward reached from lhrs/models/text_modal.py:133-151); K2 % 64 == 0 (zero padded). */
 int lhrs_gemm_bf16_nt_lora(const void* A, int lda, const void* B, int ldb, const void* A2, int lda2, const void* B2, int ldb2,
@@ -107,8 +106,12 @@ int lhrs_gemm_set_policy(int allow_256);
 int lhrs_gemm_set_tail_split(int on);
 /* kernel A/B tests only: fewest 256x256 tiles for which lhrs_gemm_bf16_nt picks the big-tile kernel (default 128) */
 int lhrs_gemm_set_min_tiles(int n);
+/* live HIP-event timing of the 16-wave 256x256 GEMM launches, on their launch stream, for bench.py's roofline leg (gemm.hip):
+ * enable(n) arms n event pairs (0 = off); read() -> {launches of the dominant <ACT,0> kernel, their ms, their flops, all GEMM launches,
+ * all GEMM flops}; read_kinds() -> [4][3] = {launches, ms, flops} per epilogue variant (0 plain, 1 SwiGLU fwd, 2 SwiGLU bwd, 3 RoPE) */
 int lhrs_gemm_profile_enable(int max_samples);
 int lhrs_gemm_profile_read(double* out5_host);
+int lhrs_gemm_profile_read_kinds(double* out12_host);
 
 /* ---- LoRA gradients (peft lora.Linear backward; lhrs/models/text_modal.py:133-151) ------------------------- *
  * C[KP,N] (+)= P[M,KP]^T . Q[M,N]: dA = (s dy B)^T x and dB^T = (s x A^T)^T dy straight from token-major operands.  */

@@ -1327,6 +1327,7 @@ struct GemmProf {
   int cap = 0, used = 0;
   hipEvent_t* ev = nullptr;   // 2 * cap
   double* flops = nullptr;    // cap
+  int* kind = nullptr;        // cap: epilogue variant of the sampled launch (0 plain <ACT,0>, 1 SwiGLU fwd, 2 SwiGLU bwd, 3 RoPE)
   double total_flops_all = 0; // every GEMM launch while enabled (sampled or not)
   long launches_all = 0;
 } g_prof;
@@ -1335,14 +1336,15 @@ struct GemmProf {
 extern "C" int lhrs_gemm_profile_enable(int max_samples) {
   if (g_prof.ev) {
     for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
-    delete[] g_prof.ev; delete[] g_prof.flops;
-    g_prof.ev = nullptr; g_prof.flops = nullptr;
+    delete[] g_prof.ev; delete[] g_prof.flops; delete[] g_prof.kind;
+    g_prof.ev = nullptr; g_prof.flops = nullptr; g_prof.kind = nullptr;
   }
   g_prof.on = max_samples > 0; g_prof.cap = max_samples > 0 ? max_samples : 0; g_prof.used = 0;
   g_prof.total_flops_all = 0; g_prof.launches_all = 0;
   if (g_prof.on) {
     g_prof.ev = new hipEvent_t[2 * g_prof.cap];
     g_prof.flops = new double[g_prof.cap];
+    g_prof.kind = new int[g_prof.cap];
     for (int i = 0; i < 2 * g_prof.cap; ++i)
       if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) LHRS_FAIL("gemm_profile_enable: hipEventCreate failed");
   }
@@ -1352,14 +1354,29 @@ extern "C" int lhrs_gemm_profile_enable(int max_samples) {
 // out[0] = sampled launches, out[1] = their summed duration (ms), out[2] = their summed flops,
 // out[3] = all GEMM launches while enabled, out[4] = flops of all of them
 extern "C" int lhrs_gemm_profile_read(double* out) {
-  double ms = 0, fl = 0;
+  double ms = 0, fl = 0, n = 0;
   for (int i = 0; i < g_prof.used; ++i) {
+    if (g_prof.kind[i] != 0) continue;  // the dominant kernel only; the fused-epilogue variants: lhrs_gemm_profile_read_kinds
     float t = 0;
     if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) LHRS_FAIL("gemm_profile_read: event sync failed");
     if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) LHRS_FAIL("gemm_profile_read: elapsed failed");
-    ms += t; fl += g_prof.flops[i];
+    ms += t; fl += g_prof.flops[i]; n += 1;
   }
-  out[0] = g_prof.used; out[1] = ms; out[2] = fl; out[3] = (double)g_prof.launches_all; out[4] = g_prof.total_flops_all;
+  out[0] = n; out[1] = ms; out[2] = fl; out[3] = (double)g_prof.launches_all; out[4] = g_prof.total_flops_all;
+  return 0;
+}
+
+// out[4][3]: per epilogue variant k (0 plain <ACT,0>, 1 SwiGLU fwd <0,1>, 2 SwiGLU bwd <0,2>, 3 RoPE <0,3>) of the 16-wave 256x256 kernel:
+// sampled launches, their summed duration (ms), their summed flops
+extern "C" int lhrs_gemm_profile_read_kinds(double* out) {
+  for (int i = 0; i < 12; ++i) out[i] = 0;
+  for (int i = 0; i < g_prof.used; ++i) {
+    float t = 0;
+    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) LHRS_FAIL("gemm_profile_read_kinds: event sync failed");
+    if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) LHRS_FAIL("gemm_profile_read_kinds: elapsed failed");
+    const int k = g_prof.kind[i];
+    out[3 * k] += 1; out[3 * k + 1] += t; out[3 * k + 2] += g_prof.flops[i];
+  }
   return 0;
 }
 
@@ -1488,6 +1505,7 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
     if (dominant && g_prof.used < g_prof.cap) {  // time exactly the launches rocprof lists as gemm_nt_256r_kernel<ACT, 0>
       slot = g_prof.used++;
       g_prof.flops[slot] = 2.0 * M * N * (K + K2);
+      g_prof.kind[slot] = 0;
       (void)hipEventRecord(g_prof.ev[2 * slot], s);
     }
   }
@@ -1556,9 +1574,17 @@ extern "C" int lhrs_gemm_swiglu_fusable(int M, int ff, int K_fwd, int K_bwd, int
 
 // the fused-epilogue launches count towards the step's GEMM FLOPs but are NOT timed as "the dominant kernel": their epilogues do
 // elementwise work (SwiGLU) that has no FLOPs in the GEMM roofline - the live roofline figure is the plain gemm_nt_256r_kernel<ACT, 0>
-static void prof_count(int M, int N, int K) {
-  if (!g_prof.on) return;
+static int prof_count(int M, int N, int K, int kind, hipStream_t s) {
+  if (!g_prof.on) return -1;
   g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * K;
+  if (g_prof.used >= g_prof.cap) return -1;
+  const int slot = g_prof.used++;
+  g_prof.flops[slot] = 2.0 * M * N * K; g_prof.kind[slot] = kind;
+  (void)hipEventRecord(g_prof.ev[2 * slot], s);
+  return slot;
+}
+static void prof_end(int slot, hipStream_t s) {
+  if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], s);
 }
 
 extern "C" int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int ldw, const void* A2, int lda2, const void* B2, int ldb2,
@@ -1576,8 +1602,9 @@ extern "C" int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int
   g.epi = 1; g.ff = ff; g.aux_out = (bf16_t*)act; g.ld_aux = ld_act;
   g.tilesM = cdiv(M, 256); g.tilesN = ff / 128;
   hipStream_t s = (hipStream_t)stream;
-  prof_count(M, 2 * ff, K + K2);
+  const int pslot = prof_count(M, 2 * ff, K + K2, 1, s);
   hipLaunchKernelGGL((gemm_nt_256r_kernel<0, 1>), dim3(g.tilesM * g.tilesN), dim3(1024), 0, s, g);
+  prof_end(pslot, s);
   LHRS_CHECK_LAUNCH("gemm_swiglu_fwd");
   return 0;
 }
@@ -1605,8 +1632,9 @@ extern "C" int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw
   g.alpha = 1.f; g.A2 = (const bf16_t*)A2; g.B2 = (const bf16_t*)B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
   g.epi = 3; g.rope_cos = cos_t; g.rope_sin = sin_t; g.rope_mod = pos_mod; g.rope_pos0 = pos0; g.rope_cols = rope_cols;
   g.tilesM = cdiv(M, 256); g.tilesN = cdiv(N, 256);
-  prof_count(M, N, K + K2);
+  const int pslot = prof_count(M, N, K + K2, 3, (hipStream_t)stream);
   hipLaunchKernelGGL((gemm_nt_256r_kernel<0, 3>), dim3(g.tilesM * g.tilesN), dim3(1024), 0, (hipStream_t)stream, g);
+  prof_end(pslot, (hipStream_t)stream);
   LHRS_CHECK_LAUNCH("gemm_rope_fwd");
   return 0;
 }
@@ -1625,8 +1653,9 @@ extern "C" int lhrs_gemm_swiglu_bwd(const void* dY, int ldy, const void* WdT, in
   g.epi = 2; g.ff = ff; g.aux = (const bf16_t*)gu; g.ld_aux = ld_gu;
   g.tilesM = cdiv(M, 256); g.tilesN = cdiv(ff, 256);
   hipStream_t s = (hipStream_t)stream;
-  prof_count(M, ff, K + K2);
+  const int pslot = prof_count(M, ff, K + K2, 2, s);
   hipLaunchKernelGGL((gemm_nt_256r_kernel<0, 2>), dim3(g.tilesM * g.tilesN), dim3(1024), 0, s, g);
+  prof_end(pslot, s);
   LHRS_CHECK_LAUNCH("gemm_swiglu_bwd");
   return 0;
 }

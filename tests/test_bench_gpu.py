@@ -27,8 +27,29 @@ def test_bench_emits_the_contract_line():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and 0 < r["achieved"] < r["peak"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["launches_timed"] > 0
+    assert "not measured in this run" in (r["traffic_source"] or "not measured in this run")
+    v = r["variants"]
+    assert {"<ACT,0> plain", "<0,1> SwiGLU-fwd epilogue", "<0,2> SwiGLU-bwd epilogue", "<0,3> RoPE epilogue"} <= set(v), v
+    assert all(0 < x["frac"] < 1 and x["launches"] > 0 for x in v.values())
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "samples/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert c["config1"]["value"] > 0 and "B=4, T=34" in c["config1"]["sample"]
+    e = d["extra"]
+    assert "error" not in e, e
+    assert e["micro_batch_8"]["value"] > 0 and e["generate_bf16"]["value"] > 0 and e["generate_fp8"]["value"] > 0
+    assert e["generate_bf16"]["roofline"]["bound"] == "hbm" and 0 < e["generate_bf16"]["roofline"]["frac"] < 1
+
+
+@pytest.mark.timeout(900)
+def test_bench_decode_line():
+    """`bench.py --decode`: BASELINE configs[4] as the line - tokens/s of a cli_qa-shaped greedy generate with an HBM roofline object."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--decode", "--steps", "1", "--llama-layers", "2", "--new-tokens", "48",
+                          "--weights", "fp8"], capture_output=True, text=True, timeout=800, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["unit"] == "tokens/s" and d["value"] > 0 and d["new_tokens"] == 48 and d["n_gpus"] == 1 and d["higher_is_better"] is True
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["unit"] == "GB/s" and d["roofline"]["peak"] == 8000.0 and 0 < d["roofline"]["frac"] < 1
+    assert "configs[4]" in d["config"]["workload"] and "e4m3" in d["dtype"]
 
 
 @pytest.mark.timeout(1200)
