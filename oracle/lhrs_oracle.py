@@ -199,22 +199,23 @@ def llama_hidden(p: Dict, embeds: torch.Tensor, mask: Optional[torch.Tensor], he
     if mask is not None:
         bias = bias.masked_fill(~mask.bool()[:, None, None, :], neg)
     x = embeds
+    lin = p.get("_linear", F.linear)  # oracle/int8_oracle.py swaps in the LLM.int8 product for `bits: 8` base weights
     for L in p["layers"]:
         h = _rms(x, L["ln1_w"], eps)
-        qkv = F.linear(h, L["qkv_w"])
+        qkv = lin(h, L["qkv_w"])
         qkv = qkv + torch.cat([_lora(L, pr, h) + torch.zeros_like(qkv[..., :d]) for pr in ("q", "k", "v")], -1)
         qkv = qkv.view(B, S, 3, heads, hd)
         q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
         q, k = _rope(q, cos, sin), _rope(k, cos, sin)
         a = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd) + bias, -1) @ v
         a = a.transpose(1, 2).reshape(B, S, d)
-        x = x + F.linear(a, L["o_w"]) + _lora(L, "o", a)
+        x = x + lin(a, L["o_w"]) + _lora(L, "o", a)
         h = _rms(x, L["ln2_w"], eps)
         ff = L["gu_w"].shape[0] // 2
-        gu = F.linear(h, L["gu_w"])
+        gu = lin(h, L["gu_w"])
         gu = gu + torch.cat([_lora(L, pr, h) + torch.zeros_like(gu[..., :ff]) for pr in ("gate", "up")], -1)
         act = F.silu(gu[..., :ff]) * gu[..., ff:]
-        x = x + F.linear(act, L["down_w"]) + _lora(L, "down", act)
+        x = x + lin(act, L["down_w"]) + _lora(L, "down", act)
         if collect is not None:
             collect.append(x)
     return _rms(x, p["norm_w"], eps)

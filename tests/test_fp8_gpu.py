@@ -145,3 +145,53 @@ def test_lora_training_on_e4m3_base_follows_the_bf16_loss_curve():
     c16, c8 = curve(16), curve(8)
     assert c16[-1] < 0.05 * c16[0] and c8[-1] < 0.05 * c8[0], (c16[0], c16[-1], c8[0], c8[-1])   # both fit the batch
     assert all(abs(a - b) < 0.1 * b + 0.02 for a, b in zip(c8, c16)), list(zip(c8, c16))         # along the same curve
+
+
+@pytest.mark.timeout(900)
+def test_e4m3_base_against_the_llm_int8_oracle():
+    """§8 f-4: the reference runs stages 2/3 on a bitsandbytes LLM.int8 base (`bits: 8`, text_modal.py:91-131).  This engine's 8-bit base
+    is e4m3 on the block-scaled MFMA - a DELIBERATE DEVIATION (no outlier decomposition; weights, activations and gradients all e4m3
+    with per-row scales).  oracle/int8_oracle.py restates LLM.int8 (PARITY UNPINNED: bitsandbytes is absent).  Same 2-layer model, same
+    LoRA state (r = 8 on q,k,v,o), same batch through (a) the fp32 oracle, (b) the LLM.int8 oracle, (c) the HIP e4m3 path: loss and
+    every adapter gradient.  Bar: the e4m3 path sits no further from fp32 than 1.5x the int8 restatement does (+ the bf16 floor), and the
+    two 8-bit schemes agree with each other to 6e-2 on the loss-relevant quantities."""
+    from oracle import int8_oracle as I8
+    from oracle import lhrs_oracle as O
+    from test_lora_gpu import make
+    targets = ("q", "k", "v", "o")
+    model, lora, P, batch = make(targets, 8, False)
+    model.text.quantize_base(8)
+    model.eval()        # stage 3: text.eval() -> lora_dropout off
+    model.training = True
+    loss_hip = model(batch)["total_loss"].item()
+    model.text.backward(need_input_grad=False)
+    torch.cuda.synchronize()
+    got = {(l, pr): [t.float().cpu().clone() for t in lora.grad_adapter(l, pr)] for l in range(2) for pr in targets}
+
+    def oracle_run(llama):
+        leaves = []
+        for L in llama["layers"]:
+            for pr in targets:
+                for t in L["lora"][pr]:
+                    t.grad = None
+                    leaves.append(t)
+        loss = O.unibind_forward(dict(P, llama=llama), batch)
+        loss.backward()
+        return loss.item(), {(l, pr): [t.grad.clone() for t in llama["layers"][l]["lora"][pr]] for l in range(2) for pr in targets}
+
+    torch.set_num_threads(32)
+    l32, g32 = oracle_run(P["llama"])
+    l8, g8 = oracle_run(I8.int8_llama_params(P["llama"]))
+
+    def dist(a, b):
+        num = sum(((x.double() - y.double()) ** 2).sum() for k in a for x, y in zip(a[k], b[k]))
+        den = sum((y.double() ** 2).sum() for k in b for y in b[k])
+        return float((num / den).sqrt())
+
+    d_hip32, d_int32, d_hip_int = dist(got, g32), dist(g8, g32), dist(got, g8)
+    print(f"loss fp32 {l32:.4f} int8 {l8:.4f} e4m3 {loss_hip:.4f}; adapter-gradient rel-L2: e4m3 vs fp32 {d_hip32:.4f}, LLM.int8 vs fp32 {d_int32:.4f}, "
+          f"e4m3 vs LLM.int8 {d_hip_int:.4f}")
+    assert abs(loss_hip - l32) < max(1.5 * abs(l8 - l32), 3e-3 * l32), (loss_hip, l8, l32)
+    assert abs(loss_hip - l8) < 6e-2 * l8
+    assert d_hip32 < max(1.5 * d_int32, 5e-2) + 5e-2, (d_hip32, d_int32)
+    assert d_hip_int < 0.25, d_hip_int
