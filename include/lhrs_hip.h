@@ -45,8 +45,6 @@ int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, i
 int lhrs_gemm_bf16_nt_lora(const void* A, int lda, const void* B, int ldb, const void* A2, int lda2, const void* B2, int ldb2,
                            int K2, void* C, int ldc, int M, int N, int K, const void* bias, const void* residual, int ldr,
                            int out_f32, int accumulate, float alpha, void* stream);
-/* 256x256-tile kernel choice (tuning / A-B tests): 0 never, 1 plain 4-stage ring, 2 default (16-wave BK=64 two-buffer kernel
- * when K % 64 == 0, else the BK=32 ring), 3 the 8-wave BK=64 kernel, 4 always the BK=32 ring */
 /* 8-bit frozen base weights (the reference trains stages 2/3 with `bits: 8`, lhrs/models/text_modal.py:91-131 -> bitsandbytes LLM.int8;
  * here OCP e4m3 with per-row fp32 scales on the 2x-rate block-scaled MFMA, unit block scales): C[M, N] bf16 =
  * sa[m] * sb[n] * (A8[M, K] . B8[N, K]^T) (+ residual).  A8 / B8 from lhrs_quant_fp8_rows; lda / ldb in bytes; K % 128 == 0. */
@@ -100,10 +98,15 @@ int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw, const voi
 int lhrs_dropout_bf16(const void* x, long ldx, void* out, long ldo, long rows, int cols, float p, unsigned seed, void* stream);
 int lhrs_gemm_bf16_nt_dropmask(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                                const void* residual, int ldr, float alpha, float p, unsigned seed, void* stream);
+/* 256x256-tile kernel choice (tuning / A-B tests): 0 never, 2 default (16-wave BK=64 two-buffer kernel when K % 64 == 0, else the BK=32
+ * ring), 4 always the BK=32 ring */
 int lhrs_gemm_set_policy(int allow_256);
 /* kernel A/B tests only: 0 disables the tail-row rule (a product whose last round of 256x256 tiles would be nearly empty is cut into
  * whole tile rows for the 16-wave kernel + the remaining rows for the small-tile kernel); default 1 */
 int lhrs_gemm_set_tail_split(int on);
+/* kernel A/B tests only: 1 (default) = the 16-wave 256x256 kernel runs one persistent workgroup per CU walking its tiles (the next tile's
+ * first operands are fetched under the current tile's epilogue); 0 = one workgroup per tile */
+int lhrs_gemm_set_persistent(int on);
 /* kernel A/B tests only: fewest 256x256 tiles for which lhrs_gemm_bf16_nt picks the big-tile kernel (default 128) */
 int lhrs_gemm_set_min_tiles(int n);
 /* live HIP-event timing of the 16-wave 256x256 GEMM launches, on their launch stream, for bench.py's roofline leg (gemm.hip):

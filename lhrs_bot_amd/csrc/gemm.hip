@@ -67,8 +67,9 @@ struct GemmArgs {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ __forceinline__ void tile_coords(const GemmArgs& g, int& tm, int& tn) {
-  const int bid = blockIdx.x, nblk = gridDim.x;
+// tile `bid` of `nblk` (the order tiles are dispatched in) -> (tm, tn): consecutive bids alternate over the 8 XCDs (bid & 7), so each XCD
+// gets a contiguous run of the m-fastest raster grouped by 8 tile rows - the 32 tiles an XCD works on at a time share 8 A and 4 B panels
+__device__ __forceinline__ void tile_coords_lin(const GemmArgs& g, int bid, int nblk, int& tm, int& tn) {
   const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
   const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   constexpr int GM = 8;
@@ -80,6 +81,7 @@ __device__ __forceinline__ void tile_coords(const GemmArgs& g, int& tm, int& tn)
   tm = first_m + in_g % gsize;
   tn = in_g / gsize;
 }
+__device__ __forceinline__ void tile_coords(const GemmArgs& g, int& tm, int& tn) { tile_coords_lin(g, blockIdx.x, gridDim.x, tm, tn); }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == 1) return quick_gelu(v);
@@ -232,132 +234,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 
 
 // ------------------------------------------------------------------------------------------------
-// 256x256 tile, 8 waves (2 x 4), v_mfma_f32_32x32x16_bf16, BK = 32 stages in a 4-deep LDS ring (128 KiB).
-//
-// Why this shape: a 128^2 tile moves 1/64 B of L2->LDS traffic per flop (15 TB/s at 950 TFLOP/s - the measured
-// ceiling of the kernel above); 256^2 halves it, and the 32x32x16 MFMA has the higher issue-rate ceiling.
-// Pipeline: the DMA for stage i+3 is issued right after the barrier that opens stage i, so a stage has three
-// stage-times (~3 x 1000 cycles) to land; each wave waits only for ITS OWN loads of stage i with a COUNTED
-// s_waitcnt vmcnt(8) (never 0 in the steady state), then one s_barrier publishes the stage to all waves.
-//   RAW: a wave reads stage i only after [its vmcnt -> barrier(i)], which every loading wave reaches after its own
-//        vmcnt for stage i.
-//   WAR: buffer (i+3)&3 == (i-1)&3 is refilled only after barrier(i), which every wave reaches after issuing the
-//        MFMAs that consumed its ds_reads of stage i-1.
-// LDS image of a stage: A[256][32], B[256][32] bf16 (64-B rows); 16-B chunk index XOR ((row>>2)&3) makes every
-// ds_read_b128 lane group hit 16 distinct slots of the 256-B bank row (swizzle applied on DMA source + read).
-// ------------------------------------------------------------------------------------------------
-template <int ACT>
-__global__ __launch_bounds__(512, 2) void gemm_nt_256_kernel(GemmArgs g) {
-  constexpr int BM = 256, BN = 256, BK = 32, NS = 4;
-  constexpr int A_BYTES = BM * BK * 2, STAGE = A_BYTES + BN * BK * 2;  // 16 KiB + 16 KiB
-  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
-
-  int tm, tn;
-  tile_coords(g, tm, tn);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  // ---- DMA: per stage 32 wave-instructions of 1 KiB (16 rows x 64 B); wave w issues #4w..4w+3 (waves 0-3: A, 4-7: B)
-  const int lrow = lane >> 2;
-  const int lchunk = (lane & 3) ^ ((lane >> 4) & 3);
-  const bf16_t* src[4];
-  int dst_off[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int idx = wave * 4 + j;
-    if (idx < 16) {
-      const int row = min(tm * BM + idx * 16 + lrow, g.M - 1);
-      src[j] = g.A + (long)row * g.lda + lchunk * 8;
-      dst_off[j] = idx * 1024;
-    } else {
-      const int row = min(tn * BN + (idx - 16) * 16 + lrow, g.N - 1);
-      src[j] = g.B + (long)row * g.ldb + lchunk * 8;
-      dst_off[j] = A_BYTES + (idx - 16) * 1024;
-    }
-  }
-  auto issue = [&](int kt) {
-    char* base = smem + (kt & (NS - 1)) * STAGE;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + (long)kt * BK), (lptr_t)(base + dst_off[j]), 16, 0, 0);
-  };
-
-  // ---- fragments: wave (wm, wn) owns rows [wm*128,+128) x cols [wn*64,+64)
-  const int wm = wave >> 2, wn = wave & 3;
-  const int fr = lane & 31, fh = lane >> 5;
-  const int sw = (lane >> 2) & 3;
-  const int a_base = (wm * 128 + fr) * 64;            // + mi*32*64
-  const int b_base = A_BYTES + (wn * 64 + fr) * 64;   // + ni*32*64
-  int koff[2];
-  koff[0] = ((0 * 2 + fh) ^ sw) * 16;
-  koff[1] = ((1 * 2 + fh) ^ sw) * 16;
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  auto compute = [&](int kt) {
-    const char* st = smem + (kt & (NS - 1)) * STAGE;
-    // all 12 fragment reads of the stage are issued before the first MFMA (48 VGPRs): the MFMAs then run
-    // back to back behind counted lgkmcnt waits instead of read->wait->4 MFMA->read->wait...
-    bf16x8 af[2][4], bfr[2][2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) bfr[kk][ni] = *reinterpret_cast<const bf16x8*>(st + b_base + ni * 2048 + koff[kk]);
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) af[kk][mi] = *reinterpret_cast<const bf16x8*>(st + a_base + mi * 2048 + koff[kk]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[kk][ni], af[kk][mi], acc[mi][ni], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  const int nk = g.K / BK;  // >= 3 (host guarantees)
-  issue(0); issue(1); issue(2);
-  for (int kt = 0; kt < nk - 2; ++kt) {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 3 < nk) issue(kt + 3);
-    compute(kt);
-  }
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  compute(nk - 2);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  compute(nk - 1);
-
-  // ---- epilogue: lane holds C[m = .. + fr][n = .. + 8*q + 4*fh + 0..3], q = 0..3
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int m = tm * BM + wm * 128 + mi * 32 + fr;
-    if (m >= g.M) continue;
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4;
-        if (n >= g.N) continue;
-        store4<ACT>(g, m, n, f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]});
-      }
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// 256x256 "pipelined" variant: same tile / ring as gemm_nt_256_kernel, but the ds_read of the NEXT k-step is in
+// 256x256 tile, 8 waves (2 x 4), BK = 32 stages in a 4-deep LDS ring (128 KiB), DMA two stages ahead; the ds_read of the NEXT k-step is in
 // flight while the MFMAs of the current k-step issue, so LDS latency never sits in front of the matrix pipe.
 // Fragment reads are inline asm (hipcc would otherwise place an lgkmcnt(0) right before every consumer, i.e.
 // behind the reads just issued); every wait is an explicit lgkmcnt(0) placed BEFORE the next batch of reads, so
@@ -596,205 +473,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256p_kernel(GemmArgs g) {
 
 
 // ------------------------------------------------------------------------------------------------
-// 256x256 "q" variant: BK = 64 stages (full 128-B rows: every DMA instruction moves 8 whole cache lines instead of 16 half
-// lines), two LDS buffers, ONE barrier per 32 MFMAs.  The stage is consumed as 4 blocks of 8 MFMAs; behind every MFMA sits a
-// ds_read of the next block's fragments, and the 8 DMA pieces of the NEXT stage are issued in the first three blocks after the
-// barrier so that each has at least one full block (~500 cycles) before the vmcnt(0) that precedes the next barrier.
-//   barrier(i) sits at the top of block k3(i-1), AFTER the lgkmcnt wait that completes the last LDS reads of stage i-1: it
-//   (a) publishes stage i (every wave waited vmcnt(0) on its own pieces first) and (b) frees buffer (i-1)&1 for the DMA of
-//   stage i+1 - nothing relies on timing.
-// LDS image: A[256][64], B[256][64] bf16 per buffer; 16-B chunk index XOR ((row>>1)&7): 32-row fragment reads hit 16 distinct
-// slots per lane group (rows of equal parity get distinct chunks).
-// ------------------------------------------------------------------------------------------------
-template <int ACT>
-__global__ __launch_bounds__(512, 2) void gemm_nt_256q_kernel(GemmArgs g) {
-  constexpr int BM = 256, BN = 256, BK = 64;
-  constexpr int A_BYTES = BM * BK * 2, STAGE = A_BYTES + BN * BK * 2;  // 32 KiB + 32 KiB
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-
-  int tm, tn;
-  tile_coords(g, tm, tn);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  // DMA: per stage 64 wave-instructions of 1 KiB (8 rows x 128 B); wave w issues #8w..8w+7 (waves 0-3: A, 4-7: B).
-  // Addresses are a wave-uniform base (SGPR pair, advanced per stage) + a 32-bit per-lane byte offset per piece.
-  const bool isA = wave < 4;
-  const char* base1 = reinterpret_cast<const char*>(isA ? g.A : g.B);
-  const char* base2 = reinterpret_cast<const char*>(isA ? g.A2 : g.B2);
-  const long ld1 = isA ? g.lda : g.ldb, ld2 = isA ? g.lda2 : g.ldb2;
-  const int row0 = isA ? tm * BM : tn * BN, rmax = (isA ? g.M : g.N) - 1;
-  unsigned off1[8], off2[8];
-  const int nk1 = g.K / BK;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int ridx = (wave & 3) * 8 + j;  // 8-row group inside the operand tile
-    const int lchunk = (lane & 7) ^ ((((j & 1) << 2) + (lane >> 4)) & 7);  // (row>>1)&7 with row = ridx*8 + (lane>>3)
-    const int row = min(row0 + ridx * 8 + (lane >> 3), rmax);
-    off1[j] = (unsigned)(((long)row * ld1 + lchunk * 8) * 2);
-    off2[j] = g.K2 > 0 ? (unsigned)(((long)row * ld2 + lchunk * 8) * 2) : 0u;
-  }
-  const int dst0 = (isA ? 0 : A_BYTES) + (wave & 3) * 8192;
-  auto issue1 = [&](int kt, int j) {
-    const char* p = kt < nk1 ? base1 + (long)kt * (BK * 2) + off1[j] : base2 + (long)(kt - nk1) * (BK * 2) + off2[j];
-    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + (kt & 1) * STAGE + dst0 + j * 1024), 16, 0, 0);
-  };
-
-  const int wm = wave >> 2, wn = wave & 3;
-  const int fr = lane & 31, fh = lane >> 5;
-  const int sw = (fr >> 1) & 7;
-  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
-  const unsigned a_base = lds0 + (wm * 128 + fr) * 128;
-  const unsigned b_base = lds0 + A_BYTES + (wn * 64 + fr) * 128;
-  unsigned koff[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) koff[kk] = ((kk * 2 + fh) ^ sw) * 16;
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  bf16x8 a0[4], b0[2], a1[4], b1[2];
-#define RDQ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
-#define MFQ(A_, B_, mi, ni) \
-  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B_[ni], A_[mi], acc[mi][ni], 0, 0, 0); __builtin_amdgcn_sched_barrier(0);
-#define SB __builtin_amdgcn_sched_barrier(0);
-  // one block: 8 MFMAs on (Ac, Bc); fillers: the 6 fragment reads of the next block into (An, Bn) from (aa, ba) and, when
-  // NDMA > 0, DMA pieces [d0, d0 + NDMA) of stage `kd`
-#define BLOCK(Ac, Bc, An, Bn, aa, ba, RD, kd, d0, NDMA, C)                                       \
-  MFQ(Ac, Bc, 0, 0) if (RD) RDQ(Bn[0], ba, 0);     if (NDMA > 0 && (C)) issue1(kd, d0);     SB     \
-  MFQ(Ac, Bc, 0, 1) if (RD) RDQ(Bn[1], ba, 4096);  if (NDMA > 4 && (C)) issue1(kd, d0 + 4); SB     \
-  MFQ(Ac, Bc, 1, 0) if (RD) RDQ(An[0], aa, 0);     if (NDMA > 1 && (C)) issue1(kd, d0 + 1); SB     \
-  MFQ(Ac, Bc, 1, 1) if (RD) RDQ(An[1], aa, 4096);  if (NDMA > 5 && (C)) issue1(kd, d0 + 5); SB     \
-  MFQ(Ac, Bc, 2, 0) if (RD) RDQ(An[2], aa, 8192);  if (NDMA > 2 && (C)) issue1(kd, d0 + 2); SB     \
-  MFQ(Ac, Bc, 2, 1) if (RD) RDQ(An[3], aa, 12288); if (NDMA > 6 && (C)) issue1(kd, d0 + 6); SB     \
-  MFQ(Ac, Bc, 3, 0)                                if (NDMA > 3 && (C)) issue1(kd, d0 + 3); SB     \
-  MFQ(Ac, Bc, 3, 1)                                if (NDMA > 7 && (C)) issue1(kd, d0 + 7); SB
-
-  const int nk = (g.K + g.K2) / BK;  // >= 2 (host guarantees)
-#pragma unroll
-  for (int j = 0; j < 8; ++j) issue1(0, j);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-#pragma unroll
-  for (int j = 0; j < 8; ++j) issue1(1, j);
-  {  // k0(0) -> set0
-    const unsigned aa = a_base + koff[0], ba = b_base + koff[0];
-    RDQ(b0[0], ba, 0); RDQ(b0[1], ba, 4096); RDQ(a0[0], aa, 0); RDQ(a0[1], aa, 4096); RDQ(a0[2], aa, 8192); RDQ(a0[3], aa, 12288);
-  }
-  // blocks k0, k1, k2 of stage 0 (DMA of stage 1 is already in flight)
-  lds_wait6(a0, b0);
-  { const unsigned aa = a_base + koff[1], ba = b_base + koff[1]; BLOCK(a0, b0, a1, b1, aa, ba, true, 0, 0, 0, true) }
-  lds_wait6(a1, b1);
-  { const unsigned aa = a_base + koff[2], ba = b_base + koff[2]; BLOCK(a1, b1, a0, b0, aa, ba, true, 0, 0, 0, true) }
-  lds_wait6(a0, b0);
-  { const unsigned aa = a_base + koff[3], ba = b_base + koff[3]; BLOCK(a0, b0, a1, b1, aa, ba, true, 0, 0, 0, true) }
-
-  // DMA placement: 6 pieces behind the MFMAs of the first block after the barrier, 2 in the second - issued as early as the
-  // freed buffer allows (measured: (6,2,0) +3 % over (3,3,2); splitting the two waves of a SIMD over different blocks -8 %)
-  constexpr int QD3 = 6, QD0 = 2, QD1 = 0, QO0 = QD3, QO1 = QD3 + QD0;
-  constexpr bool c3 = true, c0 = true;
-  auto stage = [&](auto dma_c, int kt) {
-    constexpr bool DMA = decltype(dma_c)::value;
-    const unsigned so = (kt & 1) * STAGE;
-    // ---- block k3(kt-1): completes the reads of stage kt-1, then the barrier that publishes stage kt
-    lds_wait6(a1, b1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    { const unsigned aa = a_base + so + koff[0], ba = b_base + so + koff[0]; BLOCK(a1, b1, a0, b0, aa, ba, true, kt + 1, 0, (DMA ? QD3 : 0), c3) }
-    lds_wait6(a0, b0);
-    { const unsigned aa = a_base + so + koff[1], ba = b_base + so + koff[1]; BLOCK(a0, b0, a1, b1, aa, ba, true, kt + 1, QO0, (DMA ? QD0 : 0), c0) }
-    lds_wait6(a1, b1);
-    { const unsigned aa = a_base + so + koff[2], ba = b_base + so + koff[2]; BLOCK(a1, b1, a0, b0, aa, ba, true, kt + 1, QO1, (DMA ? QD1 : 0), true) }
-    lds_wait6(a0, b0);
-    { const unsigned aa = a_base + so + koff[3], ba = b_base + so + koff[3]; BLOCK(a0, b0, a1, b1, aa, ba, true, 0, 0, 0, true) }
-  };
-  for (int kt = 1; kt < nk - 1; ++kt) stage(std::true_type{}, kt);
-  stage(std::false_type{}, nk - 1);
-  lds_wait6(a1, b1);
-  { BLOCK(a1, b1, a0, b0, a_base, b_base, false, 0, 0, 0, true) }
-#undef BLOCK
-#undef SB
-#undef MFQ
-#undef RDQ
-
-  if (g.out_f32) {
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int m = tm * BM + wm * 128 + mi * 32 + fr;
-      if (m >= g.M) continue;
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4;
-          if (n >= g.N) continue;
-          store4<ACT>(g, m, n, f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]});
-        }
-    }
-    return;
-  }
-  __builtin_amdgcn_s_barrier();
-  char* reg = smem + wave * 16384;
-  {
-    float bias_v[2][4][4];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = min(tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4, g.N - 4);
-        uint2 bb = make_uint2(0, 0);
-        if (g.bias) bb = *reinterpret_cast<const uint2*>(g.bias + n);
-        bias_v[ni][q][0] = bflo(bb.x); bias_v[ni][q][1] = bfhi(bb.x); bias_v[ni][q][2] = bflo(bb.y); bias_v[ni][q][3] = bfhi(bb.y);
-      }
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int row = mi * 32 + fr;
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            v[i] = acc[mi][ni][4 * q + i] * g.alpha + bias_v[ni][q][i];
-            if (ACT) v[i] = apply_act(v[i], ACT);
-          }
-          const int u = ni * 8 + q * 2 + fh;
-          *reinterpret_cast<uint2*>(reg + row * 128 + ((u ^ ((row & 7) << 1)) << 3)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-        }
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  {
-    const int rsub = lane >> 3, c = lane & 7;
-    const int n = tn * BN + wn * 64 + c * 8;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = i * 8 + rsub;
-      const int m = tm * BM + wm * 128 + row;
-      uint4 val = *reinterpret_cast<const uint4*>(reg + row * 128 + ((c ^ (row & 7)) << 4));
-      if (m < g.M && n < g.N) {
-        if (g.res) {
-          const uint4 r = *reinterpret_cast<const uint4*>(g.res + (long)m * g.ldr + n);
-          val.x = pack2bf(bflo(val.x) + bflo(r.x), bfhi(val.x) + bfhi(r.x));
-          val.y = pack2bf(bflo(val.y) + bflo(r.y), bfhi(val.y) + bfhi(r.y));
-          val.z = pack2bf(bflo(val.z) + bflo(r.z), bfhi(val.z) + bfhi(r.z));
-          val.w = pack2bf(bflo(val.w) + bflo(r.w), bfhi(val.w) + bfhi(r.w));
-        }
-        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n) = val;
-      }
-    }
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------------
 // 256x256 "r" variant: the q kernel's stage structure with SIXTEEN waves (4x4, 64x64 per wave, 4 waves per SIMD at <=128 VGPRs):
 // when a wave sits in a DMA issue or at the barrier three others can feed the SIMD's MFMA pipe instead of one.
 // ------------------------------------------------------------------------------------------------
@@ -809,8 +487,14 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256r_kernel(GemmArgs g) {
   constexpr int A_BYTES = BM * BK * 2, STAGE = A_BYTES + BN * BK * 2;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
-  int tm, tn;
-  tile_coords(g, tm, tn);
+  // PERSISTENT over tiles: workgroup b walks tiles b, b + gridDim.x, ... (the launcher gives one workgroup per CU when there are more
+  // tiles than CUs).  The stages of consecutive tiles form ONE stream over the two LDS buffers: the last stage of a tile issues the DMA
+  // of the NEXT tile's first stage, the epilogue stages its output through the buffer the last stage occupied (64 KiB, in two 32-row
+  // passes) while that DMA lands in the other one - a new tile starts with its operands already in LDS instead of behind a workgroup
+  // launch plus one exposed L2 / fabric round trip.
+  const int ntiles = g.tilesM * g.tilesN;
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -820,29 +504,34 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256r_kernel(GemmArgs g) {
   const char* base1 = reinterpret_cast<const char*>(isA ? g.A : g.B);
   const char* base2 = reinterpret_cast<const char*>(isA ? g.A2 : g.B2);
   const long ld1 = isA ? g.lda : g.ldb, ld2 = isA ? g.lda2 : g.ldb2;
-  const int row0 = isA ? tm * BM : tn * BN, rmax = (isA ? g.M : g.N) - 1;
-  unsigned off1[4], off2[4];
+  const int rmax = (isA ? g.M : g.N) - 1;
   const int nk1 = g.K / BK;
+  const int nk = (g.K + g.K2) / BK;  // >= 2 (host guarantees)
+  // global byte offsets of this lane's four DMA rows for tile (tm_, tn_)
+  auto dma_rows = [&](int tm_, int tn_, unsigned (&o1)[4], unsigned (&o2)[4]) {
+    const int row0 = isA ? tm_ * BM : tn_ * BN;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int ridx = (wave & 7) * 4 + j;
-    const int lchunk = (lane & 7) ^ ((((j & 1) << 2) + (lane >> 4)) & 7);
-    int row = min(row0 + ridx * 8 + (lane >> 3), rmax);
-    if (EPI == 1 && !isA) {  // B tile row r = 64*wn + 32*half + i  <-  weight row half*ff + tn*128 + wn*32 + i
-      const int r = ridx * 8 + (lane >> 3);
-      row = ((r >> 5) & 1) * g.ff + tn * 128 + (r >> 6) * 32 + (r & 31);
+    for (int j = 0; j < 4; ++j) {
+      const int ridx = (wave & 7) * 4 + j;
+      const int lchunk = (lane & 7) ^ ((((j & 1) << 2) + (lane >> 4)) & 7);
+      int row = min(row0 + ridx * 8 + (lane >> 3), rmax);
+      if (EPI == 1 && !isA) {  // B tile row r = 64*wn + 32*half + i  <-  weight row half*ff + tn*128 + wn*32 + i
+        const int r = ridx * 8 + (lane >> 3);
+        row = ((r >> 5) & 1) * g.ff + tn_ * 128 + (r >> 6) * 32 + (r & 31);
+      }
+      if (EPI == 3 && !isA && tn_ * BN < g.rope_cols) {  // B tile row r = 64*wn + 32*half + i  <-  head 2*tn + (wn >> 1), dim 64*half + 32*(wn & 1) + i
+        const int r = ridx * 8 + (lane >> 3);
+        row = tn_ * BN + ((r >> 7) << 7) + ((r >> 5) & 1) * 64 + ((r >> 6) & 1) * 32 + (r & 31);
+      }
+      o1[j] = (unsigned)(((long)row * ld1 + lchunk * 8) * 2);
+      o2[j] = g.K2 > 0 ? (unsigned)(((long)row * ld2 + lchunk * 8) * 2) : 0u;
     }
-    if (EPI == 3 && !isA && tn * BN < g.rope_cols) {  // B tile row r = 64*wn + 32*half + i  <-  head 2*tn + (wn >> 1), dim 64*half + 32*(wn & 1) + i
-      const int r = ridx * 8 + (lane >> 3);
-      row = tn * BN + ((r >> 7) << 7) + ((r >> 5) & 1) * 64 + ((r >> 6) & 1) * 32 + (r & 31);
-    }
-    off1[j] = (unsigned)(((long)row * ld1 + lchunk * 8) * 2);
-    off2[j] = g.K2 > 0 ? (unsigned)(((long)row * ld2 + lchunk * 8) * 2) : 0u;
-  }
+  };
   const int dst0 = (isA ? 0 : A_BYTES) + (wave & 7) * 4096;
-  auto issue1 = [&](int kt, int j) {
-    const char* p = kt < nk1 ? base1 + (long)kt * (BK * 2) + off1[j] : base2 + (long)(kt - nk1) * (BK * 2) + off2[j];
-    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + (kt & 1) * STAGE + dst0 + j * 1024), 16, 0, 0);
+  // piece j of k-stage kt of the tile whose row offsets are (o1, o2) -> LDS buffer `buf`
+  auto issue_to = [&](const unsigned (&o1)[4], const unsigned (&o2)[4], int kt, int buf, int j) {
+    const char* p = kt < nk1 ? base1 + (long)kt * (BK * 2) + o1[j] : base2 + (long)(kt - nk1) * (BK * 2) + o2[j];
+    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + buf * STAGE + dst0 + j * 1024), 16, 0, 0);
   };
 
   const int wm = wave >> 2, wn = wave & 3;
@@ -855,218 +544,261 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256r_kernel(GemmArgs g) {
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) koff[kk] = ((kk * 2 + fh) ^ sw) * 16;
 
-  f32x16 acc[2][2];
+  int tm, tn;
+  tile_coords_lin(g, t, ntiles, tm, tn);
+  unsigned off1[4], off2[4];
+  dma_rows(tm, tn, off1, off2);
+  int pb = 0;  // LDS buffer of this tile's stage 0 (stage kt lives in buffer (kt + pb) & 1)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int j = 0; j < 4; ++j) issue_to(off1, off2, 0, 0, j);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   bf16x8 a0[2], b0[2], a1[2], b1[2];
 #define RDQ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 #define MFQ(A_, B_, mi, ni) \
   acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B_[ni], A_[mi], acc[mi][ni], 0, 0, 0); __builtin_amdgcn_sched_barrier(0);
 #define SB __builtin_amdgcn_sched_barrier(0);
-  // one block: 4 MFMAs on (Ac, Bc); behind each: one fragment read of the next block and (NDMA > i) one DMA piece of stage kd
-#define BLOCK(Ac, Bc, An, Bn, aa, ba, RD, kd, d0, NDMA)                                  \
-  MFQ(Ac, Bc, 0, 0) if (RD) RDQ(Bn[0], ba, 0);    if (NDMA > 0) issue1(kd, d0);     SB     \
-  MFQ(Ac, Bc, 0, 1) if (RD) RDQ(Bn[1], ba, 4096); if (NDMA > 1) issue1(kd, d0 + 1); SB     \
-  MFQ(Ac, Bc, 1, 0) if (RD) RDQ(An[0], aa, 0);    if (NDMA > 2) issue1(kd, d0 + 2); SB     \
-  MFQ(Ac, Bc, 1, 1) if (RD) RDQ(An[1], aa, 4096); if (NDMA > 3) issue1(kd, d0 + 3); SB
+  // one block: 4 MFMAs on (Ac, Bc); behind each: one fragment read of the next block and (DMA) one DMA piece, ISS(j) says which
+#define BLOCK(Ac, Bc, An, Bn, aa, ba, RD, DMA)                               \
+  MFQ(Ac, Bc, 0, 0) if (RD) RDQ(Bn[0], ba, 0);    if (DMA) { ISS(0) } SB     \
+  MFQ(Ac, Bc, 0, 1) if (RD) RDQ(Bn[1], ba, 4096); if (DMA) { ISS(1) } SB     \
+  MFQ(Ac, Bc, 1, 0) if (RD) RDQ(An[0], aa, 0);    if (DMA) { ISS(2) } SB     \
+  MFQ(Ac, Bc, 1, 1) if (RD) RDQ(An[1], aa, 4096); if (DMA) { ISS(3) } SB
 
-  const int nk = (g.K + g.K2) / BK;  // >= 2 (host guarantees)
+  for (;;) {
+    const int tnext = t + (int)gridDim.x;
+    const bool has_next = tnext < ntiles;  // workgroup-uniform
+    f32x16 acc[2][2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) issue1(0, j);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) issue1(1, j);
-  {
-    const unsigned aa = a_base + koff[0], ba = b_base + koff[0];
-    RDQ(b0[0], ba, 0); RDQ(b0[1], ba, 4096); RDQ(a0[0], aa, 0); RDQ(a0[1], aa, 4096);
-  }
-  lds_wait4(a0, b0);
-  { const unsigned aa = a_base + koff[1], ba = b_base + koff[1]; BLOCK(a0, b0, a1, b1, aa, ba, true, 0, 0, 0) }
-  lds_wait4(a1, b1);
-  { const unsigned aa = a_base + koff[2], ba = b_base + koff[2]; BLOCK(a1, b1, a0, b0, aa, ba, true, 0, 0, 0) }
-  lds_wait4(a0, b0);
-  { const unsigned aa = a_base + koff[3], ba = b_base + koff[3]; BLOCK(a0, b0, a1, b1, aa, ba, true, 0, 0, 0) }
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto stage = [&](auto dma_c, int kt) {
-    constexpr bool DMA = decltype(dma_c)::value;
-    const unsigned so = (kt & 1) * STAGE;
-    lds_wait4(a1, b1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // stage 0 of this tile is in LDS buffer pb (own pieces waited for; the barrier publishes everybody's and ends the previous tile's
+    // epilogue reads of the other buffer, which now takes stage 1)
     __builtin_amdgcn_s_barrier();
-    { const unsigned aa = a_base + so + koff[0], ba = b_base + so + koff[0]; BLOCK(a1, b1, a0, b0, aa, ba, true, kt + 1, 0, (DMA ? 4 : 0)) }
-    lds_wait4(a0, b0);
-    { const unsigned aa = a_base + so + koff[1], ba = b_base + so + koff[1]; BLOCK(a0, b0, a1, b1, aa, ba, true, 0, 0, 0) }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue_to(off1, off2, 1, pb ^ 1, j);
+    {
+      const unsigned so = pb * STAGE;
+      {
+        const unsigned aa = a_base + so + koff[0], ba = b_base + so + koff[0];
+        RDQ(b0[0], ba, 0); RDQ(b0[1], ba, 4096); RDQ(a0[0], aa, 0); RDQ(a0[1], aa, 4096);
+      }
+#define ISS(j)
+      lds_wait4(a0, b0);
+      { const unsigned aa = a_base + so + koff[1], ba = b_base + so + koff[1]; BLOCK(a0, b0, a1, b1, aa, ba, true, false) }
+      lds_wait4(a1, b1);
+      { const unsigned aa = a_base + so + koff[2], ba = b_base + so + koff[2]; BLOCK(a1, b1, a0, b0, aa, ba, true, false) }
+      lds_wait4(a0, b0);
+      { const unsigned aa = a_base + so + koff[3], ba = b_base + so + koff[3]; BLOCK(a0, b0, a1, b1, aa, ba, true, false) }
+#undef ISS
+    }
+
+    // a stage: finish the previous stage's last k-block while the first fragments of stage kt are read and (first block) the DMA of
+    // the following stage is issued into the buffer the barrier has just freed
+#define STAGE_BODY(kt, DMA)                                                                                                         \
+    {                                                                                                                               \
+      const unsigned so = (((kt) + pb) & 1) * STAGE;                                                                                \
+      lds_wait4(a1, b1);                                                                                                            \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                              \
+      __builtin_amdgcn_s_barrier();                                                                                                 \
+      { const unsigned aa = a_base + so + koff[0], ba = b_base + so + koff[0]; BLOCK(a1, b1, a0, b0, aa, ba, true, DMA) }           \
+      lds_wait4(a0, b0);                                                                                                            \
+      { const unsigned aa = a_base + so + koff[1], ba = b_base + so + koff[1]; BLOCK(a0, b0, a1, b1, aa, ba, true, false) }         \
+      lds_wait4(a1, b1);                                                                                                            \
+      { const unsigned aa = a_base + so + koff[2], ba = b_base + so + koff[2]; BLOCK(a1, b1, a0, b0, aa, ba, true, false) }         \
+      lds_wait4(a0, b0);                                                                                                            \
+      { const unsigned aa = a_base + so + koff[3], ba = b_base + so + koff[3]; BLOCK(a0, b0, a1, b1, aa, ba, true, false) }         \
+    }
+#define ISS(j) issue_to(off1, off2, kt + 1, (kt + 1 + pb) & 1, j);
+    for (int kt = 1; kt < nk - 1; ++kt) STAGE_BODY(kt, true)
+#undef ISS
+    int ntm = 0, ntn = 0;
+    if (has_next) {  // this tile's DMA rows are not needed any more (its last stage is in flight): the offsets become the next tile's
+      tile_coords_lin(g, tnext, ntiles, ntm, ntn);
+      dma_rows(ntm, ntn, off1, off2);
+    }
+    // last stage of the tile: the freed buffer takes stage 0 of the NEXT tile
+#define ISS(j) if (has_next) issue_to(off1, off2, 0, (nk + pb) & 1, j);
+    STAGE_BODY(nk - 1, true)
+#undef ISS
+#define ISS(j)
     lds_wait4(a1, b1);
-    { const unsigned aa = a_base + so + koff[2], ba = b_base + so + koff[2]; BLOCK(a1, b1, a0, b0, aa, ba, true, 0, 0, 0) }
-    lds_wait4(a0, b0);
-    { const unsigned aa = a_base + so + koff[3], ba = b_base + so + koff[3]; BLOCK(a0, b0, a1, b1, aa, ba, true, 0, 0, 0) }
-  };
-  for (int kt = 1; kt < nk - 1; ++kt) stage(std::true_type{}, kt);
-  stage(std::false_type{}, nk - 1);
-  lds_wait4(a1, b1);
-  { BLOCK(a1, b1, a0, b0, a_base, b_base, false, 0, 0, 0) }
+    { BLOCK(a1, b1, a0, b0, a_base, b_base, false, false) }
+#undef ISS
+#undef STAGE_BODY
+
+    if (g.out_f32) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int m = tm * BM + wm * 64 + mi * 32 + fr;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n = tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4;
+            if (n >= g.N) continue;
+            store4<ACT>(g, m, n, f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]});
+          }
+      }
+    } else {
+      __builtin_amdgcn_s_barrier();  // every wave has read its last fragments: the last stage's buffer becomes the staging area
+      char* reg = smem + ((nk - 1 + pb) & 1) * STAGE + wave * 4096;  // [32 rows][64 cols] bf16, wave private, one pass per mi
+      const bool rope_tile = EPI == 3 && tn * BN < g.rope_cols;
+      const int rsub = lane >> 3, c = lane & 7;
+      // EPI 1: chunks 0-3 are gate columns, 4-7 the matching up columns of the [M, 2*ff] output
+      const int n = EPI == 1   ? (c < 4 ? 0 : g.ff) + tn * 128 + wn * 32 + (c & 3) * 8
+                    : rope_tile ? tn * BN + (wn >> 1) * 128 + (c < 4 ? 0 : 64) + (wn & 1) * 32 + (c & 3) * 8
+                                : tn * BN + wn * 64 + c * 8;
+      const int nlim = EPI == 2 ? g.ff : g.N;
+      const bool col_ok = n < nlim;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int row = fr;  // row inside this 32-row pass
+        // the operands this pass reads back from HBM (saved gate / up for EPI 2, the residual for EPI 0) are requested for all four row
+        // groups up front: C may alias them (d(gate|up) overwrites gate|up in place, x += ...), so the compiler must keep every load
+        // behind the previous group's store and the round trips would otherwise run one after the other
+        uint4 pre_a[4], pre_b[4];
+        if (EPI == 2 || (EPI == 0 && g.res)) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int m = tm * BM + wm * 64 + mi * 32 + i * 8 + rsub;
+            pre_a[i] = make_uint4(0, 0, 0, 0); pre_b[i] = make_uint4(0, 0, 0, 0);
+            if (m < g.M && col_ok) {
+              if (EPI == 2) {
+                pre_a[i] = *reinterpret_cast<const uint4*>(g.aux + (long)m * g.ld_aux + n);
+                pre_b[i] = *reinterpret_cast<const uint4*>(g.aux + (long)m * g.ld_aux + g.ff + n);
+              } else {
+                pre_a[i] = *reinterpret_cast<const uint4*>(g.res + (long)m * g.ldr + n);
+              }
+            }
+          }
+        }
+        if (rope_tile) {
+          // acc[mi][0] holds dims d = 32*(wn & 1) + j of the head, acc[mi][1] their rotate_half partners d + 64: rotate the bf16-rounded
+          // projections exactly like the stand-alone rope kernel does on the stored q / k rows
+          const int pos = (tm * BM + wm * 64 + mi * 32 + row) % g.rope_mod + g.rope_pos0;
+          const float* cs = g.rope_cos + (long)pos * 64 + (wn & 1) * 32 + fh * 4;
+          const float* sn = g.rope_sin + (long)pos * 64 + (wn & 1) * 32 + fh * 4;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 c4 = *reinterpret_cast<const float4*>(cs + q * 8), s4 = *reinterpret_cast<const float4*>(sn + q * 8);
+            const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w};
+            float o1[4], o2[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              rope_pair(bf2f(f2bf(acc[mi][0][4 * q + i] * g.alpha)), bf2f(f2bf(acc[mi][1][4 * q + i] * g.alpha)), cv[i], sv[i], o1[i], o2[i]);
+            const int u = q * 2 + fh;
+            *reinterpret_cast<uint2*>(reg + row * 128 + ((u ^ ((row & 7) << 1)) << 3)) = make_uint2(pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3]));
+            *reinterpret_cast<uint2*>(reg + row * 128 + (((8 + u) ^ ((row & 7) << 1)) << 3)) = make_uint2(pack2bf(o2[0], o2[1]), pack2bf(o2[2], o2[3]));
+          }
+        } else {
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float v[4];
+              uint2 bb = make_uint2(0, 0);
+              if (EPI == 0 && g.bias) bb = *reinterpret_cast<const uint2*>(g.bias + min(tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4, g.N - 4));
+              const float bias_v[4] = {bflo(bb.x), bfhi(bb.x), bflo(bb.y), bfhi(bb.y)};
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                v[i] = acc[mi][ni][4 * q + i] * g.alpha;
+                if (EPI == 0 && g.drop_thresh) {
+                  const long e = (long)(tm * BM + wm * 64 + mi * 32 + row) * g.N + tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4 + i;
+                  v[i] = drop_keep(g.drop_seed, e, g.drop_thresh) ? v[i] * g.drop_scale : 0.f;
+                }
+                v[i] += bias_v[i];
+                if (ACT) v[i] = apply_act(v[i], ACT);
+              }
+              const int u = ni * 8 + q * 2 + fh;
+              *reinterpret_cast<uint2*>(reg + row * 128 + ((u ^ ((row & 7) << 1)) << 3)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+            }
+        }
+        // own staging rows written; the next tile's stage-0 pieces and the read-back operands have landed long ago (issued a whole stage
+        // earlier): waiting for them HERE, in front of the first global store, keeps the stores out of every later vmcnt wait
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r32 = i * 8 + rsub;
+          const int m = tm * BM + wm * 64 + mi * 32 + r32;
+          uint4 val = *reinterpret_cast<const uint4*>(reg + r32 * 128 + ((c ^ (r32 & 7)) << 4));
+          if (m < g.M && col_ok) {
+            if (EPI == 2) {  // val = d_act (bf16-rounded like the unfused path): d(gate), d(up) from the saved gate|up
+              const uint4 gq = pre_a[i], uq = pre_b[i];
+              float d[8], gg[8], uu[8], dg[8], du[8];
+              unpack8(val, d); unpack8(gq, gg); unpack8(uq, uu);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float sg = 1.f / (1.f + __expf(-gg[e]));
+                du[e] = d[e] * gg[e] * sg;
+                dg[e] = d[e] * uu[e] * sg * (1.f + gg[e] * (1.f - sg));
+              }
+              bf16_t* out = reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n;
+              *reinterpret_cast<uint4*>(out) = pack8(dg);
+              *reinterpret_cast<uint4*>(out + g.ff) = pack8(du);
+              continue;
+            }
+            if (EPI == 0 && g.res) {
+              const uint4 r = pre_a[i];
+              val.x = pack2bf(bflo(val.x) + bflo(r.x), bfhi(val.x) + bfhi(r.x));
+              val.y = pack2bf(bflo(val.y) + bflo(r.y), bfhi(val.y) + bfhi(r.y));
+              val.z = pack2bf(bflo(val.z) + bflo(r.z), bfhi(val.z) + bfhi(r.z));
+              val.w = pack2bf(bflo(val.w) + bflo(r.w), bfhi(val.w) + bfhi(r.w));
+            }
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n) = val;
+          }
+        }
+      }
+      if (EPI == 1) {
+        // second output: act = silu(gate) * up on the bf16-rounded gate / up (what the unfused kernel reads back), staged [64][32]
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int row = mi * 32 + fr;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float gv = bf2f(f2bf(acc[mi][0][4 * q + i] * g.alpha)), uv = bf2f(f2bf(acc[mi][1][4 * q + i] * g.alpha));
+              v[i] = silu(gv) * uv;
+            }
+            const int u = q * 2 + fh;  // 8-byte unit 0..7 of the 64-byte row
+            *reinterpret_cast<uint2*>(reg + row * 64 + ((u ^ ((row & 3) << 1)) << 3)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int rsub4 = lane >> 2, c4 = lane & 3;
+        const int n2 = tn * 128 + wn * 32 + c4 * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = i * 16 + rsub4;
+          const int m = tm * BM + wm * 64 + row;
+          const uint4 val = *reinterpret_cast<const uint4*>(reg + row * 64 + ((c4 ^ (row & 3)) << 4));
+          if (m < g.M) *reinterpret_cast<uint4*>(g.aux_out + (long)m * g.ld_aux + n2) = val;
+        }
+      }
+    }
+    if (!has_next) break;
+    if (g.out_f32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no staged epilogue ran: the next tile's stage-0 pieces are awaited here
+    t = tnext; tm = ntm; tn = ntn;
+    pb = (pb + nk) & 1;
+  }
 #undef BLOCK
 #undef SB
 #undef MFQ
 #undef RDQ
-
-  if (g.out_f32) {
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int m = tm * BM + wm * 64 + mi * 32 + fr;
-      if (m >= g.M) continue;
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4;
-          if (n >= g.N) continue;
-          store4<ACT>(g, m, n, f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]});
-        }
-    }
-    return;
-  }
-  __builtin_amdgcn_s_barrier();
-  char* reg = smem + wave * 8192;  // [64 rows][64 cols] bf16, wave private
-  const bool rope_tile = EPI == 3 && tn * BN < g.rope_cols;
-  if (rope_tile) {
-    // acc[mi][0] holds dims d = 32*(wn & 1) + j of the head, acc[mi][1] their rotate_half partners d + 64: rotate the bf16-rounded
-    // projections exactly like the stand-alone rope kernel does on the stored q / k rows
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int row = mi * 32 + fr;
-      const int pos = (tm * BM + wm * 64 + row) % g.rope_mod + g.rope_pos0;
-      const float* cs = g.rope_cos + (long)pos * 64 + (wn & 1) * 32 + fh * 4;
-      const float* sn = g.rope_sin + (long)pos * 64 + (wn & 1) * 32 + fh * 4;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 c4 = *reinterpret_cast<const float4*>(cs + q * 8), s4 = *reinterpret_cast<const float4*>(sn + q * 8);
-        const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w};
-        float o1[4], o2[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          rope_pair(bf2f(f2bf(acc[mi][0][4 * q + i] * g.alpha)), bf2f(f2bf(acc[mi][1][4 * q + i] * g.alpha)), cv[i], sv[i], o1[i], o2[i]);
-        const int u = q * 2 + fh;
-        *reinterpret_cast<uint2*>(reg + row * 128 + ((u ^ ((row & 7) << 1)) << 3)) = make_uint2(pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3]));
-        *reinterpret_cast<uint2*>(reg + row * 128 + (((8 + u) ^ ((row & 7) << 1)) << 3)) = make_uint2(pack2bf(o2[0], o2[1]), pack2bf(o2[2], o2[3]));
-      }
-    }
-  } else {
-    float bias_v[2][4][4];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = min(tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4, g.N - 4);
-        uint2 bb = make_uint2(0, 0);
-        if (EPI == 0 && g.bias) bb = *reinterpret_cast<const uint2*>(g.bias + n);
-        bias_v[ni][q][0] = bflo(bb.x); bias_v[ni][q][1] = bfhi(bb.x); bias_v[ni][q][2] = bflo(bb.y); bias_v[ni][q][3] = bfhi(bb.y);
-      }
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int row = mi * 32 + fr;
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            v[i] = acc[mi][ni][4 * q + i] * g.alpha;
-            if (EPI == 0 && g.drop_thresh) {
-              const long e = (long)(tm * BM + wm * 64 + row) * g.N + tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4 + i;
-              v[i] = drop_keep(g.drop_seed, e, g.drop_thresh) ? v[i] * g.drop_scale : 0.f;
-            }
-            v[i] += bias_v[ni][q][i];
-            if (ACT) v[i] = apply_act(v[i], ACT);
-          }
-          const int u = ni * 8 + q * 2 + fh;
-          *reinterpret_cast<uint2*>(reg + row * 128 + ((u ^ ((row & 7) << 1)) << 3)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-        }
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  {
-    const int rsub = lane >> 3, c = lane & 7;
-    // EPI 1: chunks 0-3 are gate columns, 4-7 the matching up columns of the [M, 2*ff] output
-    const int n = EPI == 1   ? (c < 4 ? 0 : g.ff) + tn * 128 + wn * 32 + (c & 3) * 8
-                  : rope_tile ? tn * BN + (wn >> 1) * 128 + (c < 4 ? 0 : 64) + (wn & 1) * 32 + (c & 3) * 8
-                              : tn * BN + wn * 64 + c * 8;
-    const int nlim = EPI == 2 ? g.ff : g.N;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = i * 8 + rsub;
-      const int m = tm * BM + wm * 64 + row;
-      uint4 val = *reinterpret_cast<const uint4*>(reg + row * 128 + ((c ^ (row & 7)) << 4));
-      if (m < g.M && n < nlim) {
-        if (EPI == 2) {  // val = d_act (bf16-rounded like the unfused path): d(gate), d(up) from the saved gate|up
-          const uint4 gq = *reinterpret_cast<const uint4*>(g.aux + (long)m * g.ld_aux + n);
-          const uint4 uq = *reinterpret_cast<const uint4*>(g.aux + (long)m * g.ld_aux + g.ff + n);
-          float d[8], gg[8], uu[8], dg[8], du[8];
-          unpack8(val, d); unpack8(gq, gg); unpack8(uq, uu);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float sg = 1.f / (1.f + __expf(-gg[e]));
-            du[e] = d[e] * gg[e] * sg;
-            dg[e] = d[e] * uu[e] * sg * (1.f + gg[e] * (1.f - sg));
-          }
-          bf16_t* out = reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n;
-          *reinterpret_cast<uint4*>(out) = pack8(dg);
-          *reinterpret_cast<uint4*>(out + g.ff) = pack8(du);
-          continue;
-        }
-        if (EPI == 0 && g.res) {
-          const uint4 r = *reinterpret_cast<const uint4*>(g.res + (long)m * g.ldr + n);
-          val.x = pack2bf(bflo(val.x) + bflo(r.x), bfhi(val.x) + bfhi(r.x));
-          val.y = pack2bf(bflo(val.y) + bflo(r.y), bfhi(val.y) + bfhi(r.y));
-          val.z = pack2bf(bflo(val.z) + bflo(r.z), bfhi(val.z) + bfhi(r.z));
-          val.w = pack2bf(bflo(val.w) + bflo(r.w), bfhi(val.w) + bfhi(r.w));
-        }
-        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n) = val;
-      }
-    }
-  }
-  if (EPI == 1) {
-    // second pass: act = silu(gate) * up on the bf16-rounded gate / up (what the unfused kernel reads back), staged [64][32]
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int row = mi * 32 + fr;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float gv = bf2f(f2bf(acc[mi][0][4 * q + i] * g.alpha)), uv = bf2f(f2bf(acc[mi][1][4 * q + i] * g.alpha));
-          v[i] = silu(gv) * uv;
-        }
-        const int u = q * 2 + fh;  // 8-byte unit 0..7 of the 64-byte row
-        *reinterpret_cast<uint2*>(reg + row * 64 + ((u ^ ((row & 3) << 1)) << 3)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int rsub = lane >> 2, c = lane & 3;
-    const int n = tn * 128 + wn * 32 + c * 8;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = i * 16 + rsub;
-      const int m = tm * BM + wm * 64 + row;
-      const uint4 val = *reinterpret_cast<const uint4*>(reg + row * 64 + ((c ^ (row & 3)) << 4));
-      if (m < g.M) *reinterpret_cast<uint4*>(g.aux_out + (long)m * g.ld_aux + n) = val;
-    }
-  }
 }
 
 
 // ------------------------------------------------------------------------------------------------
 // e4m3 x e4m3 -> bf16 GEMM for FROZEN base weights in 8-bit (the reference trains stages 2/3 with `bits: 8` base weights,
 // lhrs/models/text_modal.py:91-131 -> bitsandbytes LLM.int8): C[m][n] = sa[m] * sb[n] * sum_k A8[m][k] * B8[n][k]
-// (+ residual).  Same skeleton as gemm_nt_256q_kernel - 256x256 tile, 8 waves, two 64 KiB LDS buffers filled by global_load_lds,
+// (+ residual).  Same skeleton as the bf16 256x256 kernels - 256x256 tile, 8 waves, two 64 KiB LDS buffers filled by global_load_lds,
 // one barrier per stage - but a stage row is 128 BYTES = 128 k and the product runs on v_mfma_scale_f32_32x32x64_f8f6f4 with unit
 // block scales (the only 2x-rate fp8 MFMA of gfx950): a stage is two blocks of 8 MFMAs (64 k each, 16 passes), every lane feeds
 // 32 consecutive k-bytes of its row (two ds_read_b128) to both operands.  Twice the FLOPs of the bf16 kernel per byte moved.
@@ -1381,10 +1113,26 @@ extern "C" int lhrs_gemm_profile_read_kinds(double* out) {
 }
 
 static int g_gemm_allow_256 = 2;
+// the 16-wave 256x256 kernel walks its tiles PERSISTENTLY: at most one workgroup per CU (128 KiB of LDS each: only one fits anyway),
+// workgroup b takes tiles b, b + grid, ...  0 = one workgroup per tile (kernel A/B tests: lhrs_gemm_set_persistent)
+static int g_gemm_persist = 1;
+extern "C" int lhrs_gemm_set_persistent(int on) { g_gemm_persist = on; return 0; }
+static int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) n = 256;
+    else n = prop.multiProcessorCount;
+  }
+  return n;
+}
+static dim3 grid_256r(long tiles) { return dim3((unsigned)(g_gemm_persist ? (tiles < num_cus() ? tiles : num_cus()) : tiles)); }
 static int g_gemm_min256 = 128;  // fewest 256x256 tiles (half a round of the 256 CUs) for which the big-tile kernels are chosen: 2184 x 4096 (144
                                  // tiles, the reference's micro-batch 8) runs 20 % faster there than on 576 small tiles; A/B: lhrs_gemm_set_min_tiles
 extern "C" int lhrs_gemm_set_min_tiles(int n) { g_gemm_min256 = n; return 0; }
-// tile policy switch for A/B measurements: 0 = never use a 256x256 kernel, 1 = simple ring kernel, 2 = pipelined (default)
+// tile policy switch for A/B measurements: 0 = never a 256x256 kernel, 2 = default (16-wave BK=64 kernel when K % 64 == 0, else the BK=32
+// ring kernel), 4 = always the BK=32 ring kernel
 extern "C" int lhrs_gemm_set_policy(int allow_256) { g_gemm_allow_256 = allow_256; return 0; }
 
 // C ABI ------------------------------------------------------------------------------------------
@@ -1463,7 +1211,7 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
   const bool al16 = out_f32 || (N % 8 == 0 && ldc % 8 == 0 && (residual == nullptr || ldr % 8 == 0));  // 16-B epilogue rows
   bool use256 = g_gemm_allow_256 && t256 >= g_gemm_min256 && K >= 96 && K % 32 == 0 && al16;  // ring prologue needs >= 3 stages
-  if (g.drop_thresh && !((g_gemm_allow_256 == 2 || g_gemm_allow_256 == 5) && K % 64 == 0 && K >= 128)) use256 = false;  // the mask lives in the r kernel and in store4
+  if (g.drop_thresh && !(g_gemm_allow_256 == 2 && K % 64 == 0 && K >= 128)) use256 = false;  // the mask lives in the r kernel and in store4
   if (K2 > 0 && !use256) {  // small problems: base GEMM, then the rank-K2 update accumulated on top of it
     if (gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, out_f32, accumulate, alpha, nullptr, 0, nullptr, 0, 0, stream))
       return -1;
@@ -1475,7 +1223,7 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   // much as a full one (M = 8736, N = 4096: 560 tiles = 2.19 rounds -> 3).  When the tile rows that spill over the last full round
   // are cheaper as a separate small-tile launch (~2.5x the time per FLOP, but no idle CUs), the row range is cut there: whole
   // 256-row tile rows for the 16-wave kernel, the remaining rows for the 64x128 / 128x128 kernel.  Disjoint rows of C, no partials.
-  if (use256 && t_split_ok && g_gemm_tail_split && (g_gemm_allow_256 == 2 || g_gemm_allow_256 == 5) && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128 &&
+  if (use256 && t_split_ok && g_gemm_tail_split && g_gemm_allow_256 == 2 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128 &&
       !g.drop_thresh) {
     const int tm = cdiv(M, 256), tn = cdiv(N, 256);
     const long T = (long)tm * tn, rounds = (T + 255) / 256, full = T / 256;
@@ -1501,7 +1249,7 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   int slot = -1;
   if (g_prof.on) {
     g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * (K + K2);
-    const bool dominant = use256 && (g_gemm_allow_256 == 2 || g_gemm_allow_256 == 5) && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128;
+    const bool dominant = use256 && g_gemm_allow_256 == 2 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128;
     if (dominant && g_prof.used < g_prof.cap) {  // time exactly the launches rocprof lists as gemm_nt_256r_kernel<ACT, 0>
       slot = g_prof.used++;
       g_prof.flops[slot] = 2.0 * M * N * (K + K2);
@@ -1512,27 +1260,13 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   if (use256) {
     g.tilesM = cdiv(M, 256); g.tilesN = cdiv(N, 256);
     const dim3 grid(g.tilesM * g.tilesN), blk(512);
-    if ((g_gemm_allow_256 == 2 || g_gemm_allow_256 == 5) && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128) {
-      const dim3 blk16(1024);
+    if (g_gemm_allow_256 == 2 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128) {
+      const dim3 blk16(1024), grid16 = grid_256r((long)g.tilesM * g.tilesN);
       switch (act) {
-        case 0: hipLaunchKernelGGL((gemm_nt_256r_kernel<0>), grid, blk16, 0, s, g); break;
-        case 1: hipLaunchKernelGGL((gemm_nt_256r_kernel<1>), grid, blk16, 0, s, g); break;
-        case 2: hipLaunchKernelGGL((gemm_nt_256r_kernel<2>), grid, blk16, 0, s, g); break;
-        default: hipLaunchKernelGGL((gemm_nt_256r_kernel<3>), grid, blk16, 0, s, g); break;
-      }
-    } else if (g_gemm_allow_256 == 3 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128) {
-      switch (act) {
-        case 0: hipLaunchKernelGGL((gemm_nt_256q_kernel<0>), grid, blk, 0, s, g); break;
-        case 1: hipLaunchKernelGGL((gemm_nt_256q_kernel<1>), grid, blk, 0, s, g); break;
-        case 2: hipLaunchKernelGGL((gemm_nt_256q_kernel<2>), grid, blk, 0, s, g); break;
-        default: hipLaunchKernelGGL((gemm_nt_256q_kernel<3>), grid, blk, 0, s, g); break;
-      }
-    } else if (g_gemm_allow_256 == 1) {
-      switch (act) {
-        case 0: hipLaunchKernelGGL((gemm_nt_256_kernel<0>), grid, blk, 0, s, g); break;
-        case 1: hipLaunchKernelGGL((gemm_nt_256_kernel<1>), grid, blk, 0, s, g); break;
-        case 2: hipLaunchKernelGGL((gemm_nt_256_kernel<2>), grid, blk, 0, s, g); break;
-        default: hipLaunchKernelGGL((gemm_nt_256_kernel<3>), grid, blk, 0, s, g); break;
+        case 0: hipLaunchKernelGGL((gemm_nt_256r_kernel<0>), grid16, blk16, 0, s, g); break;
+        case 1: hipLaunchKernelGGL((gemm_nt_256r_kernel<1>), grid16, blk16, 0, s, g); break;
+        case 2: hipLaunchKernelGGL((gemm_nt_256r_kernel<2>), grid16, blk16, 0, s, g); break;
+        default: hipLaunchKernelGGL((gemm_nt_256r_kernel<3>), grid16, blk16, 0, s, g); break;
       }
     } else {
       switch (act) {
@@ -1563,7 +1297,7 @@ extern "C" int lhrs_rope(void* x, long ld, int rows, int nheads, int D, const fl
                          int pos0, int inverse, void* stream);
 
 static bool swiglu_fusable(long tiles, int ff, int K, int K2, int lda, int ldb) {
-  return (g_gemm_allow_256 == 2 || g_gemm_allow_256 == 5) && ff % 256 == 0 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128 && tiles >= g_gemm_min256 &&
+  return g_gemm_allow_256 == 2 && ff % 256 == 0 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128 && tiles >= g_gemm_min256 &&
          lda % 8 == 0 && ldb % 8 == 0;
 }
 // 1 when lhrs_gemm_swiglu_fwd / _bwd will take the fused kernel for this problem (dense operands), else 0 (they fall back)
@@ -1603,7 +1337,7 @@ extern "C" int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int
   g.tilesM = cdiv(M, 256); g.tilesN = ff / 128;
   hipStream_t s = (hipStream_t)stream;
   const int pslot = prof_count(M, 2 * ff, K + K2, 1, s);
-  hipLaunchKernelGGL((gemm_nt_256r_kernel<0, 1>), dim3(g.tilesM * g.tilesN), dim3(1024), 0, s, g);
+  hipLaunchKernelGGL((gemm_nt_256r_kernel<0, 1>), grid_256r((long)g.tilesM * g.tilesN), dim3(1024), 0, s, g);
   prof_end(pslot, s);
   LHRS_CHECK_LAUNCH("gemm_swiglu_fwd");
   return 0;
@@ -1620,7 +1354,7 @@ extern "C" int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw
                    cos_t && sin_t && ldc % 8 == 0,
                "gemm_rope_fwd: M=%d N=%d K=%d rope_cols=%d head_dim=%d pos_mod=%d", M, N, K, rope_cols, head_dim, pos_mod);
   const long tiles = (long)cdiv(M, 256) * cdiv(N, 256);
-  const bool fused = (g_gemm_allow_256 == 2 || g_gemm_allow_256 == 5) && head_dim == 128 && rope_cols % 256 == 0 && N % 8 == 0 && K % 64 == 0 &&
+  const bool fused = g_gemm_allow_256 == 2 && head_dim == 128 && rope_cols % 256 == 0 && N % 8 == 0 && K % 64 == 0 &&
                      K2 % 64 == 0 && K + K2 >= 128 && tiles >= g_gemm_min256 && ldx % 8 == 0 && ldw % 8 == 0;
   if (!fused) {
     if (gemm_launch(X, ldx, W, ldw, C, ldc, M, N, K, nullptr, nullptr, 0, 0, 0, 0, 1.f, A2, lda2, B2, ldb2, K2, stream)) return -1;
@@ -1633,7 +1367,7 @@ extern "C" int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw
   g.epi = 3; g.rope_cos = cos_t; g.rope_sin = sin_t; g.rope_mod = pos_mod; g.rope_pos0 = pos0; g.rope_cols = rope_cols;
   g.tilesM = cdiv(M, 256); g.tilesN = cdiv(N, 256);
   const int pslot = prof_count(M, N, K + K2, 3, (hipStream_t)stream);
-  hipLaunchKernelGGL((gemm_nt_256r_kernel<0, 3>), dim3(g.tilesM * g.tilesN), dim3(1024), 0, (hipStream_t)stream, g);
+  hipLaunchKernelGGL((gemm_nt_256r_kernel<0, 3>), grid_256r((long)g.tilesM * g.tilesN), dim3(1024), 0, (hipStream_t)stream, g);
   prof_end(pslot, (hipStream_t)stream);
   LHRS_CHECK_LAUNCH("gemm_rope_fwd");
   return 0;
@@ -1654,7 +1388,7 @@ extern "C" int lhrs_gemm_swiglu_bwd(const void* dY, int ldy, const void* WdT, in
   g.tilesM = cdiv(M, 256); g.tilesN = cdiv(ff, 256);
   hipStream_t s = (hipStream_t)stream;
   const int pslot = prof_count(M, ff, K + K2, 2, s);
-  hipLaunchKernelGGL((gemm_nt_256r_kernel<0, 2>), dim3(g.tilesM * g.tilesN), dim3(1024), 0, s, g);
+  hipLaunchKernelGGL((gemm_nt_256r_kernel<0, 2>), grid_256r((long)g.tilesM * g.tilesN), dim3(1024), 0, s, g);
   prof_end(pslot, s);
   LHRS_CHECK_LAUNCH("gemm_swiglu_bwd");
   return 0;

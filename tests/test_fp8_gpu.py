@@ -161,8 +161,6 @@ def test_e4m3_base_against_the_llm_int8_oracle():
     targets = ("q", "k", "v", "o")
     model, lora, P, batch = make(targets, 8, False)
     model.text.quantize_base(8)
-    model.eval()        # stage 3: text.eval() -> lora_dropout off
-    model.training = True
     loss_hip = model(batch)["total_loss"].item()
     model.text.backward(need_input_grad=False)
     torch.cuda.synchronize()
