@@ -185,7 +185,12 @@ class LHRSEngine:
         self.world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(self.pg)
-        self.reducers = {st.name: GradReducer(st.grad, st.buckets, self.pg, comm_dtype) for st in self.stores} if self.world > 1 else {}
+        # LHRS_DP_SINGLE_RANK=1 (tools/dp_overlap_trace.py): keep the bucketed reducer on a 1-rank RCCL group, so the comm stream and its
+        # overlap with the pooler backward can be traced on a 1-GPU box; the numbers a rank ends with do not change (sum over one rank)
+        import os
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        with_reducer = self.world > 1 or (dist_on and os.environ.get("LHRS_DP_SINGLE_RANK") == "1")
+        self.reducers = {st.name: GradReducer(st.grad, st.buckets, self.pg, comm_dtype) for st in self.stores} if with_reducer else {}
         if self.world > 1:
             self.sync_replicas(broadcast_trainable)
 
