@@ -11,8 +11,7 @@ crosses PCIe; a worker never touches the GPU.
 
 Directory contract (unchanged): `<root>/<NAME>_Image/` holds the pictures of corpus NAME and `<root>/<NAME>.json` its annotations;
 the annotation schema is chosen by NAME exactly as the reference does (table `_CAPTION_SCHEMAS` / `_instruct_item`).
-The webdataset (RS5M tar shards) and weighted multi-task (`weight_sample: True`) loaders need `webdataset` / private corpora and are
-not built (NotImplementedError with the reason), see DESIGN.md §7.
+The webdataset loader (RS5M tar shards) needs `webdataset`, which the image lacks: not built (NotImplementedError with the reason).
 """
 from __future__ import annotations
 
@@ -246,7 +245,63 @@ class InstructDataset(CaptionDataset):
         return out
 
 
+class InstructDatasetWithTaskId(InstructDataset):
+    """Stage-3 mixture (`weight_sample: True` in Config/multi_modal_stage3.yaml; cap_dataset.py:489-577): every sample carries the sampling
+    weight of its corpus (first WEIGHT_DICT key found in the annotation file's name, else 0.5); text-only instruction corpora
+    (`<root>/*text.json` whose name contains "geosignal": records {instruction, input, output}) are appended AFTER the image samples - they
+    have no picture (`load_image` gives zeros, `valid_image` False) and no image token.  Unlike its parent it only ADDS the image token to
+    a first question that lacks it; later turns are left alone."""
+
+    WEIGHT_DICT = {"OSM": 0.6, "LLAVA": 1.0, "geosignal": 0.50, "RSITMD": 0.6, "NWPU": 0.6, "DOTA": 0.9, "FAST": 1.0}
+
+    def __init__(self, **kwargs):
+        self.sample_weight: List[float] = []
+        super().__init__(**kwargs)
+
+    def load_dataset(self):
+        before = 0
+        for img_dir, ann in zip(self.img_dir, self.json_dir):
+            n0 = len(self.img_list)
+            self.img_dir, self.json_dir, keep = [img_dir], [ann], (self.img_dir, self.json_dir)
+            try:
+                super().load_dataset()  # one corpus at a time: same records, same `random.sample` draws, in the same order
+            finally:
+                self.img_dir, self.json_dir = keep
+            w = next((wt for key, wt in self.WEIGHT_DICT.items() if key in ann.stem), 0.5)
+            self.sample_weight += [w] * (len(self.img_list) - n0)
+            before = n0
+        del before
+
+    def post_process(self):
+        for i, conv in enumerate(self.cap_list):
+            conv = conv if isinstance(conv, list) else [conv]
+            if DEFAULT_IMAGE_TOKEN not in conv[0]["Question"]:
+                conv[0]["Question"] = DEFAULT_IMAGE_TOKEN + conv[0]["Question"]
+            self.cap_list[i] = conv
+        self.txt_json_dir = [f for f in self.root.glob("*text.json") if f not in self.json_dir]
+        for f in self.txt_json_dir:
+            if "geosignal" in f.stem:
+                for item in json.loads(f.read_bytes()):
+                    self.cap_list.append([{"Question": item["instruction"] + item["input"], "Answer": item["output"]}])
+                    self.sample_weight.append(self.WEIGHT_DICT["geosignal"])
+
+
 # ------------------------------------------------------------------------------------------------ samplers / loaders
+class DistributedSamplerWrapper(torch.utils.data.DistributedSampler):
+    """Any sampler, sharded over the ranks (lhrs/Dataset/utils.py:7-57): every pass the wrapped sampler's index list is drawn (each rank
+    draws its own - the reference does not synchronise that RNG), and the DistributedSampler's epoch-seeded shuffle of POSITIONS decides
+    which of them this rank takes."""
+
+    def __init__(self, sampler, num_replicas: Optional[int] = None, rank: Optional[int] = None, shuffle: bool = True):
+        self.sampler = sampler
+        super().__init__(list(range(len(sampler))), num_replicas=num_replicas, rank=rank, shuffle=shuffle)
+
+    def __iter__(self):
+        drawn = list(self.sampler)
+        return iter([drawn[i] for i in super().__iter__()])
+
+
+
 class InfiniteSampler(torch.utils.data.Sampler):
     """Endless index stream for iteration-based training: reshuffled passes over the dataset from ONE seeded generator shared by all
     ranks, rank r taking elements r, r + world, ... of the stream (lhrs/CustomTrainer/utils/sampler.py)."""
@@ -316,10 +371,19 @@ def build_vlp_loader(config, is_train: bool = True, **kwargs):
     if is_train and stage == 1:
         dataset = CaptionDatasetVQA(root=root, transform=transform, **kwargs)
     elif is_train:
-        if config.get("weight_sample", False):
-            raise NotImplementedError("weight_sample: True (per-corpus sampling weights of InstructDatasetWithTaskId) is not built; "
-                                      "set weight_sample: False")
         size = config["transform"]["input_size"][0] if "transform" in config else 224
+        if config.get("weight_sample", False):  # build_loader.py:83-109: weighted draw without replacement, sharded over the ranks
+            from torch.utils.data import DataLoader, WeightedRandomSampler
+            dataset = InstructDatasetWithTaskId(root=root, transform=transform, crop_size=size, **kwargs)
+            dist = torch.distributed
+            on = dist.is_available() and dist.is_initialized()
+            sampler = DistributedSamplerWrapper(WeightedRandomSampler(dataset.sample_weight, num_samples=len(dataset), replacement=False),
+                                                num_replicas=dist.get_world_size() if on else 1, rank=dist.get_rank() if on else 0)
+            workers = int(config.get("workers", 0))
+            logger.info("Build dataset: Train samples = %d (weighted by corpus)", len(dataset))
+            return DataLoader(dataset, sampler=sampler, batch_size=int(config["batch_size"]), num_workers=workers,
+                              pin_memory=torch.cuda.is_available(), drop_last=True, persistent_workers=workers > 0,
+                              collate_fn=DataCollatorForSupervisedDataset(tokenizer=kwargs["tokenizer"]))
         dataset = InstructDataset(root=root, transform=transform, crop_size=size, **kwargs)
     else:
         raise NotImplementedError("evaluation loaders are built by the eval scripts (main_vqa / main_cls / main_vg), outside this path")

@@ -74,6 +74,15 @@ def build_case(root, case):
         for i, (h, w) in enumerate(SIZES[:2]):
             _png(os.path.join(root, "XRSVG_Image", f"g{i}.jpg"), 50 + i, h, w)
         J("XRSVG.json", {"data": [{"img": f"g{i}.jpg", "question": f"[VG] locate the object number {i}", "answer": f"[{i}, 2, 30, 40]"} for i in range(2)]})
+    elif case == "taskid":
+        for i, (h, w) in enumerate(SIZES[:3]):
+            _png(os.path.join(root, "FAST_Image", f"f{i}.png"), 60 + i, h, w)
+            _png(os.path.join(root, "XDOTA_Image", f"d{i}.png"), 70 + i, h, w)
+        J("FAST.json", {"data": [{"name": f"f{i}.png", "conv": [{"Question": f"what is object {i}?", "Answer": f"thing {i}"},
+                                                                   {"Question": "and next? <image>", "Answer": "kept <image> as is"}]} for i in range(3)]})
+        J("XDOTA.json", [{"name": f"d{i}.png", "conv": {"Question": f"<image>\ncount the ships {i}", "Answer": str(i)}} for i in range(3)])
+        J("geosignal_text.json", [{"instruction": "Explain NDVI. ", "input": "briefly", "output": "a vegetation index"},
+                                  {"instruction": "What is SAR?", "input": "", "output": "synthetic aperture radar"}])
     else:
         raise ValueError(case)
     return dict(root=root)
@@ -81,3 +90,4 @@ def build_case(root, case):
 
 STAGE1 = [("rsicd", "plain"), ("nwpu", "plain"), ("textrs", "llava_llama_2"), ("llava", "llava_llama_2")]
 STAGE2 = [("instruct", "llava_llama_2"), ("rsvg", "llava_llama_2")]
+STAGE3 = [("taskid", "llava_llama_2")]

@@ -53,7 +53,7 @@ import dataset_cases as DC  # noqa: E402
 tok = DC.ToyTok()
 out = {"seed": 1234, "cases": {}}
 with tempfile.TemporaryDirectory() as tmp:
-    for cls_name, cases in (("CaptionDatasetVQA", DC.STAGE1), ("InstructDataset", DC.STAGE2)):
+    for cls_name, cases in (("CaptionDatasetVQA", DC.STAGE1), ("InstructDataset", DC.STAGE2), ("InstructDatasetWithTaskId", DC.STAGE3)):
         for case, prompt in cases:
             kw = DC.build_case(os.path.join(tmp, case), case)
             random.seed(out["seed"])
@@ -61,6 +61,10 @@ with tempfile.TemporaryDirectory() as tmp:
             rows = []
             for i in range(len(ds)):
                 s = ds[i]
+                if i >= len(ds.img_list):  # text-only sample of the weighted mixture: zero picture, no file
+                    rows.append({"file": None, "size": list(s["rgb"].shape), "ids": s["text"]["input_ids"].tolist(), "labels": s["text"]["labels"].tolist(),
+                                 "valid_image": s["valid_image"]})
+                    continue
                 rows.append({"file": ds.img_list[i].name, "size": list(s["rgb"].size), "ids": s["text"]["input_ids"].tolist(),
                              "labels": s["text"]["labels"].tolist(), **({"valid_image": s["valid_image"]} if "valid_image" in s else {})})
             # the collated batch of the first (up to) four samples, images replaced by stand-in tensors (PIL images stay a list)
@@ -69,6 +73,8 @@ with tempfile.TemporaryDirectory() as tmp:
             b = cd.DataCollatorForSupervisedDataset(tokenizer=tok)(inst)
             out["cases"][case] = {"cls": cls_name, "prompt_type": prompt, "n": len(ds), "rows": rows,
                                   "batch": {k: v.tolist() for k, v in b.items() if k != "rgb"}}
+            if hasattr(ds, "sample_weight"):
+                out["cases"][case]["sample_weight"] = list(ds.sample_weight)
             print(case, cls_name, prompt, len(ds), [len(r["ids"]) for r in rows])
 json.dump(out, open(os.path.join(HERE, "datasets.json"), "w"))
 print(os.path.getsize(os.path.join(HERE, "datasets.json")) // 1024, "KiB")

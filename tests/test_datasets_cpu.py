@@ -26,14 +26,23 @@ def test_dataset_matches_reference_class(case, tmp_path):
     random.seed(Z["seed"])
     ds = getattr(DS, want["cls"])(tokenizer=tok, prompt_type=want["prompt_type"], transform=None, **kw)
     assert len(ds) == want["n"]
-    for i, row in enumerate(want["rows"]):
+    # a root with several corpora is listed in file-system order (the reference does not sort either): match samples by file name
+    order = list(range(len(want["rows"])))
+    if case == "taskid":
+        names = [p.name for p in ds.img_list]
+        order = [names.index(r["file"]) if r["file"] is not None else j for j, r in enumerate(want["rows"])]
+        assert [ds.sample_weight[i] for i in order] == want["sample_weight"]
+    for i, row in zip(order, want["rows"]):
         s = ds[i]
-        assert ds.img_list[i].name == row["file"] and list(s["rgb"].size) == row["size"]
+        if row["file"] is None:  # text-only sample of the weighted mixture
+            assert i >= len(ds.img_list) and list(s["rgb"].shape) == row["size"] and float(s["rgb"].abs().sum()) == 0.0
+        else:
+            assert ds.img_list[i].name == row["file"] and list(s["rgb"].size) == row["size"]
         assert s["text"]["input_ids"].tolist() == row["ids"], (case, i)
         assert s["text"]["labels"].tolist() == row["labels"], (case, i)
         if "valid_image" in row:
             assert s["valid_image"] == row["valid_image"]
-    inst = [dict(ds[i], rgb=torch.zeros(3, 2, 2)) for i in range(min(4, len(ds)))]
+    inst = [dict(ds[i], rgb=torch.zeros(3, 2, 2)) for i in order[: min(4, len(ds))]]
     b = DataCollatorForSupervisedDataset(tok)(inst)
     assert {k: v.tolist() for k, v in b.items() if k != "rgb"} == want["batch"]
 
@@ -77,3 +86,43 @@ def test_build_loader_stage1_batches_uint8_pixels_and_samplers(tmp_path):
     assert sorted(first[:6]) == list(range(6)) and sorted(first[6:]) == list(range(6))
     with pytest.raises(NotImplementedError):
         DS.build_loader(ConfigDict(dict(data_path="/x/RS5M", stage=1, batch_size=2, rgb_vision={"arch": "vit_large"})), mode="pretrain", tokenizer=tok)
+
+
+def test_weighted_stage3_loader_and_sampler_wrapper(tmp_path):
+    """`weight_sample: True` (Config/multi_modal_stage3.yaml): WeightedRandomSampler without replacement = a weighted permutation of all
+    samples, sharded by DistributedSamplerWrapper; batches may mix pictures with text-only samples (zero picture, no image token)."""
+    from torch.utils.data import WeightedRandomSampler
+    from lhrs_bot_amd.trainer import ConfigDict
+    DC.build_case(str(tmp_path / "d"), "taskid")
+    tok = DC.ToyTok()
+    ds = DS.InstructDatasetWithTaskId(tokenizer=tok, prompt_type="llava_llama_2", transform=None, root=str(tmp_path / "d"))
+    assert len(ds) == 8 and len(ds.sample_weight) == 8 and sorted(set(ds.sample_weight)) == [0.5, 0.9, 1.0]
+    base = WeightedRandomSampler(ds.sample_weight, num_samples=len(ds), replacement=False)
+    shards = []
+    for r in range(2):
+        w = DS.DistributedSamplerWrapper(base, num_replicas=2, rank=r)
+        w.set_epoch(3)
+        idx = list(w)
+        assert len(idx) == 4 and all(0 <= i < 8 for i in idx)
+        shards.append(idx)
+    one = DS.DistributedSamplerWrapper(base, num_replicas=1, rank=0)
+    assert sorted(one) == list(range(8))                       # one rank: every sample exactly once per pass
+
+    class Deferred(DS.CLIPImageProcessorHIP):
+        def __init__(self):
+            pass
+
+    import lhrs_bot_amd.datasets as mod
+    orig = mod.build_vlp_transform
+    mod.build_vlp_transform = lambda config, is_train=True: Deferred()
+    try:
+        cfg = ConfigDict(dict(data_path=str(tmp_path / "d"), stage=3, weight_sample=True, batch_size=3, workers=0, is_distribute=False,
+                              transform={"input_size": [224, 224]}, rgb_vision={"arch": "vit_large"}))
+        loader = DS.build_loader(cfg, mode="pretrain", tokenizer=tok, prompt_type="llava_llama_2")
+        batches = list(loader)
+    finally:
+        mod.build_vlp_transform = orig
+    assert len(batches) == 2 and all(b["input_ids"].shape[0] == 3 and "valid_image" in b for b in batches)   # 8 samples, drop_last
+    for b in batches:
+        has_img = b["input_ids"].eq(-200).any(dim=1)
+        assert torch.equal(has_img, b["valid_image"])
