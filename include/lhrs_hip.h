@@ -160,6 +160,13 @@ int lhrs_attn_bwd(const void* q, long ldq, const void* k, long ldk, const void* 
                   long ld_do, const float* lse, const float* delta, void* dq, long ld_dq, void* dk, long ld_dk, void* dv,
                   long ld_dv, const int* desc, int nseq, int H, int D, int max_q, int max_kv, int LTq, int causal,
                   float scale, void* stream);
+/* ... of ROTATED q / k (HF LlamaAttention.forward: apply_rotary_pos_emb precedes the scores; text_modal.py:281-292): dq / dk leave the
+ * kernel as gradients of the un-rotated projections - the inverse rotation (token row m at position m % pos_mod + pos0; fp32 cos / sin
+ * tables [pos][D / 2]) rides in the stores.  Bit-identical to lhrs_attn_bwd + lhrs_rope(inverse) over rows [0, rows) of dq and dk. */
+int lhrs_attn_bwd_rope(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout,
+                       long ld_do, const float* lse, const float* delta, void* dq, long ld_dq, void* dk, long ld_dk, void* dv,
+                       long ld_dv, const int* desc, int nseq, int H, int D, int max_q, int max_kv, int LTq, int causal,
+                       float scale, const float* cos_t, const float* sin_t, int pos_mod, int pos0, long rows, void* stream);
 
 /* ---- element-wise / layout -------------------------------------------------------------------------- *
  * patchify/assemble: HF CLIPVisionEmbeddings (rgb_vision_modal.py:166-172); rope: HF apply_rotary_pos_emb;

@@ -43,6 +43,11 @@ struct AttnArgs {
   float scale;
   const unsigned char* kmask;  // optional key-visibility bytes [seq][ld_kmask] (HF attention_mask semantics), tiled forward only
   long ld_kmask;
+  // backward only (lhrs_attn_bwd_rope): the INVERSE rotary embedding of the dq / dk rows applied in the store (resident kernels): fp32
+  // cos / sin tables [pos][D / 2], position of token row m = m % rope_mod + rope_pos0; nullptr = plain stores
+  const float* rope_cos;
+  const float* rope_sin;
+  int rope_mod, rope_pos0;
 };
 
 constexpr float NEG_INF = -__builtin_huge_valf();
@@ -141,6 +146,27 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 __device__ __forceinline__ void store4bf(bf16_t* p, const f32x4& v, float s) {
   *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v[0] * s, v[1] * s), pack2bf(v[2] * s, v[3] * s));
+}
+
+// d(q) / d(k) of one token row, as the lane holds it (DB f32x4 blocks: dims db * 16 + fg * 4 + 0..3), through the transpose of the rotary
+// embedding: the gradient of (x1 cos - x2 sin, x2 cos + x1 sin) is rope_pair with -sin.  The values are rounded to bf16 first, exactly
+// what the stand-alone kernel reads back from HBM: attention-backward + lhrs_rope(inverse) and this fused store agree bit for bit.
+template <int DB>
+__device__ __forceinline__ void rope_bwd_inplace(f32x4 (&g)[DB], const AttnArgs& a, long token_row, int fg) {
+  const int pos = (int)(token_row % a.rope_mod) + a.rope_pos0;
+  const float* cs = a.rope_cos + (long)pos * (DB * 8) + fg * 4;
+  const float* sn = a.rope_sin + (long)pos * (DB * 8) + fg * 4;
+#pragma unroll
+  for (int db = 0; db < DB / 2; ++db) {
+    const float4 c4 = *reinterpret_cast<const float4*>(cs + db * 16), s4 = *reinterpret_cast<const float4*>(sn + db * 16);
+    const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float o1, o2;
+      rope_pair(bf2f(f2bf(g[db][i])), bf2f(f2bf(g[db + DB / 2][i])), cv[i], -sv[i], o1, o2);
+      g[db][i] = o1; g[db + DB / 2][i] = o2;
+    }
+  }
 }
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
@@ -652,6 +678,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_res_kernel(AttnArgs a) {
       for (int db = 0; db < DB; ++db) dq[db] = MFMA(join(k1lo[db], k1hi[db]), d1, dq[db]);
     }
     if (qrow < q_len) {
+      if (a.rope_cos != nullptr) rope_bwd_inplace<DB>(dq, a, (long)q_off + qrow, fg);
       bf16_t* pq = a.dq + (long)(q_off + qrow) * a.ld_dq + h * D + fg * 4;
 #pragma unroll
       for (int db = 0; db < DB; ++db) store4bf(pq + db * 16, dq[db], 1.f);
@@ -753,6 +780,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_res_kernel(AttnArgs a) {
       for (int db = 0; db < DB; ++db) dk[db] = MFMA(join(blo[db], bhi[db]), d1, dk[db]);
     }
     if (key < kv_rows) {
+      if (a.rope_cos != nullptr) rope_bwd_inplace<DB>(dk, a, (long)kv_off + key, fg);
       bf16_t* pk = a.dk + (long)(kv_off + key) * a.ld_dk + h * D + fg * 4;
       bf16_t* pv = a.dv + (long)(kv_off + key) * a.ld_dv + h * D + fg * 4;
 #pragma unroll
@@ -886,11 +914,19 @@ extern "C" int lhrs_attn_delta(const void* o, long ldo, const void* dout, long l
   return 0;
 }
 
-extern "C" int lhrs_attn_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
-                             const void* dout, long ld_do, const float* lse, const float* delta, void* dq, long ld_dq,
-                             void* dk, long ld_dk, void* dv, long ld_dv, const int* desc, int nseq, int H, int D,
-                             int max_q, int max_kv, int LTq, int causal, float scale, void* stream) {
+extern "C" int lhrs_rope(void* x, long ld, int rows, int nheads, int D, const float* cos_t, const float* sin_t, const int* pos_ids, int pos_mod,
+                         int pos0, int inverse, void* stream);
+
+static int attn_bwd_impl(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                         const void* dout, long ld_do, const float* lse, const float* delta, void* dq, long ld_dq,
+                         void* dk, long ld_dk, void* dv, long ld_dv, const int* desc, int nseq, int H, int D,
+                         int max_q, int max_kv, int LTq, int causal, float scale, const float* rope_cos, const float* rope_sin,
+                         int rope_mod, int rope_pos0, long rope_rows, void* stream) {
   AttnArgs a; memset(&a, 0, sizeof(a));
+  const bool rope = rope_cos != nullptr;
+  const int rmax_ = D == 128 ? res_rows<128>() : res_rows<64>();
+  const bool fuse_rope = rope && max_kv <= rmax_ && max_q <= rmax_;  // both resident kernels run: the rotation rides in their stores
+  if (fuse_rope) { a.rope_cos = rope_cos; a.rope_sin = rope_sin; a.rope_mod = rope_mod; a.rope_pos0 = rope_pos0; }
   a.q = (const bf16_t*)q; a.ldq = ldq; a.k = (const bf16_t*)k; a.ldk = ldk; a.v = (const bf16_t*)v; a.ldv = ldv;
   a.dout = (const bf16_t*)dout; a.ld_do = ld_do; a.lse = (float*)lse; a.delta = delta;
   a.dq = (bf16_t*)dq; a.ld_dq = ld_dq; a.dk = (bf16_t*)dk; a.ld_dk = ld_dk; a.dv = (bf16_t*)dv; a.ld_dv = ld_dv;
@@ -912,6 +948,7 @@ extern "C" int lhrs_attn_bwd(const void* q, long ldq, const void* k, long ldk, c
     dkv_done = true;
   }
   if (dq_done && dkv_done) { LHRS_CHECK_LAUNCH("attn_bwd_res"); return 0; }
+  // (never reached with fuse_rope: it requires both resident kernels)
 #define LAUNCH_TILED(KERN, GRID)                                                                 \
   do {                                                                                           \
     if (D == 128) { if (causal) hipLaunchKernelGGL((KERN<128, true>), GRID, blk, 0, s, a); else hipLaunchKernelGGL((KERN<128, false>), GRID, blk, 0, s, a); } \
@@ -921,5 +958,30 @@ extern "C" int lhrs_attn_bwd(const void* q, long ldq, const void* k, long ldk, c
   if (!dkv_done) LAUNCH_TILED(attn_bwd_dkv_kernel, gk);
 #undef LAUNCH_TILED
   LHRS_CHECK_LAUNCH("attn_bwd");
+  if (rope) {  // long sequences (tiled kernels): the rotation as its own pass over the dq and dk rows, same numbers
+    if (lhrs_rope(dq, ld_dq, (int)rope_rows, H, D, rope_cos, rope_sin, nullptr, rope_mod, rope_pos0, 1, stream)) return -1;
+    if (lhrs_rope(dk, ld_dk, (int)rope_rows, H, D, rope_cos, rope_sin, nullptr, rope_mod, rope_pos0, 1, stream)) return -1;
+  }
   return 0;
+}
+
+extern "C" int lhrs_attn_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                             const void* dout, long ld_do, const float* lse, const float* delta, void* dq, long ld_dq,
+                             void* dk, long ld_dk, void* dv, long ld_dv, const int* desc, int nseq, int H, int D,
+                             int max_q, int max_kv, int LTq, int causal, float scale, void* stream) {
+  return attn_bwd_impl(q, ldq, k, ldk, v, ldv, dout, ld_do, lse, delta, dq, ld_dq, dk, ld_dk, dv, ld_dv, desc, nseq, H, D, max_q, max_kv, LTq,
+                       causal, scale, nullptr, nullptr, 1, 0, 0, stream);
+}
+
+// attention backward of ROTATED q / k (HF LlamaAttention: apply_rotary_pos_emb before the scores): dq and dk come out as gradients of the
+// UN-rotated projections - the inverse rotation (position of token row m = m % pos_mod + pos0, fp32 cos / sin tables [pos][D / 2]) is
+// applied where the rows are stored.  Bit-identical to lhrs_attn_bwd followed by lhrs_rope(inverse) on the dq and dk rows [0, rows).
+extern "C" int lhrs_attn_bwd_rope(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                                  const void* dout, long ld_do, const float* lse, const float* delta, void* dq, long ld_dq,
+                                  void* dk, long ld_dk, void* dv, long ld_dv, const int* desc, int nseq, int H, int D,
+                                  int max_q, int max_kv, int LTq, int causal, float scale, const float* cos_t, const float* sin_t,
+                                  int pos_mod, int pos0, long rows, void* stream) {
+  LHRS_REQUIRE(cos_t && sin_t && pos_mod > 0 && rows > 0, "attn_bwd_rope: cos/sin tables, pos_mod=%d, rows=%ld", pos_mod, rows);
+  return attn_bwd_impl(q, ldq, k, ldk, v, ldv, dout, ld_do, lse, delta, dq, ld_dq, dk, ld_dk, dv, ld_dv, desc, nseq, H, D, max_q, max_kv, LTq,
+                       causal, scale, cos_t, sin_t, pos_mod, pos0, rows, stream);
 }

@@ -344,11 +344,21 @@ def attn_delta(o, dout, delta, desc, nseq, H, D, max_q, LTq):
     _lib.check(st, "attn_delta")
 
 
-def attn_bwd(q, k, v, dout, lse, delta, dq, dk, dv, desc, nseq, H, D, max_q, max_kv, LTq, causal, scale):
-    st = _L().lhrs_attn_bwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), dout.data_ptr(),
-                            dout.stride(0), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dq.stride(0), dk.data_ptr(),
-                            dk.stride(0), dv.data_ptr(), dv.stride(0), desc.data_ptr(), nseq, H, D, max_q, max_kv, LTq,
-                            int(causal), float(scale), _stream())
+def attn_bwd(q, k, v, dout, lse, delta, dq, dk, dv, desc, nseq, H, D, max_q, max_kv, LTq, causal, scale, rope=None):
+    """rope = (cos_t, sin_t, pos_mod, pos0): q / k were rotated before the scores - dq / dk are returned as gradients of the UN-rotated
+    projections (inverse rotation inside the stores of the resident kernels; a separate pass for long sequences), rows = dq.shape[0]."""
+    if rope is None:
+        st = _L().lhrs_attn_bwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), dout.data_ptr(),
+                                dout.stride(0), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dq.stride(0), dk.data_ptr(),
+                                dk.stride(0), dv.data_ptr(), dv.stride(0), desc.data_ptr(), nseq, H, D, max_q, max_kv, LTq,
+                                int(causal), float(scale), _stream())
+    else:
+        cos_t, sin_t, pos_mod, pos0 = rope
+        st = _L().lhrs_attn_bwd_rope(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), dout.data_ptr(),
+                                     dout.stride(0), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dq.stride(0), dk.data_ptr(),
+                                     dk.stride(0), dv.data_ptr(), dv.stride(0), desc.data_ptr(), nseq, H, D, max_q, max_kv, LTq,
+                                     int(causal), float(scale), cos_t.data_ptr(), sin_t.data_ptr(), int(pos_mod), int(pos0), dq.shape[0],
+                                     _stream())
     _lib.check(st, "attn_bwd")
 
 

@@ -866,8 +866,7 @@ class TextModal:
             do = self._lin_bwd(li, "o", dx_mid, L["o_wT"], s["o"], s.get("T_o"), q8=self._q8(L, "o_wT"), dyq=dmq, drop=self._drop(s, "o"))
             hk.attn_delta(s["o"], do, delta, desc, B, H, hd, S, LT)
             hk.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], do, s["lse"], delta, dqkv[:, :d], dqkv[:, d:2 * d],
-                        dqkv[:, 2 * d:], desc, B, H, hd, S, S, LT, True, scale)
-            hk.rope_(dqkv, M, 2 * H, hd, self.cos, self.sin, pos_mod=S, inverse=True)
+                        dqkv[:, 2 * d:], desc, B, H, hd, S, S, LT, True, scale, rope=(self.cos, self.sin, S, 0))  # inverse RoPE in the dq / dk stores
             h1 = hk.rmsnorm_fwd(s["x_in"], L["ln1_w"], self.eps) if lo is not None and "qkv" in lo.groups else None
             dh1 = self._lin_bwd(li, "qkv", dqkv, L["qkv_wT"], h1, s.get("T_qkv"), q8=self._q8(L, "qkv_wT"), drop=self._drop(s, "qkv"))
             if self.base8:

@@ -160,7 +160,18 @@ class UniBind:
         if getattr(self, "_image_processor", None) is None:
             from .data import CLIPImageProcessorHIP
             self._image_processor = CLIPImageProcessorHIP(device=self.device)
-        return self._image_processor.preprocess(list(rgb))["pixel_values"]
+        items = list(rgb)
+        ready = [torch.is_tensor(x) and x.is_floating_point() for x in items]  # e.g. the zero picture of a text-only sample (stage-3 mixture)
+        if not any(ready):
+            return self._image_processor.preprocess(items)["pixel_values"]
+        out = torch.empty((len(items), 3, 224, 224), device=self.device, dtype=torch.float32)
+        todo = [i for i, r in enumerate(ready) if not r]
+        if todo:
+            out[todo] = self._image_processor.preprocess([items[i] for i in todo])["pixel_values"]
+        for i, r in enumerate(ready):
+            if r:
+                out[i] = items[i].to(self.device, torch.float32)
+        return out
 
     def init_random(self, seed: int = 0):
         if hasattr(self, "rgb"):

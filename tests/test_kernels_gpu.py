@@ -543,3 +543,38 @@ def test_host_splice_integers_equal_the_device_splice():
             _, dl, dm, pos = hk.splice_fwd(ids.to(DEV), None if lab is None else lab.to(DEV), None if msk is None else msk.to(DEV), image, embed, S)
             assert torch.equal(dl.cpu(), nl) and torch.equal(dm.cpu(), nm), trial
             assert torch.equal(pos.cpu() >= 0, with_img)
+
+
+@pytest.mark.parametrize("S,B,H", [(273, 3, 32), (130, 2, 4), (700, 1, 2)])   # resident kernels (twice), tiled kernels + separate pass
+def test_attention_backward_with_fused_inverse_rope_is_bit_identical(S, B, H):
+    """lhrs_attn_bwd_rope: dq / dk leave the kernel as gradients of the UN-rotated q / k projections (HF LlamaAttention rotates before the
+    scores).  The rotation rides in the stores; it must equal lhrs_attn_bwd followed by lhrs_rope(inverse) bit for bit (same bf16
+    rounding points), for the LDS-resident kernels of the training shapes and for the tiled fallback of long sequences."""
+    D = 128
+    d = H * D
+    g = torch.Generator().manual_seed(S + B)
+    M = B * S
+    qkv = bf(torch.randn(M, 3 * d, generator=g) * 0.5).to(DEV)
+    do = bf(torch.randn(M, d, generator=g) * 0.1).to(DEV)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
+    fr = torch.outer(torch.arange(1024).float(), inv)
+    cos_t, sin_t = fr.cos().to(torch.bfloat16).float().to(DEV).contiguous(), fr.sin().to(torch.bfloat16).float().to(DEV).contiguous()
+    desc = hk.make_desc([(b * S, S, b * S, S if b else S - 7, S, 0) for b in range(B)], DEV)
+    LT = hk.pad64(S)
+    scale = 1.0 / math.sqrt(D)
+    q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    o = torch.zeros(M, d, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, LT, device=DEV, dtype=torch.float32)
+    hk.attn_fwd(q, k, v, o, lse, desc, B, H, D, S, S, LT, True, scale)
+    delta = torch.zeros(B, H, LT, device=DEV, dtype=torch.float32)
+    hk.attn_delta(o, do, delta, desc, B, H, D, S, LT)
+    ref = torch.zeros(M, 3 * d, device=DEV, dtype=torch.bfloat16)
+    hk.attn_bwd(q, k, v, do, lse, delta, ref[:, :d], ref[:, d:2 * d], ref[:, 2 * d:], desc, B, H, D, S, S, LT, True, scale)
+    plain = ref.clone()
+    hk.rope_(ref, M, 2 * H, D, cos_t, sin_t, pos_mod=S, inverse=True)
+    got = torch.zeros_like(ref)
+    hk.attn_bwd(q, k, v, do, lse, delta, got[:, :d], got[:, d:2 * d], got[:, 2 * d:], desc, B, H, D, S, S, LT, True, scale,
+                rope=(cos_t, sin_t, S, 0))
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    assert torch.equal(got[:, 2 * d:], plain[:, 2 * d:]) and not torch.equal(got[:, :2 * d], plain[:, :2 * d])   # dv untouched, dq / dk rotated
