@@ -7,17 +7,21 @@
 // HBM; 288 GB makes the second copy free), so dX is NT as well; dW for the projector is NT over transposed
 // activations.  One layout, one kernel family.
 //
-// Structure (CDNA4):
-//   * 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 4x4 fragments of v_mfma_f32_16x16x32_bf16.
-//   * HBM -> LDS by direct-to-LDS DMA (global_load_lds_dwordx4): no VGPR round trip.  The LDS image of a
-//     wave-instruction is lane-linear, so the bank-conflict swizzle (16-B chunk ^= row&7) is applied to the
-//     per-lane SOURCE address and to the ds_read_b128 address (both sides, same involution).
-//   * two LDS stages; the DMA for tile t+1 is in flight while tile t is multiplied.
-//   * operands are fed to the MFMA swapped (weight fragment as A, activation fragment as B) so that each
-//     lane ends up with 4 consecutive n of one m: 8-byte bf16 / 16-byte f32 row-contiguous stores, and
-//     bias / residual become 8-byte vector loads.
-//   * block id -> tile map is XCD-aware (block b runs on XCD b%8; each XCD gets a contiguous run of tiles,
-//     rastered in groups of 8 tile-rows) so neighbouring tiles share A/B panels in one XCD's L2.
+// Kernel family (CDNA4), chosen by tile count in gemm_launch:
+//   * gemm_nt_256r_kernel<ACT, EPI> - THE dominant kernel (every LLaMA linear at training batch sizes): 256x256x64 tile, 16 waves (4x4 of
+//     64x64 = 2x2 fragments of v_mfma_f32_32x32x16_bf16), two 64 KiB LDS stages filled by direct-to-LDS DMA (global_load_lds_dwordx4, no VGPR
+//     round trip), one barrier per stage, PERSISTENT over tiles (one workgroup per CU; the next tile's first stage is fetched under the
+//     epilogue), fused epilogues: bias / activation / residual / dropout mask (EPI 0), SwiGLU forward / backward (EPI 1 / 2), RoPE (EPI 3).
+//   * gemm_nt_256p_kernel - K % 64 != 0 fallback of the above (BK = 32, 4-deep ring, 8 waves).
+//   * gemm_nt_kernel<WM, WN> - 128x128 / 64x128 / 64x64 tiles, 4 waves, for the small products of the ViT and the projector.
+//   * e4m3 siblings (gemm_fp8_256_kernel, gemm_fp8_small_kernel) for the 8-bit frozen base of stages 2/3.
+// Common to all:
+//   * the LDS image of a DMA wave-instruction is lane-linear, so the bank-conflict swizzle (16-B chunk ^= f(row)) is applied to the
+//     per-lane SOURCE address and to the ds_read_b128 address (both sides, same involution);
+//   * operands are fed to the MFMA swapped (weight fragment as A, activation fragment as B) so that each lane ends up with consecutive n
+//     of one m: row-contiguous stores, and bias / residual become vector loads;
+//   * block id -> tile map is XCD-aware (block b runs on XCD b % 8; each XCD gets a contiguous run of tiles, rastered in groups of 8 tile
+//     rows) so the 32 tiles an XCD works on at a time share 8 A panels and 4 B panels in its L2.
 #include "common.h"
 #include <type_traits>
 
