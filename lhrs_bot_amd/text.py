@@ -74,6 +74,25 @@ LORA_GROUPS = {  # fused GEMM group -> (sub-projections, in_features, out_featur
 LORA_ALL = ("q", "k", "v", "o", "gate", "up", "down")  # find_all_linear_names: every nn.Linear except lm_head (text_modal.py:658-667)
 
 
+def warp_logits(logits: torch.Tensor, temperature: float = 1.0, top_k: Optional[int] = None, top_p: Optional[float] = None) -> torch.Tensor:
+    """The score processing HF `generate(do_sample=True)` applies before its multinomial draw, in HF's order: TemperatureLogitsWarper ->
+    TopKLogitsWarper -> TopPLogitsWarper (transformers generation/logits_process.py; cli_qa.py:176-186 passes temperature, the Llama-2
+    generation config top-k / top-p).  fp32 logits [B, V] in, filtered (-inf) logits out; pinned to the HF classes by
+    tests/test_host_cpu.py::test_sampling_warpers_match_hf.  Runs on whatever device the HIP-computed logits live on."""
+    z = logits / max(float(temperature), 1e-6)
+    if top_k:
+        k = min(int(top_k), z.shape[-1])
+        kth = torch.topk(z, k, dim=-1).values[:, -1:]
+        z = z.masked_fill(z < kth, float("-inf"))
+    if top_p is not None and top_p < 1.0:
+        sz, si = torch.sort(z, descending=False, dim=-1)
+        cp = torch.softmax(sz, -1).cumsum(-1)
+        rm = cp <= (1 - top_p)
+        rm[:, -1] = False  # keep at least the most likely token
+        z = z.masked_fill(rm.scatter(1, si, rm), float("-inf"))
+    return z
+
+
 class LoraStore:
     """peft-style LoRA adapters (lora.Linear: y = W x + (alpha/r) B A x; A ~ kaiming-uniform(a=sqrt 5), B = 0) for the fused
     GEMM groups, in three flat buffers (fp32 master, bf16 shadow, fp32 grad) ordered layer-major so that a layer's
@@ -680,14 +699,20 @@ class TextModal:
         return out
 
     @torch.no_grad()
-    def generate(self, input_ids, image_embedding=None, attention_mask=None, do_sample=False, temperature=1.0, top_p=None,
-                 top_k=None, max_new_tokens=512, use_cache=True, stopping_criteria=None, streamer=None, eos_token_id="default",
+    def generate(self, input_ids, image_embedding=None, attention_mask=None, do_sample=False, temperature=1.0, top_p="default",
+                 top_k="default", max_new_tokens=512, use_cache=True, stopping_criteria=None, streamer=None, eos_token_id="default",
                  return_logits=False, use_graph=True, weights="bf16", **_kw):
         """See `_generate`.  Two things happen here first: (1) `eos_token_id` defaults to the tokenizer's EOS, as HF `generate` stops on
         the generation config's EOS (pass None to disable); (2) if LoRA adapters are attached and not merged, the call runs on merged
         COPIES of the affected weights (`_lora_merged_layers`) and the base weights come back untouched."""
         if eos_token_id == "default":
             eos_token_id = getattr(self.tokenizer, "eos_token_id", None)
+        # sampling defaults of the reference's callers: HF GenerationConfig top_k = 50 and the Llama-2 generation_config.json top_p = 0.9
+        # apply when the caller (cli_qa.py:176-186 passes only temperature) does not say otherwise
+        if top_k == "default":
+            top_k = 50 if do_sample else None
+        if top_p == "default":
+            top_p = 0.9 if do_sample else None
         kw = dict(image_embedding=image_embedding, attention_mask=attention_mask, do_sample=do_sample, temperature=temperature, top_p=top_p,
                   top_k=top_k, max_new_tokens=max_new_tokens, use_cache=use_cache, stopping_criteria=stopping_criteria, streamer=streamer,
                   eos_token_id=eos_token_id, return_logits=return_logits, use_graph=use_graph, weights=weights)
@@ -730,17 +755,7 @@ class TextModal:
         def pick(logits):
             if not do_sample:
                 return hk.argmax_rows(logits)
-            z = logits / max(float(temperature), 1e-6)
-            if top_k:
-                kth = torch.topk(z, int(top_k), dim=-1).values[:, -1:]
-                z = z.masked_fill(z < kth, float("-inf"))
-            if top_p is not None and top_p < 1.0:
-                sz, si = torch.sort(z, descending=False, dim=-1)
-                cp = torch.softmax(sz, -1).cumsum(-1)
-                rm = cp <= (1 - top_p)
-                rm[:, -1] = False
-                z = z.masked_fill(rm.scatter(1, si, rm), float("-inf"))
-            return torch.multinomial(torch.softmax(z, -1), 1).squeeze(1)
+            return torch.multinomial(torch.softmax(warp_logits(logits, temperature, top_k, top_p), -1), 1).squeeze(1)
 
         # ---- prefill (GEMM path) -> logits of the last prompt position -> first new token
         desc = hk.make_desc([(b * S0, S0, b * max_ctx, S0, S0, 0) for b in range(B)], dev)

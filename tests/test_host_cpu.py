@@ -224,3 +224,27 @@ def test_keywords_stopping_criteria_matches_reference():
     for c in z["cases"]:
         crit = KeywordsStoppingCriteria(z["keywords"], Tok(), torch.zeros((1, c["prompt_len"]), dtype=torch.long))
         assert crit(torch.tensor([c["out"]]), None) == c["stop"], c
+
+
+def test_sampling_warpers_match_hf():
+    """generate(do_sample=True): the HIP-computed fp32 logits go through temperature -> top-k -> top-p exactly as HF's generate does
+    (cli_qa.py:176-186: do_sample=True, temperature=0.4; Llama-2 generation config: top_k 50, top_p 0.9).  Pinned to the installed
+    transformers' own warper classes on random and on peaked logits."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+
+    from lhrs_bot_amd.text import warp_logits
+    g = torch.Generator().manual_seed(0)
+    ids = torch.zeros((3, 1), dtype=torch.long)
+    for scale in (1.0, 8.0):
+        logits = torch.randn(3, 32000, generator=g) * scale
+        for temp, k, p in ((0.4, 50, 0.9), (1.0, None, 0.9), (0.7, 5, None), (0.2, 50, 0.5), (1.3, 0, 1.0)):
+            want = TemperatureLogitsWarper(temp)(ids, logits.clone())
+            if k:
+                want = TopKLogitsWarper(k)(ids, want)
+            if p is not None and p < 1.0:
+                want = TopPLogitsWarper(p)(ids, want)
+            got = warp_logits(logits, temp, k, p)
+            assert torch.equal(torch.isinf(got), torch.isinf(want)), (scale, temp, k, p)
+            keep = ~torch.isinf(want)
+            assert torch.allclose(got[keep], want[keep], rtol=1e-6, atol=1e-6)
+            assert (keep.sum(-1) >= 1).all()
