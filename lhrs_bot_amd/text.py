@@ -213,6 +213,9 @@ class TextModal:
         self._ctx = None
         self.lora: Optional[LoraStore] = None
         self.base8 = False  # frozen decoder linears in e4m3 (quantize_base)
+        # training forward: run the last decoder layer's post-attention half on the supervised rows only when they are one contiguous
+        # range per sequence (_layer_fwd `tail`); LHRS_TAIL_ROWS_ONLY=0 / attribute False: every row, as HF does
+        self.tail_rows_only = os.environ.get("LHRS_TAIL_ROWS_ONLY", "1") != "0"
         self.text_encoder = self  # attribute path used by the entry scripts (.text.text_encoder)
 
     def get_text_encoder(self):
@@ -414,7 +417,11 @@ class TextModal:
         return hk.splice_fwd(ids, lab, msk, image_embedding.contiguous(), self.p["embed"], S)
 
     # ------------------------------------------------------------------ forward
-    def _layer_fwd(self, L, x, B, S, desc, LT, save, li=0):
+    def _layer_fwd(self, L, x, B, S, desc, LT, save, li=0, tail=None):
+        """One decoder layer.  tail = (rows int32 [n], desc, max_q): the LAST layer of a training forward whose supervised positions
+        form one contiguous range per sequence - only those rows of its output are ever read (final norm -> lm_head -> loss), so the
+        attention runs for those queries only (all keys), and o_proj / residual / RMSNorm / MLP run on the n gathered rows instead of
+        all B*S.  HF computes every row and the loss ignores them: same loss, same gradients, ~0.4 of a layer's linear work less."""
         d, H, hd, ff = self.d, self.heads, self.hd, self.ff
         M = x.shape[0]
         rec = {} if save is not None else None
@@ -427,22 +434,29 @@ class TextModal:
         qkv = self._lin(li, "qkv", h, L["qkv_w"], save=rec, q8=self._q8(L, "qkv_w"), xq=hq, rope=(S, 0))
         o = torch.empty((M, d), device=self.device, dtype=torch.bfloat16)
         lse = torch.empty((B, H, LT), device=self.device, dtype=torch.float32)
-        hk.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, desc, B, H, hd, S, S, LT, True, 1.0 / math.sqrt(hd))
-        x_mid = self._lin(li, "o", o, L["o_w"], residual=x, save=rec, q8=self._q8(L, "o_w"))
+        o_full, x_res = o, x
+        if tail is None:
+            hk.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, desc, B, H, hd, S, S, LT, True, 1.0 / math.sqrt(hd))
+        else:
+            rows, tdesc, max_q = tail
+            hk.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, tdesc, B, H, hd, max_q, S, LT, True, 1.0 / math.sqrt(hd))
+            o, x_res = hk.gather_rows(o_full, rows), hk.gather_rows(x, rows)   # from here on: n rows
+        x_mid = self._lin(li, "o", o, L["o_w"], residual=x_res, save=rec, q8=self._q8(L, "o_w"))
         if self.base8:
             h, hq = hk.rmsnorm_fwd_q(x_mid, L["ln2_w"], self.eps, want_bf16=lo is not None and "gu" in lo.groups)
         else:
-            h = hk.rmsnorm_fwd(x_mid, L["ln2_w"], self.eps, out=h)
+            h = hk.rmsnorm_fwd(x_mid, L["ln2_w"], self.eps, out=h if tail is None else None)
         gu, act, actq = self._gu_fwd(li, h, L["gu_w"], rec, q8=self._q8(L, "gu_w"), xq=hq)
         x_out = self._lin(li, "down", act, L["down_w"], residual=x_mid, save=rec, q8=self._q8(L, "down_w"), xq=actq)
         if save is not None:
-            rec.update(x_in=x, qkv=qkv, o=o, lse=lse, x_mid=x_mid, gu=gu)
+            rec.update(x_in=x, qkv=qkv, o=o, o_full=o_full, lse=lse, x_mid=x_mid, gu=gu)
             save.append(rec)
         return x_out
 
-    def forward_hidden(self, embeds, mask_u8, save_ctx=True, kv_len=None):
+    def forward_hidden(self, embeds, mask_u8, save_ctx=True, kv_len=None, tail=None):
         """embeds [B,S,d] bf16, mask [B,S] uint8 (right padding) -> final-norm hidden [B*S, d].  kv_len: the per-sequence key counts when
-        the caller already has them on the host (saves the device round trip of summing the mask)."""
+        the caller already has them on the host (saves the device round trip of summing the mask).  tail = [(p0, n)] per sequence: only
+        the positions [p0, p0 + n) are needed from the last layer on (see _layer_fwd) -> hidden [sum n, d] of those rows, sequence-major."""
         B, S, d = embeds.shape
         if S > self.cos.shape[0]:
             raise ValueError(f"sequence length {S} exceeds the {self.cos.shape[0]} positions of the RoPE table")
@@ -454,11 +468,17 @@ class TextModal:
         if self.lora is not None:
             self.lora.drop_epoch += 1  # a fresh dropout mask per forward pass
         x = embeds.reshape(B * S, d)
+        nl = len(self.p["layers"])
+        tail_t = None
+        if tail is not None and nl > 0:
+            rows = torch.cat([torch.arange(b * S + p0, b * S + p0 + n, dtype=torch.int32) for b, (p0, n) in enumerate(tail)])
+            tdesc = hk.make_desc([(b * S + p0, n, b * S, int(kv_len[b]), S, p0) for b, (p0, n) in enumerate(tail)], self.device)
+            tail_t = (hk.h2d(rows, self.device), tdesc, max(n for _, n in tail))
         for li, L in enumerate(self.p["layers"]):
-            x = self._layer_fwd(L, x, B, S, desc, LT, saved, li)
+            x = self._layer_fwd(L, x, B, S, desc, LT, saved, li, tail=tail_t if li == nl - 1 else None)
         hidden = hk.rmsnorm_fwd(x, self.p["norm_w"], self.eps)
         if save_ctx:
-            self._ctx = dict(B=B, S=S, desc=desc, LT=LT, layers=saved, x_last=x)
+            self._ctx = dict(B=B, S=S, desc=desc, LT=LT, layers=saved, x_last=x, tail=tail_t)
         return hidden
 
     @staticmethod
@@ -523,9 +543,19 @@ class TextModal:
         targets = hk.h2d(flat[rows].to(torch.int32), self.device)
         ids_d = input_ids if input_ids.is_cuda else hk.h2d(ids_h.contiguous(), self.device)
         embeds, _, _, img_pos = hk.splice_fwd(ids_d, None, None, image_embedding.contiguous(), self.p["embed"], S)
-        hidden = self.forward_hidden(embeds, None, save_ctx, kv_len=new_mask.to(torch.int32).sum(dim=1).tolist())
-        self.last_hidden = hidden  # [B*S, d] final-norm output of this call (parity tests read it; the buffer exists anyway)
-        hv = hk.gather_rows(hidden, rows32)
+        # supervised positions of each sequence: when they form ONE contiguous range (stage 1: the caption at the end of the sequence; any
+        # single-answer sample) the last decoder layer only has to produce those rows
+        tail = None
+        if self.tail_rows_only and self.p["layers"]:
+            valid = tgt != IGNORE_INDEX
+            cnt = valid.sum(dim=1)
+            first = valid.to(torch.int64).argmax(dim=1)
+            last = S - 1 - valid.flip(1).to(torch.int64).argmax(dim=1)
+            if bool((cnt > 0).all()) and bool((last - first + 1 == cnt).all()):
+                tail = list(zip(first.tolist(), cnt.tolist()))
+        hidden = self.forward_hidden(embeds, None, save_ctx, kv_len=new_mask.to(torch.int32).sum(dim=1).tolist(), tail=tail)
+        self.last_hidden = hidden  # final-norm output of this call: [B*S, d], or the supervised rows only in tail mode (tests read it)
+        hv = hidden if tail is not None else hk.gather_rows(hidden, rows32)
         logits = hk.gemm_nt(hv, self.p["lm_head"])
         loss, dlogits = hk.cross_entropy(logits, targets, want_grad=save_ctx, inplace=True)
         if save_ctx:
@@ -852,8 +882,12 @@ class TextModal:
         lo = self.lora
         M = B * S
         dhv = hk.gemm_nt(c["dlogits"], p["lm_headT"], alpha=loss_scale)
-        dhid = torch.zeros((M, d), device=self.device, dtype=torch.bfloat16)
-        hk.scatter_rows(dhv, c["rows"], dhid)
+        tail = c.get("tail")
+        if tail is None:
+            dhid = torch.zeros((M, d), device=self.device, dtype=torch.bfloat16)
+            hk.scatter_rows(dhv, c["rows"], dhid)
+        else:
+            dhid = dhv  # x_last holds exactly the supervised rows: the last layer's backward starts compact
         dxq = None
         if self.base8:
             dx, dxq = hk.rmsnorm_bwd_q(dhid, c["x_last"], p["norm_w"], None, eps=self.eps)
@@ -866,6 +900,7 @@ class TextModal:
         for li in reversed(range(nl)):
             L, s = p["layers"][li], c["layers"][li]
             gu, qkv = s["gu"], s["qkv"]
+            tl = tail if li == nl - 1 else None  # tail layer: dx, dgu, dh, dx_mid, do below have n rows until they are scattered back
             act = hk.swiglu_fwd(gu, ff) if lo is not None and "down" in lo.groups else None      # x of the down projection
             dgu = self._down_bwd(li, dx, L["down_wT"], gu, act, s.get("T_down"), q8=self._q8(L, "down_wT"), dyq=dxq, drop=self._drop(s, "down"))
             dguq = None
@@ -879,9 +914,15 @@ class TextModal:
             else:
                 dx_mid = hk.rmsnorm_bwd(dh, s["x_mid"], L["ln2_w"], None, add=dx, eps=self.eps, out=dh)
             do = self._lin_bwd(li, "o", dx_mid, L["o_wT"], s["o"], s.get("T_o"), q8=self._q8(L, "o_wT"), dyq=dmq, drop=self._drop(s, "o"))
-            hk.attn_delta(s["o"], do, delta, desc, B, H, hd, S, LT)
+            adesc, max_q = desc, S
+            if tl is not None:
+                rows_t, adesc, max_q = tl
+                do = hk.scatter_rows(do, rows_t, torch.empty((M, d), device=self.device, dtype=torch.bfloat16))   # only query rows are read
+                dx_mid = hk.scatter_rows(dx_mid, rows_t, torch.zeros((M, d), device=self.device, dtype=torch.bfloat16))  # residual path: 0 elsewhere
+                dqkv[:, :d].zero_()                                                                                # dq exists for the query rows only
+            hk.attn_delta(s["o_full"], do, delta, adesc, B, H, hd, max_q, LT)
             hk.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], do, s["lse"], delta, dqkv[:, :d], dqkv[:, d:2 * d],
-                        dqkv[:, 2 * d:], desc, B, H, hd, S, S, LT, True, scale, rope=(self.cos, self.sin, S, 0))  # inverse RoPE in the dq / dk stores
+                        dqkv[:, 2 * d:], adesc, B, H, hd, max_q, S, LT, True, scale, rope=(self.cos, self.sin, S, 0))  # inverse RoPE in the dq / dk stores
             h1 = hk.rmsnorm_fwd(s["x_in"], L["ln1_w"], self.eps) if lo is not None and "qkv" in lo.groups else None
             dh1 = self._lin_bwd(li, "qkv", dqkv, L["qkv_wT"], h1, s.get("T_qkv"), q8=self._q8(L, "qkv_wT"), drop=self._drop(s, "qkv"))
             if self.base8:

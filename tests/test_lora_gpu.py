@@ -92,6 +92,7 @@ def test_lora_dropout_matches_oracle_with_the_same_masks(bits):
     from lhrs_bot_amd import kernels as hk
     targets = ("q", "k", "v", "o", "gate", "up", "down")
     model, lora, P, batch = make(targets, 8, False)
+    model.text.tail_rows_only = False  # the masks are rebuilt below over ALL B*S rows of every layer (tail mode draws the last layer's over its n rows)
     p = 0.3
     lora.dropout = p
     if bits == 8:
