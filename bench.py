@@ -372,6 +372,9 @@ def main():
         # rows that have a target only (caption tokens), so the executed share is lower
         tgt_rows = a.caption_tokens
         f_exec = f_alg(S) - 2 * (S - tgt_rows) * 2 * 4096 * 32000
+        tail_only = os.environ.get("LHRS_TAIL_ROWS_ONLY", "1") != "0"
+        if tail_only:  # last decoder layer: o_proj, gate|up, down (forward and dX) on the supervised rows only
+            f_exec -= 2 * (S - tgt_rows) * 2 * (4096 * 4096 + 4096 * 22016 + 11008 * 4096)
         res = {
             "metric": ("stage-1 pretrain samples/sec (224^2 image + 128-tok caption)" if a.stage == 1 else
                        f"stage-{a.stage} LoRA train samples/sec (224^2 image + 128-tok sequence)"), "value": round(sps, 3), "unit": "samples/s",
@@ -383,6 +386,7 @@ def main():
                        "micro_batch_per_gpu": B, "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
                        "optimizer": "adanp" if a.stage == 1 else "adamw", "stage": a.stage,
                        "lora": None if a.stage == 1 else ("r=8 on q,k,v,o, lora_dropout 0" if a.stage == 3 else "r=128 on all 7 linears, lora_dropout 0.05 (train mode)"),
+                       "last_layer_rows": "supervised positions only (same loss and gradients; LHRS_TAIL_ROWS_ONLY=0 computes all)" if os.environ.get("LHRS_TAIL_ROWS_ONLY", "1") != "0" else "all",
                        "grad_allreduce": a.comm_dtype if world > 1 else "none",
                        "dist_backend": (torch.distributed.get_backend() if world > 1 else None)},
             "loss": round(final_loss, 4),
