@@ -259,18 +259,16 @@ class InstructDatasetWithTaskId(InstructDataset):
         super().__init__(**kwargs)
 
     def load_dataset(self):
-        before = 0
-        for img_dir, ann in zip(self.img_dir, self.json_dir):
+        corpora = list(zip(self.img_dir, self.json_dir))
+        for img_dir, ann in corpora:
             n0 = len(self.img_list)
-            self.img_dir, self.json_dir, keep = [img_dir], [ann], (self.img_dir, self.json_dir)
+            self.img_dir, self.json_dir = [img_dir], [ann]
             try:
                 super().load_dataset()  # one corpus at a time: same records, same `random.sample` draws, in the same order
             finally:
-                self.img_dir, self.json_dir = keep
+                self.img_dir, self.json_dir = [c[0] for c in corpora], [c[1] for c in corpora]
             w = next((wt for key, wt in self.WEIGHT_DICT.items() if key in ann.stem), 0.5)
             self.sample_weight += [w] * (len(self.img_list) - n0)
-            before = n0
-        del before
 
     def post_process(self):
         for i, conv in enumerate(self.cap_list):
