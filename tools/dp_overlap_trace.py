@@ -43,7 +43,7 @@ def summarize(src, dst):
     trace = sorted(glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True))[-1]
     rows = list(csv.DictReader(open(trace)))
     ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", r.get("Queue_Id", "?"))) for r in rows))
-    comm = [e for e in ev if "ccl" in e[2].lower()]
+    comm = [e for e in ev if "nccl" in e[2].lower() or "rccl" in e[2].lower()]  # RCCL device kernels are named ncclDevKernel_* (NOT "rocclr" copies)
     mine = [e for e in ev if "anonymous namespace" in e[2] or "lhrs" in e[2]]
     # keep the last 3 steps (steady state): a step's first kernel is patchify
     marks = [e[0] for e in mine if "patchify_kernel" in e[2]]
@@ -59,6 +59,13 @@ def summarize(src, dst):
         per.append({"kernel": name[:70], "stream": stream, "us": round((ce - cs) / 1e3, 1), "us_concurrent_with_compute": round(min(ov, ce - cs) / 1e3, 1),
                     "concurrent_kernels": with_k[:6]})
     total = sum(ce - cs for cs, ce, _, _ in comm)
+    if not comm:
+        out = {"command": "rocprofv3 --kernel-trace --output-format csv -- python tools/dp_overlap_trace.py run", "rccl_kernels": 0,
+               "note": "a one-rank RCCL group launches no device kernel for an in-place all-reduce: the reducer's stream / event plumbing runs, but there is "
+                       "nothing to overlap - the overlap of communication with the pooler backward can only be traced with >= 2 devices"}
+        json.dump(out, open(dst, "w"), indent=1)
+        print(json.dumps(out))
+        return
     out = {"command": "rocprofv3 --kernel-trace --output-format csv -- python tools/dp_overlap_trace.py run (1 rank, RCCL, micro-batch 8, 4 LLaMA layers, bf16 buckets)",
            "steps_summarised": 3, "rccl_kernels": len(comm), "rccl_streams": sorted({c[3] for c in comm}), "compute_streams": sorted({m[3] for m in mine}),
            "rccl_us_total": round(total / 1e3, 1), "rccl_us_concurrent_with_engine_kernels": round(overlap / 1e3, 1),
