@@ -40,3 +40,23 @@ for name, M, out, inn, n in shapes:
     tot_t += n * t_tr
     tot_g += n * t_g
 print(f"per step: transposes {tot_t / 1e3:.2f} ms + GEMMs {tot_g / 1e3:.2f} ms")
+
+# alternative: the TN kernel of the LoRA path (tn_skinny: both operands transposed by LDS reads, no operand transposes) in chunks of <= 384 output rows
+print("--- same products through lhrs_gemm_tn_skinny in chunks of 256 output rows (no operand transposes)")
+tot = 0.0
+for name, M, out, inn, n in shapes:
+    dy = (torch.randn(M, out, device="cuda") * 0.1).to(torch.bfloat16)
+    x = torch.randn(M, inn, device="cuda").to(torch.bfloat16)
+    g = torch.empty(out, inn, device="cuda")
+    gref = torch.empty(out, inn, device="cuda")
+    Mp = hk.pad64(M)
+    hk.gemm_nt_splitk_f32(hk.transpose(dy, rows_pad=Mp), hk.transpose(x, rows_pad=Mp), gref)
+
+    def run():
+        for c0 in range(0, out, 256):
+            hk.gemm_tn_skinny(dy[:, c0:c0 + 256], x, g[c0:c0 + 256])
+    t = timeit(run)
+    err = ((g - gref).norm() / gref.norm()).item()
+    print(f"{name} tokens {M:6d} -> dW [{out}, {inn}]: {t:6.1f} us ({2.0 * M * out * inn / t / 1e6:6.1f} TF/s)  rel diff vs transposed path {err:.1e}")
+    tot += n * t
+print(f"per step: {tot / 1e3:.2f} ms")
