@@ -74,6 +74,13 @@ int lhrs_gemm_bf16_nt_skinny(const void* A, int lda, const void* B, int ldb, voi
  * tokens (what autograd computes for nn.Linear / nn.MultiheadAttention in common_arch.py:93-173,302-333): K split across blocks into
  * f32 slabs of `workspace` (lhrs_gemm_splitk_splits(M, N, K) * M * N floats; may be NULL when that is 1), summed in a fixed order. */
 int lhrs_gemm_splitk_splits(int M, int N, int K);
+/* The same weight gradients straight from the TOKEN-major operands: C[Mo, No] f32 = P[T, Mo]^T . Q[T, No] (P = dY, Q = X as they lie in
+ * HBM; both MFMA operands are formed by transposing LDS reads, no transposed copies are written).  Mo, No multiples of 128, ldp / ldq
+ * multiples of 8; the token range is split lhrs_gemm_tn_splits() ways into f32 slabs of `workspace` (splits * Mo * No floats; may be
+ * NULL when that is 1) summed in a fixed order. */
+int lhrs_gemm_tn_splits(int T, int Mo, int No);
+int lhrs_gemm_tn_f32(const void* P, long ldp, const void* Q, long ldq, float* C, long ldc, int T, int Mo, int No, float* workspace,
+                     void* stream);
 int lhrs_gemm_bf16_nt_splitk_f32(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
                                  float* workspace, void* stream);
 /* LLaMA MLP with SwiGLU fused into the GEMM epilogues (HF LlamaMLP.forward: down(silu(gate(x)) * up(x)); text_modal.py:258-294).

@@ -158,6 +158,19 @@ def gemm_nt_splitk_f32(a, b, out):
     return out
 
 
+def gemm_tn_f32(p, q, out):
+    """out[Mo, No] fp32 = p[T, Mo]^T @ q[T, No] - weight gradients dW = dY^T X from the token-major operands as they lie (no transposes).
+    Mo, No multiples of 128; row strides free (multiples of 8)."""
+    T, Mo = p.shape
+    No = q.shape[1]
+    L = _L()
+    splits = L.lhrs_gemm_tn_splits(T, Mo, No)
+    ws = torch.empty(splits * Mo * No, device=p.device, dtype=torch.float32) if splits > 1 else None
+    st = L.lhrs_gemm_tn_f32(p.data_ptr(), p.stride(0), q.data_ptr(), q.stride(0), out.data_ptr(), out.stride(0), T, Mo, No, _p(ws), _stream())
+    _lib.check(st, "gemm_tn_f32")
+    return out
+
+
 class BatchedTranspose:
     """out_i = in_i^T for a fixed list of (in, out) bf16 matrix pairs, refreshed by ONE launch (lhrs_transpose_batched)."""
 

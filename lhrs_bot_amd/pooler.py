@@ -20,6 +20,11 @@ STAGE_NUM = (64, 48, 32)       # common_arch.py:104
 SPLIT_PART = (256, 256, 256)   # common_arch.py:105
 
 
+import os as _os
+
+_DW_TN = _os.environ.get("LHRS_DW_TRANSPOSED", "0") != "1"
+
+
 class AttnPooler:
     def __init__(self, num_query=144, num_layers=6, num_attention_heads=16, encoder_hidden_size=1024, hidden_size=1024,
                  output_size=4096, device="cuda", **_unused):
@@ -198,11 +203,15 @@ class AttnPooler:
 
     # ------------------------------------------------------------------ backward
     def _dw(self, name: str, dy: torch.Tensor, x: torch.Tensor, rows=None) -> None:
-        """grad[name] (rows slice) = dy^T @ x as an NT GEMM over token-transposed, zero-padded operands."""
+        """grad[name] (rows slice) = dy^T @ x, straight from the token-major operands (lhrs_gemm_tn_f32: transposing LDS reads, token range
+        split into f32 slabs, ordered sum); LHRS_DW_TRANSPOSED=1 takes the round-1 path (transposed copies + NT split-K GEMM)."""
+        g = self.g[name] if rows is None else self.g[name][rows[0]: rows[1]]
+        if _DW_TN and g.shape[0] % 128 == 0 and g.shape[1] % 128 == 0 and dy.stride(1) == 1 and x.stride(1) == 1:
+            hk.gemm_tn_f32(dy, x, g)
+            return
         Mp = hk.pad64(dy.shape[0])
         dyT = hk.transpose(dy, rows_pad=Mp)
         xT = hk.transpose(x, rows_pad=Mp)
-        g = self.g[name] if rows is None else self.g[name][rows[0]: rows[1]]
         hk.gemm_nt_splitk_f32(dyT, xT, g)  # K = padded token count (B * 912 for the kv projection): split across blocks, ordered sum
 
     def backward(self, d_out: torch.Tensor, on_ready=None) -> None:

@@ -578,3 +578,29 @@ def test_attention_backward_with_fused_inverse_rope_is_bit_identical(S, B, H):
     torch.cuda.synchronize()
     assert torch.equal(got, ref)
     assert torch.equal(got[:, 2 * d:], plain[:, 2 * d:]) and not torch.equal(got[:, :2 * d], plain[:, :2 * d])   # dv untouched, dq / dk rotated
+
+
+@pytest.mark.parametrize("T,Mo,No", [(4320, 1024, 1024), (27360, 2048, 1024), (4320, 4096, 1024), (130, 128, 256), (64, 128, 128), (4321, 1024, 4096)])
+def test_gemm_tn_f32_weight_gradient_from_token_major_operands(T, Mo, No):
+    """lhrs_gemm_tn_f32: dW[out, in] = dY^T X straight from the token-major operands (transposing LDS reads) vs the fp64 product, and vs the
+    round-1 path (transposed copies + NT split-K GEMM) it replaces; partial last 64-token stage (zero fill), strided operands, and a
+    transpose-detecting input (out != in, asymmetric values)."""
+    g = torch.Generator().manual_seed(T + Mo)
+    big = bf(torch.randn(T, Mo + 64, generator=g) * 0.1).to(DEV)
+    dy = big[:, :Mo]                                    # row stride Mo + 64: a column slice of a wider buffer
+    x = bf(torch.randn(T, No, generator=g)).to(DEV)
+    out = torch.full((Mo + 8, No), float("nan"), device=DEV)
+    hk.gemm_tn_f32(dy, x, out[4:4 + Mo])
+    torch.cuda.synchronize()
+    ref = dy.double().t() @ x.double()
+    assert rel_err(out[4:4 + Mo], ref) < 2e-6                                  # exact bf16 products, fp32 accumulation
+    assert torch.isnan(out[:4]).all() and torch.isnan(out[4 + Mo:]).all()      # nothing outside the target rows is touched
+    Mp = hk.pad64(T)
+    old = torch.empty(Mo, No, device=DEV)
+    hk.gemm_nt_splitk_f32(hk.transpose(dy.contiguous(), rows_pad=Mp), hk.transpose(x, rows_pad=Mp), old)
+    assert rel_err(out[4:4 + Mo], old) < 2e-6
+    again = torch.empty(Mo, No, device=DEV)
+    hk.gemm_tn_f32(dy, x, again)
+    assert torch.equal(again, out[4:4 + Mo])                                   # ordered slab sum: bit-reproducible
+    with pytest.raises(RuntimeError):
+        hk.gemm_tn_f32(dy[:, :Mo - 64], x, torch.empty(Mo - 64, No, device=DEV))   # Mo % 128 != 0 is rejected at the ABI

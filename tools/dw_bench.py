@@ -41,6 +41,17 @@ for name, M, out, inn, n in shapes:
     tot_g += n * t_g
 print(f"per step: transposes {tot_t / 1e3:.2f} ms + GEMMs {tot_g / 1e3:.2f} ms")
 
+print("--- lhrs_gemm_tn_f32 (token-major operands, transposing LDS reads, token-split slabs)")
+tot = 0.0
+for name, M, out, inn, n in shapes:
+    dy = (torch.randn(M, out, device="cuda") * 0.1).to(torch.bfloat16)
+    x = torch.randn(M, inn, device="cuda").to(torch.bfloat16)
+    g = torch.empty(out, inn, device="cuda")
+    t = timeit(lambda: hk.gemm_tn_f32(dy, x, g))
+    print(f"{name} tokens {M:6d} -> dW [{out}, {inn}]: {t:6.1f} us ({2.0 * M * out * inn / t / 1e6:6.1f} TF/s)")
+    tot += n * t
+print(f"per step: {tot / 1e3:.2f} ms")
+
 # alternative: the TN kernel of the LoRA path (tn_skinny: both operands transposed by LDS reads, no operand transposes) in chunks of <= 384 output rows
 print("--- same products through lhrs_gemm_tn_skinny in chunks of 256 output rows (no operand transposes)")
 tot = 0.0
