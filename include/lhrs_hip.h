@@ -281,6 +281,16 @@ int lhrs_decode_attn(const void* qkv, long ld, void* kcache, void* vcache, const
 long lhrs_clip_preprocess_workspace(int H, int W);
 int lhrs_clip_preprocess(const unsigned char* img, int H, int W, long row_stride, float* out, void* workspace,
                          long workspace_bytes, void* stream);
+/* General form of the same three kernels: Pillow BICUBIC resize of the short edge to `short_edge` (>= 224), 224x224 centre crop whose
+ * offset is floor((n - 224) / 2) (crop_round 0: HF `center_crop`) or Python round((n - 224) / 2.0) (crop_round 1: torchvision
+ * `CenterCrop`), byte -> float32 as float32(float64(b) / 255) (rescale_mode 0: HF) or float32(b) / 255.f (rescale_mode 1: torchvision
+ * `ToTensor`), then (x - mean[c]) / std[c] in float32.  mean / std: HOST pointers to 3 floats.  Replaces the evaluation transform of the
+ * classification caller - lhrs/Dataset/build_transform.py:27-40 `build_cls_transform(is_train=False)` = Resize(256) -> CenterCrop(224) ->
+ * ToTensor -> Normalize(ImageNet), reached from lhrs/Dataset/build_loader.py:164-199 `build_zero_shot_loader` (main_cls.py:133) - with
+ * short_edge 256, crop_round 1, rescale_mode 1. */
+long lhrs_image_preprocess_workspace(int H, int W, int short_edge);
+int lhrs_image_preprocess(const unsigned char* img, int H, int W, long row_stride, float* out, void* workspace, long workspace_bytes,
+                          int short_edge, int crop_round, int rescale_mode, const float* mean, const float* stdv, void* stream);
 
 #ifdef __cplusplus
 }

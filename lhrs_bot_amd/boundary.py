@@ -151,6 +151,12 @@ def setup_logger(name: Optional[str] = None, output: Optional[str] = None, log_l
     return lg
 
 
+def init_distributed(auto: bool = False) -> Tuple[int, int, int]:
+    """lhrs/CustomTrainer/utils/distribute.py:525-560, the evaluation scripts' variant: same environment contract and return value as
+    `deepspeed_init_distributed`; `auto` (pick a free MASTER_PORT) is accepted - torchrun already hands every rank a free port."""
+    return deepspeed_init_distributed()
+
+
 def deepspeed_init_distributed() -> Tuple[int, int, int]:
     """(rank, local_rank, world_size) from the launcher's environment (torchrun / `deepspeed --num_gpus` export RANK, WORLD_SIZE,
     LOCAL_RANK; SLURM_PROCID / SLURM_NTASKS otherwise); one process per GPU, process group = RCCL ("nccl") over xGMI, barrier, device

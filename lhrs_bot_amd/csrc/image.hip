@@ -11,6 +11,10 @@
 //   2. hpass_kernel    - horizontal pass for the 224 crop columns of every input row -> uint8 [H][224][3]
 //   3. vpass_kernel    - vertical pass for the 224 crop rows + table lookup -> float32 planar output
 // A pass whose size does not change is the identity in Pillow (it is skipped); here it is a one-tap window with coefficient 2^22.
+//
+// `lhrs_image_preprocess` is the general entry: short edge -> `short_edge`, crop-offset rule and rescale arithmetic selectable, so that
+// the evaluation transform of the classification caller (lhrs/Dataset/build_transform.py:27-40: torchvision Resize(256, BICUBIC) ->
+// CenterCrop(224) -> ToTensor -> Normalize(ImageNet mean / std), used by build_zero_shot_loader) runs on the same three kernels.
 #include "common.h"
 
 namespace {
@@ -108,16 +112,23 @@ __global__ void vpass_kernel(const unsigned char* __restrict__ tmp, const int* _
   out[o + 2 * CROP * CROP] = lut.v[2][clip8(s2)];
 }
 
-void plan(int H, int W, Axis& ax, Axis& ay) {
-  int nh, nw;  // HF get_resize_output_image_size(shortest_edge = 224, default_to_square = False)
-  if (H <= W) { nh = CROP; nw = (int)((double)CROP * W / H); } else { nh = (int)((double)CROP * H / W); nw = CROP; }
+// first row / column of the 224 crop window inside a resized axis of n pixels: HF `center_crop` floors (n - 224) / 2, torchvision's
+// `CenterCrop` takes Python's round((n - 224) / 2.0) (half to even)
+int crop_offset(int n, int crop_round) {
+  const int d = n - CROP, k = d / 2;
+  return (crop_round == 1 && (d & 1) && (k & 1)) ? k + 1 : k;
+}
+
+void plan(int H, int W, int short_edge, int crop_round, Axis& ax, Axis& ay) {
+  int nh, nw;  // HF get_resize_output_image_size(shortest_edge, default_to_square = False) == torchvision Resize(int): long = int(size * long / short)
+  if (H <= W) { nh = short_edge; nw = (int)((double)short_edge * W / H); } else { nh = (int)((double)short_edge * H / W); nw = short_edge; }
   auto ks = [](int in, int out) {
     double fs = (double)in / (double)out;
     if (fs < 1.0) fs = 1.0;
     return (int)ceil(2.0 * fs) * 2 + 1;
   };
-  ax = Axis{W, nw, (nw - CROP) / 2, ks(W, nw)};
-  ay = Axis{H, nh, (nh - CROP) / 2, ks(H, nh)};
+  ax = Axis{W, nw, crop_offset(nw, crop_round), ks(W, nw)};
+  ay = Axis{H, nh, crop_offset(nh, crop_round), ks(H, nh)};
 }
 
 long ws_bytes(int H, const Axis& ax, const Axis& ay) {
@@ -127,24 +138,29 @@ long ws_bytes(int H, const Axis& ax, const Axis& ay) {
 
 }  // namespace
 
-extern "C" long lhrs_clip_preprocess_workspace(int H, int W) {
-  if (H <= 0 || W <= 0) return -1;
+extern "C" long lhrs_image_preprocess_workspace(int H, int W, int short_edge) {
+  if (H <= 0 || W <= 0 || short_edge < CROP) return -1;
   Axis ax, ay;
-  plan(H, W, ax, ay);
+  plan(H, W, short_edge, 0, ax, ay);
   return ws_bytes(H, ax, ay);
 }
 
-extern "C" int lhrs_clip_preprocess(const unsigned char* img, int H, int W, long row_stride, float* out, void* workspace,
-                                    long workspace_bytes, void* stream) {
-  LHRS_REQUIRE(img != nullptr && out != nullptr && workspace != nullptr, "clip_preprocess: null pointer");
-  LHRS_REQUIRE(H > 0 && W > 0 && row_stride >= 3L * W, "clip_preprocess: H=%d W=%d row_stride=%ld", H, W, row_stride);
+extern "C" long lhrs_clip_preprocess_workspace(int H, int W) { return lhrs_image_preprocess_workspace(H, W, CROP); }
+
+extern "C" int lhrs_image_preprocess(const unsigned char* img, int H, int W, long row_stride, float* out, void* workspace,
+                                     long workspace_bytes, int short_edge, int crop_round, int rescale_mode, const float* mean,
+                                     const float* stdv, void* stream) {
+  LHRS_REQUIRE(img != nullptr && out != nullptr && workspace != nullptr && mean != nullptr && stdv != nullptr, "image_preprocess: null pointer");
+  LHRS_REQUIRE(H > 0 && W > 0 && row_stride >= 3L * W, "image_preprocess: H=%d W=%d row_stride=%ld", H, W, row_stride);
+  LHRS_REQUIRE(short_edge >= CROP && (crop_round == 0 || crop_round == 1) && (rescale_mode == 0 || rescale_mode == 1),
+               "image_preprocess: short_edge=%d (>= 224) crop_round=%d rescale_mode=%d", short_edge, crop_round, rescale_mode);
   Axis ax, ay;
-  plan(H, W, ax, ay);
-  LHRS_REQUIRE(workspace_bytes >= ws_bytes(H, ax, ay), "clip_preprocess: workspace %ld < %ld bytes", workspace_bytes, ws_bytes(H, ax, ay));
-  static const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f}, stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+  plan(H, W, short_edge, crop_round, ax, ay);
+  LHRS_REQUIRE(workspace_bytes >= ws_bytes(H, ax, ay), "image_preprocess: workspace %ld < %ld bytes", workspace_bytes, ws_bytes(H, ax, ay));
   Lut lut;
   for (int b = 0; b < 256; ++b) {
-    const float r = (float)((double)b * 0.00392156862745098);  // np rescale: float64 product, then float32
+    // mode 0: numpy rescale of HF's image processor (float64 product, then float32); mode 1: torchvision ToTensor (float32 division)
+    const float r = rescale_mode == 0 ? (float)((double)b * 0.00392156862745098) : (float)b / 255.0f;
     for (int c = 0; c < 3; ++c) lut.v[c][b] = (r - mean[c]) / stdv[c];
   }
   int* bounds = (int*)workspace;
@@ -158,4 +174,10 @@ extern "C" int lhrs_clip_preprocess(const unsigned char* img, int H, int W, long
   hipLaunchKernelGGL(vpass_kernel, dim3(1, CROP), dim3(256), 0, s, tmp, bounds + CROP * 2, kk + (long)CROP * ax.ksize, ay.ksize, lut, out);
   LHRS_CHECK_LAUNCH("clip_preprocess_v");
   return 0;
+}
+
+extern "C" int lhrs_clip_preprocess(const unsigned char* img, int H, int W, long row_stride, float* out, void* workspace,
+                                    long workspace_bytes, void* stream) {
+  static const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f}, stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+  return lhrs_image_preprocess(img, H, W, row_stride, out, workspace, workspace_bytes, CROP, 0, 0, mean, stdv, stream);
 }

@@ -10,7 +10,7 @@ object with `__call__(text).input_ids`, `bos_token_id`, `pad_token_id`, `model_m
 from __future__ import annotations
 
 import copy
-from typing import Callable, Dict, List, Optional, Sequence
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -216,16 +216,16 @@ class _Features(dict):
     __getattr__ = dict.__getitem__
 
 
-class CLIPImageProcessorHIP:
-    """Drop-in for the transform `build_vlp_transform` returns for the ViT arch (lhrs/Dataset/build_transform.py:43-45, HF
-    `CLIPImageProcessor`): `.preprocess(images, return_tensors="pt")["pixel_values"]` -> float32 [B, 3, 224, 224] ON THE DEVICE,
-    bit-exact with the PIL pipeline (resize short edge 224 BICUBIC, center crop, /255, CLIP mean/std) but computed by
-    `lhrs_clip_preprocess`: the DataLoader only has to decode and ship uint8 pixels.  Accepts PIL images, uint8 HWC numpy
+class DeviceImageTransform:
+    """An image transform whose arithmetic runs on the GPU for a whole batch (`lhrs_image_preprocess`): a dataset that is handed one of
+    these only DECODES in its workers (PIL -> uint8 HWC tensor); `preprocess` turns decoded pictures into float32 [B, 3, 224, 224]
+    pixel values on the device.  Subclasses fix the parameters of the pipeline they stand in for.  Accepts PIL images, uint8 HWC numpy
     arrays or uint8 HWC tensors (host or device)."""
 
     crop_size = {"height": 224, "width": 224}
-    image_mean = (0.48145466, 0.4578275, 0.40821073)
-    image_std = (0.26862954, 0.26130258, 0.27577711)
+    short_edge, crop_round, rescale_mode = 224, 0, 0
+    image_mean: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    image_std: Tuple[float, float, float] = (1.0, 1.0, 1.0)
 
     def __init__(self, device="cuda"):
         from . import _lib
@@ -246,11 +246,39 @@ class CLIPImageProcessorHIP:
 
     def preprocess(self, images, return_tensors="pt", **_kw) -> Dict[str, torch.Tensor]:
         from . import kernels as hk
+        if torch.is_tensor(images) and images.dim() == 4:
+            images = list(images)
         if not isinstance(images, (list, tuple)):
             images = [images]
         out = torch.empty((len(images), 3, 224, 224), device=self.device, dtype=torch.float32)
         for b, im in enumerate(images):
-            hk.clip_preprocess(self._to_u8(im), out=out[b])
+            hk.image_preprocess(self._to_u8(im), out=out[b], short_edge=self.short_edge, crop_round=self.crop_round, rescale_mode=self.rescale_mode,
+                                mean=self.image_mean, std=self.image_std)
         return _Features(pixel_values=out)
 
     __call__ = preprocess
+
+
+class CLIPImageProcessorHIP(DeviceImageTransform):
+    """Drop-in for the transform `build_vlp_transform` returns for the ViT arch (lhrs/Dataset/build_transform.py:43-45, HF
+    `CLIPImageProcessor`): `.preprocess(images, return_tensors="pt")["pixel_values"]` -> float32 [B, 3, 224, 224] ON THE DEVICE,
+    bit-exact with the PIL pipeline (resize short edge 224 BICUBIC, center crop, /255, CLIP mean/std)."""
+
+    image_mean = (0.48145466, 0.4578275, 0.40821073)
+    image_std = (0.26862954, 0.26130258, 0.27577711)
+
+
+class ClsEvalTransformHIP(DeviceImageTransform):
+    """`build_cls_transform(config, is_train=False)` (lhrs/Dataset/build_transform.py:27-40), the transform of the zero-shot
+    classification loader: torchvision Resize(int(224 / (224 / 256)) = 256, BICUBIC) -> CenterCrop(224) -> ToTensor -> Normalize with the
+    ImageNet mean / std.  `pixels(images)` -> float32 [B, 3, 224, 224] on the device."""
+
+    short_edge, crop_round, rescale_mode = 256, 1, 1
+    image_mean = (0.485, 0.456, 0.406)
+    image_std = (0.229, 0.224, 0.225)
+
+    def __init__(self, device="cuda", input_size=(224, 224)):
+        size = input_size if isinstance(input_size, (list, tuple)) else (input_size, input_size)
+        if tuple(size)[-2:] != (224, 224):
+            raise ValueError(f"transform.input_size {input_size}: the device transform crops 224 x 224 (every shipped YAML)")
+        super().__init__(device)

@@ -26,7 +26,8 @@ from typing import Callable, Dict, Iterator, List, Optional, Tuple
 import torch
 
 from . import conversation as conversation_lib
-from .data import (DEFAULT_IMAGE_TOKEN, CLIPImageProcessorHIP, DataCollatorForSupervisedDataset, preprocess, preprocess_multimodal)
+from .data import (DEFAULT_IMAGE_TOKEN, CLIPImageProcessorHIP, DataCollatorForSupervisedDataset, DeviceImageTransform, preprocess,
+                   preprocess_multimodal)
 
 logger = logging.getLogger("train")
 
@@ -129,7 +130,7 @@ class CaptionDataset(torch.utils.data.Dataset):
         img = Image.open(self.img_list[idx]).convert("RGB")
         if self.transform is None:
             return img
-        if isinstance(self.transform, CLIPImageProcessorHIP):
+        if isinstance(self.transform, DeviceImageTransform):
             import numpy as np
             return torch.from_numpy(np.array(img, copy=True))  # uint8 [H, W, 3]: decoded here, transformed on the device
         return self.transform(img)

@@ -5,6 +5,7 @@ of liblhrs_hip.so on the current HIP stream.
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Optional
 
 import torch
@@ -730,16 +731,31 @@ def adamw_step(p, g, m, v, shadow, step, lr, betas=(0.9, 0.95), eps=1e-8, wd=0.0
 
 
 # --------------------------------------------------------------------------------------------- data boundary (images)
-def clip_preprocess(img_u8: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
-    """uint8 [H, W, 3] device tensor -> float32 [3, 224, 224] pixel_values, bit-exact with CLIPImageProcessor (lhrs_clip_preprocess)."""
+CLIP_MEAN, CLIP_STD = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def image_preprocess(img_u8: torch.Tensor, out: torch.Tensor = None, short_edge: int = 224, crop_round: int = 0, rescale_mode: int = 0,
+                     mean=CLIP_MEAN, std=CLIP_STD) -> torch.Tensor:
+    """uint8 [H, W, 3] device tensor -> float32 [3, 224, 224]: Pillow-BICUBIC resize of the short edge to `short_edge`, centre crop,
+    byte -> float, (x - mean) / std (lhrs_image_preprocess; the defaults are CLIPImageProcessor, bit-exact)."""
     assert img_u8.dtype == torch.uint8 and img_u8.dim() == 3 and img_u8.shape[2] == 3 and img_u8.is_cuda and img_u8.stride(2) == 1 \
-        and img_u8.stride(1) == 3, "clip_preprocess: uint8 [H, W, 3] device tensor with packed pixels"
+        and img_u8.stride(1) == 3, "image_preprocess: uint8 [H, W, 3] device tensor with packed pixels"
     H, W = int(img_u8.shape[0]), int(img_u8.shape[1])
     if out is None:
         out = torch.empty((3, 224, 224), device=img_u8.device, dtype=torch.float32)
     assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == 3 * 224 * 224
-    nbytes = _L().lhrs_clip_preprocess_workspace(H, W)
+    nbytes = _L().lhrs_image_preprocess_workspace(H, W, short_edge)
+    if nbytes < 0:
+        raise ValueError(f"image_preprocess: H={H} W={W} short_edge={short_edge} (short_edge must be >= 224)")
     ws = torch.empty(nbytes, device=img_u8.device, dtype=torch.uint8)
-    st = _L().lhrs_clip_preprocess(img_u8.data_ptr(), H, W, img_u8.stride(0), out.data_ptr(), ws.data_ptr(), nbytes, _stream())
-    _lib.check(st, "clip_preprocess")
+    m, sd = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    st = _L().lhrs_image_preprocess(img_u8.data_ptr(), H, W, img_u8.stride(0), out.data_ptr(), ws.data_ptr(), nbytes, short_edge, crop_round,
+                                    rescale_mode, ctypes.cast(m, ctypes.c_void_p), ctypes.cast(sd, ctypes.c_void_p), _stream())
+    _lib.check(st, "image_preprocess")
     return out
+
+
+def clip_preprocess(img_u8: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """uint8 [H, W, 3] device tensor -> float32 [3, 224, 224] pixel_values, bit-exact with CLIPImageProcessor."""
+    return image_preprocess(img_u8, out)
