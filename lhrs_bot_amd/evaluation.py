@@ -259,6 +259,65 @@ def save_result(result: List[Dict], result_dir: str, filename: str, remove_dupli
     return final
 
 
+def eval_parse_option(args=None, data_target: bool = False, data_type: bool = False):
+    """The argument parser the four evaluation scripts share (main_cls.py:65-123; main_vqa / main_vg / main_bench_gen add `--data-target`,
+    main_vqa / main_bench_gen `--data-type`), plus this engine's offline knobs."""
+    from .trainer import ConfigArgumentParser, ConfigDict, str2bool
+    p = ConfigArgumentParser()
+    p.add_argument("--opts", default=None, nargs="+", help="Modify config options by adding 'KEY VALUE' pairs.")
+    p.add_argument("--batch-size", type=int, help="batch size for single GPU")
+    p.add_argument("--data-path", type=str, help="path to dataset")
+    if data_target:
+        p.add_argument("--data-target", type=str, help="path to dataset annotation file ")
+    if data_type:
+        p.add_argument("--data-type", type=str, choices=["LR", "HR"], default="HR", help="VQA dataset type")
+    p.add_argument("--workers", type=int, default=8, help="workers of dataloader")
+    p.add_argument("--model-path", type=str, default=None, help="pretrained checkpoint path")
+    p.add_argument("--enable-amp", type=str2bool, default=False, help="mixed precision")
+    p.add_argument("--output", default="output", type=str, metavar="PATH", help="root of output folder")
+    p.add_argument("--seed", type=int, default=322, help="random seed")
+    p.add_argument("--use-checkpoint", action="store_true", help="accepted; nothing is recomputed in evaluation")
+    p.add_argument("--gpus", type=int, default=0, help="gpus ID")
+    p.add_argument("--inf_sampler", type=str2bool, default=False)
+    p.add_argument("--wandb", type=str2bool, default=False, help="wandb logger (not available offline: must stay False)")
+    p.add_argument("--entity", type=str, default="pumpkinn")
+    p.add_argument("--project", type=str, default="MaskIndexNet")
+    p.add_argument("--accelerator", default="gpu", type=str, choices=["cpu", "gpu", "mps"], help="accelerator (the engine is HIP: gpu)")
+    p.add_argument("--local_rank", type=int, help="local rank")
+    # knobs of this engine
+    p.add_argument("--tokenizer-path", type=str, default=None, help="directory holding the LLaMA-2 tokenizer files")
+    p.add_argument("--llama-layers", type=int, default=32, help="decoder layers to build (smoke runs)")
+    config = ConfigDict(p.parse_args(wandb=True, args=args))
+    opts = config.get("opts") or []
+    if len(opts) % 2:
+        p.error("--opts takes KEY VALUE pairs")
+    import yaml
+    for k, v in zip(opts[0::2], opts[1::2]):  # dotted keys descend into the YAML's sections: --opts eval.dataset UCM
+        node, *rest = config, *k.split(".")
+        for part in rest[:-1]:
+            node = node.setdefault(part, ConfigDict())
+        node[rest[-1]] = yaml.safe_load(v)
+    return config
+
+
+def eval_model(config):
+    """build_model -> dtype -> `--model-path` -> device check -> eval(), as every evaluation script opens (main_cls.py:126-148)."""
+    from .unibind import build_model
+    if config.get("accelerator", "gpu") != "gpu" or not torch.cuda.is_available():
+        raise RuntimeError("the evaluation scripts drive the HIP engine: they need --accelerator gpu and a visible MI355X (there is no CPU path)")
+    logger.info("Creating model")
+    model = build_model(config, activate_modal=("rgb", "text"))
+    if config.get("tokenizer_path"):
+        import transformers
+        model.text.tokenizer = transformers.AutoTokenizer.from_pretrained(config.tokenizer_path, use_fast=False)
+    return load_for_eval(model, config)
+
+
+def generation_weights(config) -> str:
+    """`bits: 8` in the YAML streams the e4m3 copies of the decoder weights through the MFMA GEMV (the reference loads LLM.int8 there)."""
+    return "fp8" if int(config.get("bits", 16) or 16) == 8 else "bf16"
+
+
 def load_for_eval(model, config):
     """The block every evaluation script repeats (main_cls.py:135-146): `--model-path` -> `custom_load_state_dict`, then eval mode."""
     path = config.get("model_path")

@@ -113,3 +113,24 @@ def clip_preprocess(img: np.ndarray, crop: int = 224):
     lut = normalise_lut()
     out = np.stack([lut[ch][c[:, :, ch]] for ch in range(3)], 0)
     return c, out
+
+
+def cls_eval_preprocess(img: np.ndarray, short: int = 256, crop: int = 224):
+    """The evaluation transform of the classification caller (/root/reference lhrs/Dataset/build_transform.py:27-40):
+    torchvision `Resize(256, BICUBIC)` -> `CenterCrop(224)` -> `ToTensor()` -> `Normalize(IMAGENET mean, std)` on a PIL image.
+
+    torchvision is absent from this image AND from /root/reference (pyproject pins torchvision==0.16.2): PARITY UNPINNED - restated from
+    torchvision 0.16's functional API: `resize` of a PIL image = `img.resize((new_w, new_h), BICUBIC)` with the short edge -> 256 and the
+    long edge int(256 * long / short) (an image whose short edge already is 256 is returned as is); `center_crop` takes
+    top = int(round((h - 224) / 2.0)), left likewise (Python rounding: half to even); `to_tensor` = uint8 -> float32, `.div(255)`;
+    `normalize` = `(x - mean) / std` in float32.  The resize itself is Pillow's (restated and pinned above).
+    [H, W, 3] uint8 -> float32 [3, 224, 224]."""
+    h, w = img.shape[:2]
+    nh, nw = resized_size(h, w, short)
+    r = resize_u8(img, nw, nh)
+    top, left = int(round((nh - crop) / 2.0)), int(round((nw - crop) / 2.0))
+    c = r[top:top + crop, left:left + crop].astype(np.float32)
+    x = (c / np.float32(255.0)).astype(np.float32)
+    mean = np.array((0.485, 0.456, 0.406), dtype=np.float32)
+    std = np.array((0.229, 0.224, 0.225), dtype=np.float32)
+    return np.ascontiguousarray(((x - mean) / std).astype(np.float32).transpose(2, 0, 1))

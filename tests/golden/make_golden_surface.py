@@ -1,7 +1,8 @@
 """tests/golden/import_surface.json: the Python surface the reference's entry scripts use, read from the
 reference's SOURCE with `ast` (nothing is imported or executed, no text is copied - only names):
 
-  * imports:    every `from lhrs... import a, b` of main_pretrain_stage{1,2,3}.py and cli_qa.py
+  * imports:    every `from lhrs... import a, b` of main_pretrain_stage{1,2,3}.py, cli_qa.py and the evaluation scripts
+                main_cls.py / main_vqa.py / main_vg.py / main_bench_gen.py
   * calls:      inside each script's `main()` (and its `__main__` block) every call with its positional count and keyword names, in order
   * signatures: parameter names (and which have defaults) of the functions / methods those calls land on, from the lhrs/ sources
 
@@ -12,7 +13,8 @@ import os
 
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
-SCRIPTS = ["main_pretrain_stage1.py", "main_pretrain_stage2.py", "main_pretrain_stage3.py", "cli_qa.py"]
+SCRIPTS = ["main_pretrain_stage1.py", "main_pretrain_stage2.py", "main_pretrain_stage3.py", "cli_qa.py",
+           "main_cls.py", "main_vqa.py", "main_vg.py", "main_bench_gen.py"]  # the last four: the evaluation callers of generate (§8 f-3)
 
 
 def dotted(node):
@@ -88,6 +90,19 @@ SIGS = {
     "Conversation.get_prompt": ("lhrs/Dataset/conversation.py", "Conversation.get_prompt"),
     "Conversation.copy": ("lhrs/Dataset/conversation.py", "Conversation.copy"),
     "ConfigArgumentParser.parse_args": ("lhrs/CustomTrainer/utils/config_parser.py", "ConfigArgumentParser.parse_args"),
+    # evaluation callers (§8 f-3)
+    "lhrs.CustomTrainer.init_distributed": ("lhrs/CustomTrainer/utils/distribute.py", "init_distributed"),
+    "lhrs.Dataset.build_loader.build_zero_shot_loader": ("lhrs/Dataset/build_loader.py", "build_zero_shot_loader"),
+    "lhrs.Dataset.build_transform.build_cls_transform": ("lhrs/Dataset/build_transform.py", "build_cls_transform"),
+    "lhrs.Dataset.UCM.UCM": ("lhrs/Dataset/UCM.py", "UCM.__init__"),
+    "lhrs.Dataset.millionaid_eval.MillionAidEval": ("lhrs/Dataset/millionaid_eval.py", "MillionAidEval.__init__"),
+    "lhrs.Dataset.ImageFolderInstance.ImageFolderInstance": ("lhrs/Dataset/ImageFolderInstance.py", "ImageFolderInstance.__init__"),
+    "lhrs.Dataset.meterml.METERMLDataset": ("lhrs/Dataset/meterml.py", "METERMLDataset.__init__"),
+    "lhrs.Dataset.rsvqa.RSVQA": ("lhrs/Dataset/rsvqa.py", "RSVQA.__init__"),
+    "lhrs.Dataset.rsvqa.RSVQALR": ("lhrs/Dataset/rsvqa.py", "RSVQALR.__init__"),
+    "lhrs.Dataset.rsvqa.RSVQAHR": ("lhrs/Dataset/rsvqa.py", "RSVQAHR.__init__"),
+    "lhrs.Dataset.cap_dataset.VGEvalDataset": ("lhrs/Dataset/cap_dataset.py", "VGEvalDataset.__init__"),
+    "lhrs.Dataset.cap_dataset.CapEvalDataset": ("lhrs/Dataset/cap_dataset.py", "CapEvalDataset.__init__"),
 }
 
 out = {"scripts": {s: script_surface(os.path.join(REF, s)) for s in SCRIPTS},

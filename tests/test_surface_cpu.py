@@ -1,7 +1,7 @@
 """CPU: the reference's import block and call sequence replayed against this repo's `lhrs` package.
 
 tests/golden/import_surface.json holds, read from the reference's sources with `ast` (make_golden_surface.py): every `from lhrs... import`
-of main_pretrain_stage{1,2,3}.py / cli_qa.py, every call inside their `main()` with its positional count and keyword names, and the
+of main_pretrain_stage{1,2,3}.py / cli_qa.py / main_cls.py / main_vqa.py / main_vg.py / main_bench_gen.py, every call inside their `main()` with its positional count and keyword names, and the
 parameter names of the functions those calls land on.  Here: (1) every imported name resolves, (2) every call binds to this repo's
 callable, (3) every reference parameter is accepted under the same name.  What the calls COMPUTE is the GPU suites' business
 (tests/test_surface_gpu.py runs the same sequence on a tiny model)."""
@@ -28,10 +28,10 @@ def _resolve(script, callee):
         if callee in imp["names"]:
             return getattr(importlib.import_module(imp["module"]), callee)
     head, _, tail = callee.partition(".")
-    table = {"model": UniBind, "trainer": Trainer, "conv": Conversation, "default_conversation": Conversation}
+    table = {"model": UniBind, "trainer": Trainer, "conv": Conversation, "default_conversation": Conversation, "dummy_conv": Conversation}
     if callee == "deepspeed.initialize":
         return initialize  # the ONE substitution: `from lhrs.CustomTrainer import initialize`
-    if callee == "vision_processor":
+    if callee in ("vision_processor", "vis_transform"):
         return CLIPImageProcessorHIP.__call__
     if head in table and tail and "." not in tail:
         return getattr(table[head], tail, "MISSING")
@@ -76,7 +76,13 @@ def test_call_sequence_binds(script):
                                         "deepspeed_init_distributed", "setup_logger"},
             "cli_qa.py": {"build_model", "build_vlp_transform", "model.to", "default_conversation.copy", "model.custom_load_state_dict",
                           "vision_processor", "conv.append_message", "conv.get_prompt", "tokenizer_image_token", "KeywordsStoppingCriteria",
-                          "model.generate"}}
+                          "model.generate"},
+            "main_cls.py": {"build_model", "build_zero_shot_loader", "default_conversation.copy", "conv.append_message", "conv.get_prompt",
+                            "tokenizer_image_token", "model.generate", "model.custom_load_state_dict", "init_distributed", "setup_logger"},
+            "main_vqa.py": {"build_model", "RSVQAHR", "RSVQALR", "DataCollatorForVQASupervisedDataset", "model.generate", "is_main_process", "init_distributed"},
+            "main_vg.py": {"build_model", "VGEvalDataset", "DataCollatorForVGSupervisedDataset", "model.generate", "is_main_process", "init_distributed"},
+            "main_bench_gen.py": {"build_model", "default_conversation.copy", "dummy_conv.append_message", "dummy_conv.get_prompt", "tokenizer_image_token",
+                                  "vis_transform", "model.generate", "init_distributed"}}
     for name in want.get(script, ()):
         assert name in checked, f"{script}: {name} was not exercised (fixture or resolver changed?)"
 
