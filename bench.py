@@ -280,6 +280,8 @@ def main():
         lib.lhrs_gemm_set_policy(a.gemm_policy)
     if os.environ.get("LHRS_GEMM_PERSISTENT"):  # kernel A/B tests only
         lib.lhrs_gemm_set_persistent(int(os.environ["LHRS_GEMM_PERSISTENT"]))
+    if os.environ.get("LHRS_GEMM_MFMA16"):  # kernel A/B tests only: 0 = the 32x32x16 kernel
+        lib.lhrs_gemm_set_mfma16(int(os.environ["LHRS_GEMM_MFMA16"]))
     if os.environ.get("LHRS_GEMM_MIN_TILES"):  # kernel A/B tests only
         lib.lhrs_gemm_set_min_tiles(int(os.environ["LHRS_GEMM_MIN_TILES"]))
     B, T = a.micro_batch, a.caption_tokens + 2

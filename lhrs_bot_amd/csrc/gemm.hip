@@ -798,6 +798,306 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256r_kernel(GemmArgs g) {
 #undef RDQ
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256x256 "s" variant: the r kernel (16 waves, persistent, two 64 KiB DMA stages) with the OTHER dense bf16 MFMA shape,
+// v_mfma_f32_16x16x32_bf16.  Per FLOP that instruction moves half the accumulator data of v_mfma_f32_32x32x16_bf16 (4 accumulator VGPRs per
+// 16 KFLOP instead of 16 per 32 KFLOP) and under the 1400 W package cap a loop of nothing but MFMAs on random bf16 sustains 2.00 PFLOP/s
+// with it against 1.78 PFLOP/s (tools/mfma_peak.hip, alternating 0.2 s runs) - the GEMM is power-bound, so the cheaper instruction is the
+// faster one.  A wave still owns 64x64 of the tile: 4x4 fragments of 16x16, one k-block = 32 k = 16 MFMAs, a stage = 2 k-blocks.  Fragment
+// registers are single-buffered and roll - a fragment is re-read for the next block right behind the last MFMA that uses it - 32 VGPRs, as
+// many as the r kernel's double-buffered 32x32 fragments; the MFMA order walks the 2x2 quadrants of the fragment grid (block 0: Q00 Q01 Q11 Q10,
+// block 1: Q01 Q00 Q10 Q11) so that every fragment has >= 7 MFMA slots between its re-read and its next use, and the waits are counted
+// (LDS returns in order).  Order, re-reads, waits, barrier and DMA slots are generated: tools/gen_gemm16_sched.py -> gemm_256s_sched.inc.  The LDS image,
+// its swizzle (conflict-free for 16-row x 4-chunk reads as well), the DMA, the barrier placement and the epilogue's read-back half are the
+// r kernel's; the accumulator layout (lane: m = lane & 15, n = 4 * (lane >> 4) + i) changes the staging writes only.
+// ------------------------------------------------------------------------------------------------
+#include "gemm_256s_sched.inc"
+__device__ __forceinline__ void lds_wait8(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int ACT, int EPI, bool K2P>
+__global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int A_BYTES = BM * BK * 2, STAGE = A_BYTES + BN * BK * 2;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int ntiles = g.tilesM * g.tilesN;
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // DMA: 64 pieces of 1 KiB per stage; wave w issues #4w..4w+3 (waves 0-7: A, 8-15: B) - identical to the r kernel
+  const bool isA = wave < 8;
+  const char* base1 = reinterpret_cast<const char*>(isA ? g.A : g.B);
+  const char* base2 = reinterpret_cast<const char*>(isA ? g.A2 : g.B2);
+  const long ld1 = isA ? g.lda : g.ldb, ld2 = isA ? g.lda2 : g.ldb2;
+  const int rmax = (isA ? g.M : g.N) - 1;
+  const int nk1 = g.K / BK;
+  const int nk = (g.K + (K2P ? g.K2 : 0)) / BK;  // >= 2 (host guarantees)
+  // global byte offsets of this lane's four DMA rows for tile (tm_, tn_); K2P: a second operand pair (the fused LoRA product) follows the
+  // first in the k-loop - a template parameter so that the plain product does not carry four more offset registers through the main loop
+  auto dma_rows = [&](int tm_, int tn_, unsigned (&o1)[4], unsigned (&o2)[K2P ? 4 : 1]) {
+    const int row0 = isA ? tm_ * BM : tn_ * BN;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ridx = (wave & 7) * 4 + j;
+      const int lchunk = (lane & 7) ^ ((((j & 1) << 2) + (lane >> 4)) & 7);
+      int row = min(row0 + ridx * 8 + (lane >> 3), rmax);
+      if (EPI == 1 && !isA) {  // B tile row r = 64*wn + 32*half + i  <-  weight row half*ff + tn*128 + wn*32 + i
+        const int r = ridx * 8 + (lane >> 3);
+        row = ((r >> 5) & 1) * g.ff + tn_ * 128 + (r >> 6) * 32 + (r & 31);
+      }
+      if (EPI == 3 && !isA && tn_ * BN < g.rope_cols) {  // B tile row r = 64*wn + 32*half + i  <-  head 2*tn + (wn >> 1), dim 64*half + 32*(wn & 1) + i
+        const int r = ridx * 8 + (lane >> 3);
+        row = tn_ * BN + ((r >> 7) << 7) + ((r >> 5) & 1) * 64 + ((r >> 6) & 1) * 32 + (r & 31);
+      }
+      o1[j] = (unsigned)(((long)row * ld1 + lchunk * 8) * 2);
+      if (K2P) o2[j] = (unsigned)(((long)row * ld2 + lchunk * 8) * 2);
+    }
+  };
+  const int dst0 = (isA ? 0 : A_BYTES) + (wave & 7) * 4096;
+  auto issue_to = [&](const unsigned (&o1)[4], const unsigned (&o2)[K2P ? 4 : 1], int kt, int buf, int j) {
+    // wave-uniform 64-bit base (SGPR pair) + the lane's 32-bit row offset: the saddr form of global_load_lds
+    const char* sp = (!K2P || kt < nk1) ? base1 + (long)kt * (BK * 2) : base2 + (long)(kt - nk1) * (BK * 2);
+    const char* p = sp + ((!K2P || kt < nk1) ? o1[j] : o2[K2P ? j : 0]);
+    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + buf * STAGE + dst0 + j * 1024), 16, 0, 0);
+  };
+
+  // fragment of 16 rows x 32 k: lane -> row (lane & 15), 16-byte chunk kb * 4 + (lane >> 4) of the 128-byte row (swizzled)
+  const int wm = wave >> 2, wn = wave & 3;
+  const int sw = ((lane & 15) >> 1) & 7;
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+  // LDS address of this lane's fragment row in buffer 0, k-block 0 (the fragment index is the instruction's immediate offset).  smem is the
+  // kernel's only LDS object (offset 0), so the other k-block is this address ^ 64 (chunk bit 2) and the other buffer ^ STAGE: every fragment
+  // address of the main loop is ONE v_xor of these two registers with a loop-variant scalar (nothing for the compiler to hoist and keep)
+  const unsigned a0 = lds0 + (wm * 64 + (lane & 15)) * 128 + (((lane >> 4)) ^ sw) * 16;
+  const unsigned b0 = lds0 + A_BYTES + (wn * 64 + (lane & 15)) * 128 + (((lane >> 4)) ^ sw) * 16;
+
+  int tm, tn;
+  tile_coords_lin(g, t, ntiles, tm, tn);
+  unsigned off1[4], off2[K2P ? 4 : 1];
+  dma_rows(tm, tn, off1, off2);
+  int pb = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) issue_to(off1, off2, 0, 0, j);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  bf16x8 A[4], B[4];
+#define RDQ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+#define SB __builtin_amdgcn_sched_barrier(0);
+#define MF(mi, ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[ni], A[mi], acc[mi][ni], 0, 0, 0); SB
+
+  for (;;) {
+    const int tnext = t + (int)gridDim.x;
+    const bool has_next = tnext < ntiles;  // workgroup-uniform
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // stage 0 of this tile is in LDS buffer pb; the barrier publishes it and ends the previous tile's epilogue reads of the other buffer
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue_to(off1, off2, 1, pb ^ 1, j);
+    {
+      const unsigned aa = a0 ^ (unsigned)(pb * STAGE), ba = b0 ^ (unsigned)(pb * STAGE);
+      RDQ(A[0], aa, 0); RDQ(A[1], aa, 2048); RDQ(A[2], aa, 4096); RDQ(A[3], aa, 6144);
+      RDQ(B[0], ba, 0); RDQ(B[1], ba, 2048); RDQ(B[2], ba, 4096); RDQ(B[3], ba, 6144);
+      lds_wait8(A, B);
+    }
+    // one stage = S_BLOCK0 (first 32 k; re-reads every fragment for the second 32 k of the same buffer) + S_BLOCK1 (the stage boundary -
+    // full wait, vmcnt, barrier: stage s + 1 is published and the buffer of stage s is free - then the second 32 k, behind whose first
+    // MFMAs the DMA of stage s + 2 goes into the freed buffer, and the re-reads from stage s + 1) - gemm_256s_sched.inc
+#define STAGE_S(s_)                                                                                             \
+    {                                                                                                           \
+      const unsigned so = (((s_) + pb) & 1) * STAGE, sn = so ^ STAGE;                                           \
+      { const unsigned aa = a0 ^ (so | 64u), ba = b0 ^ (so | 64u); S_BLOCK0(aa, ba) }                           \
+      { const unsigned aa = a0 ^ sn, ba = b0 ^ sn; S_BLOCK1(aa, ba) }                                           \
+    }
+#define ISS(j) issue_to(off1, off2, s + 2, (s + pb) & 1, j);
+    for (int s = 0; s < nk - 2; ++s) STAGE_S(s)
+#undef ISS
+    int ntm = 0, ntn = 0;
+    if (has_next) {  // this tile's DMA rows are not needed any more (its last stage is in flight): the offsets become the next tile's
+      tile_coords_lin(g, tnext, ntiles, ntm, ntn);
+      dma_rows(ntm, ntn, off1, off2);
+    }
+    // stage nk - 2: the buffer its barrier frees takes stage 0 of the NEXT tile
+#define ISS(j) if (has_next) issue_to(off1, off2, 0, (nk + pb) & 1, j);
+    STAGE_S(nk - 2)
+#undef ISS
+#undef STAGE_S
+    {  // last stage: nothing left to fetch behind it
+      const unsigned so = ((nk - 1 + pb) & 1) * STAGE;
+      { const unsigned aa = a0 ^ (so | 64u), ba = b0 ^ (so | 64u); S_BLOCK0(aa, ba) }
+      S_BLOCK1_FINAL(0, 0)
+    }
+
+    // accumulator element acc[mi][ni][i]: m = wm*64 + mi*16 + fr, n = wn*64 + ni*16 + fg*4 + i.
+    // Everything the epilogue derives from the lane id is derived from an opaque copy made HERE, per tile: otherwise those values are
+    // loop-invariant across tiles, get hoisted in front of the tile loop and sit in (or spill from) registers all through the main loop
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int fr = le & 15, fg = le >> 4;
+    if (g.out_f32) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int m = tm * BM + wm * 64 + mi * 16 + fr;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int n = tn * BN + wn * 64 + ni * 16 + fg * 4;
+          if (n >= g.N) continue;
+          store4<ACT>(g, m, n, acc[mi][ni]);
+        }
+      }
+    } else {
+      __builtin_amdgcn_s_barrier();  // every wave has read its last fragments: the last stage's buffer becomes the staging area
+      char* reg = smem + ((nk - 1 + pb) & 1) * STAGE + wave * 4096;  // [32 rows][64 cols] bf16, wave private, one pass per 32 rows
+      const bool rope_tile = EPI == 3 && tn * BN < g.rope_cols;
+      const int rsub = le >> 3, c = le & 7;
+      const int n = EPI == 1   ? (c < 4 ? 0 : g.ff) + tn * 128 + wn * 32 + (c & 3) * 8
+                    : rope_tile ? tn * BN + (wn >> 1) * 128 + (c < 4 ? 0 : 64) + (wn & 1) * 32 + (c & 3) * 8
+                                : tn * BN + wn * 64 + c * 8;
+      const int nlim = EPI == 2 ? g.ff : g.N;
+      const bool col_ok = n < nlim;
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        uint4 pre_a[4], pre_b[4];
+        if (EPI == 2 || (EPI == 0 && g.res)) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int m = tm * BM + wm * 64 + ps * 32 + i * 8 + rsub;
+            pre_a[i] = make_uint4(0, 0, 0, 0); pre_b[i] = make_uint4(0, 0, 0, 0);
+            if (m < g.M && col_ok) {
+              if (EPI == 2) {
+                pre_a[i] = *reinterpret_cast<const uint4*>(g.aux + (long)m * g.ld_aux + n);
+                pre_b[i] = *reinterpret_cast<const uint4*>(g.aux + (long)m * g.ld_aux + g.ff + n);
+              } else {
+                pre_a[i] = *reinterpret_cast<const uint4*>(g.res + (long)m * g.ldr + n);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int mi = ps * 2 + h;
+          const int row = h * 16 + fr;  // row inside this 32-row pass
+          if (rope_tile) {
+            // fragments ni = 0, 1 hold dims d = 32*(wn & 1) + 16*ni + 4*fg + i of the head, ni + 2 their rotate_half partners d + 64
+            const int pos = (tm * BM + wm * 64 + mi * 16 + fr) % g.rope_mod + g.rope_pos0;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+              const float4 c4 = *reinterpret_cast<const float4*>(g.rope_cos + (long)pos * 64 + (wn & 1) * 32 + ni * 16 + fg * 4);
+              const float4 s4 = *reinterpret_cast<const float4*>(g.rope_sin + (long)pos * 64 + (wn & 1) * 32 + ni * 16 + fg * 4);
+              const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w};
+              float o1[4], o2[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                rope_pair(bf2f(f2bf(acc[mi][ni][i] * g.alpha)), bf2f(f2bf(acc[mi][ni + 2][i] * g.alpha)), cv[i], sv[i], o1[i], o2[i]);
+              const int u = ni * 4 + fg;
+              *reinterpret_cast<uint2*>(reg + row * 128 + ((u ^ ((row & 7) << 1)) << 3)) = make_uint2(pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3]));
+              *reinterpret_cast<uint2*>(reg + row * 128 + (((8 + u) ^ ((row & 7) << 1)) << 3)) = make_uint2(pack2bf(o2[0], o2[1]), pack2bf(o2[2], o2[3]));
+            }
+          } else {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+              float v[4];
+              uint2 bb = make_uint2(0, 0);
+              if (EPI == 0 && g.bias) bb = *reinterpret_cast<const uint2*>(g.bias + min(tn * BN + wn * 64 + ni * 16 + fg * 4, g.N - 4));
+              const float bias_v[4] = {bflo(bb.x), bfhi(bb.x), bflo(bb.y), bfhi(bb.y)};
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                v[i] = acc[mi][ni][i] * g.alpha;
+                if (EPI == 0 && g.drop_thresh) {
+                  const long e = (long)(tm * BM + wm * 64 + mi * 16 + fr) * g.N + tn * BN + wn * 64 + ni * 16 + fg * 4 + i;
+                  v[i] = drop_keep(g.drop_seed, e, g.drop_thresh) ? v[i] * g.drop_scale : 0.f;
+                }
+                v[i] += bias_v[i];
+                if (ACT) v[i] = apply_act(v[i], ACT);
+              }
+              const int u = ni * 4 + fg;
+              *reinterpret_cast<uint2*>(reg + row * 128 + ((u ^ ((row & 7) << 1)) << 3)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+            }
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r32 = i * 8 + rsub;
+          const int m = tm * BM + wm * 64 + ps * 32 + r32;
+          uint4 val = *reinterpret_cast<const uint4*>(reg + r32 * 128 + ((c ^ (r32 & 7)) << 4));
+          if (m < g.M && col_ok) {
+            if (EPI == 2) {
+              const uint4 gq = pre_a[i], uq = pre_b[i];
+              float d[8], gg[8], uu[8], dg[8], du[8];
+              unpack8(val, d); unpack8(gq, gg); unpack8(uq, uu);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float sg = 1.f / (1.f + __expf(-gg[e]));
+                du[e] = d[e] * gg[e] * sg;
+                dg[e] = d[e] * uu[e] * sg * (1.f + gg[e] * (1.f - sg));
+              }
+              bf16_t* out = reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n;
+              *reinterpret_cast<uint4*>(out) = pack8(dg);
+              *reinterpret_cast<uint4*>(out + g.ff) = pack8(du);
+              continue;
+            }
+            if (EPI == 0 && g.res) {
+              const uint4 r = pre_a[i];
+              val.x = pack2bf(bflo(val.x) + bflo(r.x), bfhi(val.x) + bfhi(r.x));
+              val.y = pack2bf(bflo(val.y) + bflo(r.y), bfhi(val.y) + bfhi(r.y));
+              val.z = pack2bf(bflo(val.z) + bflo(r.z), bfhi(val.z) + bfhi(r.z));
+              val.w = pack2bf(bflo(val.w) + bflo(r.w), bfhi(val.w) + bfhi(r.w));
+            }
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n) = val;
+          }
+        }
+      }
+      if (EPI == 1) {
+        // second output: act = silu(gate) * up on the bf16-rounded gate / up (fragments ni = 0, 1 / ni + 2), staged [64][32]
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const int row = mi * 16 + fr;
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float gv = bf2f(f2bf(acc[mi][ni][i] * g.alpha)), uv = bf2f(f2bf(acc[mi][ni + 2][i] * g.alpha));
+              v[i] = silu(gv) * uv;
+            }
+            const int u = ni * 4 + fg;  // 8-byte unit 0..7 of the 64-byte row
+            *reinterpret_cast<uint2*>(reg + row * 64 + ((u ^ ((row & 3) << 1)) << 3)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int rsub4 = le >> 2, c4 = le & 3;
+        const int n2 = tn * 128 + wn * 32 + c4 * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = i * 16 + rsub4;
+          const int m = tm * BM + wm * 64 + row;
+          const uint4 val = *reinterpret_cast<const uint4*>(reg + row * 64 + ((c4 ^ (row & 3)) << 4));
+          if (m < g.M) *reinterpret_cast<uint4*>(g.aux_out + (long)m * g.ld_aux + n2) = val;
+        }
+      }
+    }
+    if (!has_next) break;
+    if (g.out_f32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    t = tnext; tm = ntm; tn = ntn;
+    pb = (pb + nk) & 1;
+  }
+#undef MF
+#undef SB
+#undef RDQ
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // e4m3 x e4m3 -> bf16 GEMM for FROZEN base weights in 8-bit (the reference trains stages 2/3 with `bits: 8` base weights,
@@ -1121,6 +1421,15 @@ static int g_gemm_allow_256 = 2;
 // workgroup b takes tiles b, b + grid, ...  0 = one workgroup per tile (kernel A/B tests: lhrs_gemm_set_persistent)
 static int g_gemm_persist = 1;
 extern "C" int lhrs_gemm_set_persistent(int on) { g_gemm_persist = on; return 0; }
+// MFMA shape of the 16-wave 256x256 kernel: 1 = v_mfma_f32_16x16x32_bf16 (gemm_nt_256s_kernel), 0 = v_mfma_f32_32x32x16_bf16 (gemm_nt_256r_kernel)
+static int g_gemm_mfma16 = 1;
+extern "C" int lhrs_gemm_set_mfma16(int on) { g_gemm_mfma16 = on; return 0; }
+#define LAUNCH_256(ACT_, EPI_, grid_, s_, g_)                                                                          \
+  do {                                                                                                                 \
+    if (g_gemm_mfma16 && (g_).K2 > 0) hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT_, EPI_, true>), grid_, dim3(1024), 0, s_, g_);   \
+    else if (g_gemm_mfma16) hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT_, EPI_, false>), grid_, dim3(1024), 0, s_, g_);              \
+    else hipLaunchKernelGGL((gemm_nt_256r_kernel<ACT_, EPI_>), grid_, dim3(1024), 0, s_, g_);                          \
+  } while (0)
 static int num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -1265,12 +1574,12 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
     g.tilesM = cdiv(M, 256); g.tilesN = cdiv(N, 256);
     const dim3 grid(g.tilesM * g.tilesN), blk(512);
     if (g_gemm_allow_256 == 2 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128) {
-      const dim3 blk16(1024), grid16 = grid_256r((long)g.tilesM * g.tilesN);
+      const dim3 grid16 = grid_256r((long)g.tilesM * g.tilesN);
       switch (act) {
-        case 0: hipLaunchKernelGGL((gemm_nt_256r_kernel<0>), grid16, blk16, 0, s, g); break;
-        case 1: hipLaunchKernelGGL((gemm_nt_256r_kernel<1>), grid16, blk16, 0, s, g); break;
-        case 2: hipLaunchKernelGGL((gemm_nt_256r_kernel<2>), grid16, blk16, 0, s, g); break;
-        default: hipLaunchKernelGGL((gemm_nt_256r_kernel<3>), grid16, blk16, 0, s, g); break;
+        case 0: LAUNCH_256(0, 0, grid16, s, g); break;
+        case 1: LAUNCH_256(1, 0, grid16, s, g); break;
+        case 2: LAUNCH_256(2, 0, grid16, s, g); break;
+        default: LAUNCH_256(3, 0, grid16, s, g); break;
       }
     } else {
       switch (act) {
@@ -1341,7 +1650,7 @@ extern "C" int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int
   g.tilesM = cdiv(M, 256); g.tilesN = ff / 128;
   hipStream_t s = (hipStream_t)stream;
   const int pslot = prof_count(M, 2 * ff, K + K2, 1, s);
-  hipLaunchKernelGGL((gemm_nt_256r_kernel<0, 1>), grid_256r((long)g.tilesM * g.tilesN), dim3(1024), 0, s, g);
+  LAUNCH_256(0, 1, grid_256r((long)g.tilesM * g.tilesN), s, g);
   prof_end(pslot, s);
   LHRS_CHECK_LAUNCH("gemm_swiglu_fwd");
   return 0;
@@ -1371,7 +1680,7 @@ extern "C" int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw
   g.epi = 3; g.rope_cos = cos_t; g.rope_sin = sin_t; g.rope_mod = pos_mod; g.rope_pos0 = pos0; g.rope_cols = rope_cols;
   g.tilesM = cdiv(M, 256); g.tilesN = cdiv(N, 256);
   const int pslot = prof_count(M, N, K + K2, 3, (hipStream_t)stream);
-  hipLaunchKernelGGL((gemm_nt_256r_kernel<0, 3>), grid_256r((long)g.tilesM * g.tilesN), dim3(1024), 0, (hipStream_t)stream, g);
+  LAUNCH_256(0, 3, grid_256r((long)g.tilesM * g.tilesN), (hipStream_t)stream, g);
   prof_end(pslot, (hipStream_t)stream);
   LHRS_CHECK_LAUNCH("gemm_rope_fwd");
   return 0;
@@ -1392,7 +1701,7 @@ extern "C" int lhrs_gemm_swiglu_bwd(const void* dY, int ldy, const void* WdT, in
   g.tilesM = cdiv(M, 256); g.tilesN = cdiv(ff, 256);
   hipStream_t s = (hipStream_t)stream;
   const int pslot = prof_count(M, ff, K + K2, 2, s);
-  hipLaunchKernelGGL((gemm_nt_256r_kernel<0, 2>), grid_256r((long)g.tilesM * g.tilesN), dim3(1024), 0, s, g);
+  LAUNCH_256(0, 2, grid_256r((long)g.tilesM * g.tilesN), s, g);
   prof_end(pslot, s);
   LHRS_CHECK_LAUNCH("gemm_swiglu_bwd");
   return 0;

@@ -5,6 +5,7 @@
 #include <string.h>
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+static int g_iters = 20000;
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, 2) void k(const bf16x8* in, float* out, int iters) {
   bf16x8 a[4], b[2];
@@ -24,8 +25,41 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k(const bf16x8* in, float* out,
   for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+// the other dense bf16 shape: 16x16x32 (half the accumulator traffic per FLOP, twice the operand traffic), same FLOPs per loop iteration
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void k16(const bf16x8* in, float* out, int iters) {
+  bf16x8 a[4], b[4];
+  for (int i = 0; i < 4; ++i) a[i] = in[threadIdx.x + i * 512];
+  for (int i = 0; i < 4; ++i) b[i] = in[(threadIdx.x + (4 + i) * 512) % (6 * 512)];
+  f32x4 acc[4][4];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+  }
+  float s = 0;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) s += acc[i][j][r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int WAVES> void run16(const bf16x8* din, float* dout, int blocks) {
+  const int iters = g_iters;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(k16<WAVES>, dim3(blocks), dim3(WAVES * 64), 0, 0, din, dout, 1000);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(k16<WAVES>, dim3(blocks), dim3(WAVES * 64), 0, 0, din, dout, iters);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  double flops = (double)blocks * WAVES * iters * 32 * 2.0 * 16 * 16 * 32;
+  printf("16x16x32 waves/block=%d blocks=%d: %.1f TFLOP/s (%.2f ms)\n", WAVES, blocks, flops / (ms * 1e-3) / 1e12, ms);
+}
 template <int WAVES> void run(const bf16x8* din, float* dout, int blocks) {
-  const int iters = 20000;
+  const int iters = g_iters;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipLaunchKernelGGL(k<WAVES>, dim3(blocks), dim3(WAVES * 64), 0, 0, din, dout, 1000);
   hipDeviceSynchronize();
@@ -36,16 +70,26 @@ template <int WAVES> void run(const bf16x8* din, float* dout, int blocks) {
   double flops = (double)blocks * WAVES * iters * 16 * 2.0 * 32 * 32 * 16;
   printf("waves/block=%d blocks=%d: %.1f TFLOP/s (%.2f ms)\n", WAVES, blocks, flops / (ms * 1e-3) / 1e12, ms);
 }
-int main() {
+int main(int argc, char** argv) {
   bf16x8* din; float* dout;
   size_t n = 6 * 512;
   short* h = (short*)malloc(n * 16);
   for (size_t i = 0; i < n * 8; ++i) { float f = (float)rand() / RAND_MAX * 2 - 1; unsigned u; memcpy(&u, &f, 4); h[i] = (short)(u >> 16); }
   hipMalloc(&din, n * 16); hipMemcpy(din, h, n * 16, hipMemcpyHostToDevice);
   hipMalloc(&dout, 4096 * 512 * 4);
+  if (argc > 1) g_iters = atoi(argv[1]);
+  if (argc > 2) {  // long alternating runs: which shape sustains more under the power cap
+    for (int r = 0; r < 4; ++r) { run<8>(din, dout, 256); run16<8>(din, dout, 256); }
+    return 0;
+  }
   run<8>(din, dout, 256);
   run<4>(din, dout, 256);
   run<8>(din, dout, 512);
+  run16<8>(din, dout, 256);
+  run16<4>(din, dout, 256);
+  run16<8>(din, dout, 512);
+  run<8>(din, dout, 256);
+  run16<8>(din, dout, 256);
   for (size_t i = 0; i < n * 8; ++i) h[i] = 0;
   hipMemcpy(din, h, n * 16, hipMemcpyHostToDevice);
   printf("zero operands:\n");
