@@ -1099,6 +1099,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
 }
 
 
+
 // ------------------------------------------------------------------------------------------------
 // e4m3 x e4m3 -> bf16 GEMM for FROZEN base weights in 8-bit (the reference trains stages 2/3 with `bits: 8` base weights,
 // lhrs/models/text_modal.py:91-131 -> bitsandbytes LLM.int8): C[m][n] = sa[m] * sb[n] * sum_k A8[m][k] * B8[n][k]

@@ -20,7 +20,7 @@ for (m, n, k) in shapes:
 # results of the two kernels on one shape: same products, fp32 accumulation in a different order
 lib.lhrs_gemm_set_mfma16(0); c0 = hk.gemm_nt(ops[1][0], ops[1][1]).float()
 lib.lhrs_gemm_set_mfma16(1); c1 = hk.gemm_nt(ops[1][0], ops[1][1]).float()
-print("rel diff 16x16x32 vs 32x32x16:", ((c1 - c0).norm() / c0.norm()).item(), "max", (c1 - c0).abs().max().item())
+print("max |s - r|:", (c1 - c0).abs().max().item())
 for rep in range(3):
     for mode in (0, 1):
         lib.lhrs_gemm_set_mfma16(mode)
@@ -39,4 +39,4 @@ for rep in range(3):
             ms = e0.elapsed_time(e1) / 12
             tot_t += ms; tot_f += 2.0 * m * n * k
             line.append(f"{2.0 * m * n * k / (ms * 1e-3) / 1e12:6.1f}")
-        print(f"{'16x16x32' if mode else '32x32x16'} M={M}: " + " ".join(line) + f" | all {tot_f / (tot_t * 1e-3) / 1e12:.1f} TF", flush=True)
+        print(f"{('32x32x16 r', '16x16x32 s')[mode]:12s} M={M}: " + " ".join(line) + f" | all {tot_f / (tot_t * 1e-3) / 1e12:.1f} TF", flush=True)

@@ -9,7 +9,10 @@ first use is `s_waitcnt lgkmcnt(N)`, N = reads issued after that fragment's relo
 opens with the stage boundary (full wait, vmcnt, s_barrier); the four DMA pieces of the stage after next follow in its first four gaps.
 Tried and measured worse (MI355X, all-zero operands, TFLOP/s over the seven LLaMA shapes at M = 8190): the barrier in front of block 1's
 first re-read instead of at its top 1294 (vs 1429); the 64 DMA pieces of a stage spread over 16 slots with the wave rows taking turns 1013
-/ 1306 (scalar branches in the MFMA stream cost more than the burst they smooth).
+/ 1306 (scalar branches in the MFMA stream cost more than the burst they smooth); the DMA pieces behind MFMA slots 0,2,4,6 1298 (vs 1302
+random operands), 0,3,6,9 1275, 1,5,9,13 1240, 0,4,8,12 1199; a ring of four 32-k half-stages (every block opens with a boundary, the DMA of
+half-stage b + 4 goes out at the boundary of block b and has three block times to land, `vmcnt(4)`) 1313 zeros / 1200 random against 1424 /
+1341 on the same box: the pipeline is not waiting for DMA latency, and twice the barriers cost more than the longer prefetch returns.
 
    python tools/gen_gemm16_sched.py > lhrs_bot_amd/csrc/gemm_256s_sched.inc
 """
@@ -41,8 +44,12 @@ def frag(f):
 
 
 import os
+import sys
 
 DMA_SLOTS = [int(x) for x in os.environ.get("DMA_SLOTS", "0,1,2,3").split(",")]  # MFMA slots of block 1 behind which the four DMA pieces go out
+
+
+N_DMA, VMCNT, FRAG_STRIDE = 4, 0, 2048  # DMA pieces per wave and stage; pieces that may stay in flight at a boundary; bytes between fragments
 
 
 def emit_block(name, seq, prev_reads, do_reads, barrier):
@@ -61,7 +68,7 @@ def emit_block(name, seq, prev_reads, do_reads, barrier):
         # the stage boundary: every read of the current stage's buffer is complete (full wait), this wave's DMA pieces of the next stage
         # have landed (vmcnt), the barrier publishes everybody's and frees the current buffer for the stage after next
         cons = ", ".join(f'"+v"({frag(f)})' for f in sorted(set(outstanding)))
-        lines.append(f'  asm volatile("s_waitcnt lgkmcnt(0)" : {cons}); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB \\')
+        lines.append(f'  asm volatile("s_waitcnt lgkmcnt(0)" : {cons}); asm volatile("s_waitcnt vmcnt({VMCNT})" ::: "memory"); __builtin_amdgcn_s_barrier(); SB \\')
         outstanding = []
     for t, (mi, ni) in enumerate(seq):
         need = [f for f in (("A", mi), ("B", ni)) if first[f] == t and f in outstanding]
@@ -76,10 +83,10 @@ def emit_block(name, seq, prev_reads, do_reads, barrier):
         if do_reads and dead:
             for f in dead:
                 addr = "aa" if f[0] == "A" else "ba"
-                lines.append(f"  RDQ({frag(f)}, {addr}, {f[1] * 2048}); SB \\")
+                lines.append(f"  RDQ({frag(f)}, {addr}, {f[1] * FRAG_STRIDE}); SB \\")
                 outstanding.append(f)
                 issued.append(f)
-        if barrier and dma_pos < 4 and t == DMA_SLOTS[dma_pos]:
+        if barrier and dma_pos < N_DMA and t == DMA_SLOTS[dma_pos]:
             lines.append(f"  {{ ISS({dma_pos}) }} SB \\")
             dma_pos += 1
     lines.append("  ;")
