@@ -280,8 +280,6 @@ def main():
         lib.lhrs_gemm_set_policy(a.gemm_policy)
     if os.environ.get("LHRS_GEMM_PERSISTENT"):  # kernel A/B tests only
         lib.lhrs_gemm_set_persistent(int(os.environ["LHRS_GEMM_PERSISTENT"]))
-    if os.environ.get("LHRS_GEMM_MFMA16"):  # kernel A/B tests only: 0 = the 32x32x16 kernel
-        lib.lhrs_gemm_set_mfma16(int(os.environ["LHRS_GEMM_MFMA16"]))
     if os.environ.get("LHRS_GEMM_MIN_TILES"):  # kernel A/B tests only
         lib.lhrs_gemm_set_min_tiles(int(os.environ["LHRS_GEMM_MIN_TILES"]))
     B, T = a.micro_batch, a.caption_tokens + 2
@@ -394,7 +392,7 @@ def main():
             "loss": round(final_loss, 4),
             "step_mfma_frac": round(sps / world * f_alg(S) / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 and a.stage == 1 else None,
             "step_mfma_frac_executed": round(sps / world * f_exec / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 and a.stage == 1 else None,
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_256r_kernel<ACT, 0> (256x256 tile, 16 waves, BK=64 double-buffered LDS stages via global_load_lds DMA, v_mfma_f32_32x32x16_bf16; the two launches per layer with a fused SwiGLU epilogue are timed separately under `variants`)", "achieved": round(ach, 1),
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_256s_kernel<ACT, 0, K2P> (256x256 tile, 16 waves, BK=64 double-buffered LDS stages via global_load_lds DMA, v_mfma_f32_16x16x32_bf16; the launches with a fused SwiGLU / RoPE epilogue are timed separately under `variants`)", "achieved": round(ach, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "variants": variants,
                          "launches_timed": int(n_samp), "avg_launch_us": round(1e3 * ms / max(n_samp, 1), 2),

@@ -114,8 +114,7 @@ int lhrs_gemm_set_tail_split(int on);
 /* kernel A/B tests only: 1 (default) = the 16-wave 256x256 kernel runs one persistent workgroup per CU walking its tiles (the next tile's
  * first operands are fetched under the current tile's epilogue); 0 = one workgroup per tile */
 int lhrs_gemm_set_persistent(int on);
-/* MFMA shape of the dominant 256x256 kernel: 1 (default) v_mfma_f32_16x16x32_bf16, 0 v_mfma_f32_32x32x16_bf16 (kernel A/B tests). */
-int lhrs_gemm_set_mfma16(int on);
+
 /* kernel A/B tests only: fewest 256x256 tiles for which lhrs_gemm_bf16_nt picks the big-tile kernel (default 128) */
 int lhrs_gemm_set_min_tiles(int n);
 /* live HIP-event timing of the 16-wave 256x256 GEMM launches, on their launch stream, for bench.py's roofline leg (gemm.hip):

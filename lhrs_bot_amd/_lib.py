@@ -72,8 +72,6 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
-    if os.environ.get("LHRS_GEMM_MFMA16"):  # kernel A/B runs only: which variant of the dominant GEMM (include/lhrs_hip.h lhrs_gemm_set_mfma16)
-        lib.lhrs_gemm_set_mfma16(int(os.environ["LHRS_GEMM_MFMA16"]))
     _lib = lib
     return lib
 

@@ -8,10 +8,11 @@
 // activations.  One layout, one kernel family.
 //
 // Kernel family (CDNA4), chosen by tile count in gemm_launch:
-//   * gemm_nt_256r_kernel<ACT, EPI> - THE dominant kernel (every LLaMA linear at training batch sizes): 256x256x64 tile, 16 waves (4x4 of
-//     64x64 = 2x2 fragments of v_mfma_f32_32x32x16_bf16), two 64 KiB LDS stages filled by direct-to-LDS DMA (global_load_lds_dwordx4, no VGPR
-//     round trip), one barrier per stage, PERSISTENT over tiles (one workgroup per CU; the next tile's first stage is fetched under the
-//     epilogue), fused epilogues: bias / activation / residual / dropout mask (EPI 0), SwiGLU forward / backward (EPI 1 / 2), RoPE (EPI 3).
+//   * gemm_nt_256s_kernel<ACT, EPI, K2P> - THE dominant kernel (every LLaMA linear at training batch sizes): 256x256x64 tile, 16 waves (4x4 of
+//     64x64 = 4x4 fragments of v_mfma_f32_16x16x32_bf16 - the dense bf16 shape that costs the least power per FLOP), two 64 KiB LDS stages
+//     filled by direct-to-LDS DMA (global_load_lds_dwordx4, no VGPR round trip), one barrier per stage, PERSISTENT over tiles (one workgroup
+//     per CU; the next tile's first stage is fetched under the epilogue), fused epilogues: bias / activation / residual / dropout mask
+//     (EPI 0), SwiGLU forward / backward (EPI 1 / 2), RoPE (EPI 3).
 //   * gemm_nt_256p_kernel - K % 64 != 0 fallback of the above (BK = 32, 4-deep ring, 8 waves).
 //   * gemm_nt_kernel<WM, WN> - 128x128 / 64x128 / 64x64 tiles, 4 waves, for the small products of the ViT and the projector.
 //   * e4m3 siblings (gemm_fp8_256_kernel, gemm_fp8_small_kernel) for the 8-bit frozen base of stages 2/3.
@@ -477,339 +478,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256p_kernel(GemmArgs g) {
 
 
 // ------------------------------------------------------------------------------------------------
-// 256x256 "r" variant: the q kernel's stage structure with SIXTEEN waves (4x4, 64x64 per wave, 4 waves per SIMD at <=128 VGPRs):
-// when a wave sits in a DMA issue or at the barrier three others can feed the SIMD's MFMA pipe instead of one.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lds_wait4(bf16x8 (&a)[2], bf16x8 (&b)[2]) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(a[0]), "+v"(a[1]));
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-template <int ACT, int EPI = 0>
-__global__ __launch_bounds__(1024, 1) void gemm_nt_256r_kernel(GemmArgs g) {
-  constexpr int BM = 256, BN = 256, BK = 64;
-  constexpr int A_BYTES = BM * BK * 2, STAGE = A_BYTES + BN * BK * 2;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-
-  // PERSISTENT over tiles: workgroup b walks tiles b, b + gridDim.x, ... (the launcher gives one workgroup per CU when there are more
-  // tiles than CUs).  The stages of consecutive tiles form ONE stream over the two LDS buffers: the last stage of a tile issues the DMA
-  // of the NEXT tile's first stage, the epilogue stages its output through the buffer the last stage occupied (64 KiB, in two 32-row
-  // passes) while that DMA lands in the other one - a new tile starts with its operands already in LDS instead of behind a workgroup
-  // launch plus one exposed L2 / fabric round trip.
-  const int ntiles = g.tilesM * g.tilesN;
-  int t = blockIdx.x;
-  if (t >= ntiles) return;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  // DMA: 64 pieces of 1 KiB per stage; wave w issues #4w..4w+3 (waves 0-7: A, 8-15: B)
-  const bool isA = wave < 8;
-  const char* base1 = reinterpret_cast<const char*>(isA ? g.A : g.B);
-  const char* base2 = reinterpret_cast<const char*>(isA ? g.A2 : g.B2);
-  const long ld1 = isA ? g.lda : g.ldb, ld2 = isA ? g.lda2 : g.ldb2;
-  const int rmax = (isA ? g.M : g.N) - 1;
-  const int nk1 = g.K / BK;
-  const int nk = (g.K + g.K2) / BK;  // >= 2 (host guarantees)
-  // global byte offsets of this lane's four DMA rows for tile (tm_, tn_)
-  auto dma_rows = [&](int tm_, int tn_, unsigned (&o1)[4], unsigned (&o2)[4]) {
-    const int row0 = isA ? tm_ * BM : tn_ * BN;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int ridx = (wave & 7) * 4 + j;
-      const int lchunk = (lane & 7) ^ ((((j & 1) << 2) + (lane >> 4)) & 7);
-      int row = min(row0 + ridx * 8 + (lane >> 3), rmax);
-      if (EPI == 1 && !isA) {  // B tile row r = 64*wn + 32*half + i  <-  weight row half*ff + tn*128 + wn*32 + i
-        const int r = ridx * 8 + (lane >> 3);
-        row = ((r >> 5) & 1) * g.ff + tn_ * 128 + (r >> 6) * 32 + (r & 31);
-      }
-      if (EPI == 3 && !isA && tn_ * BN < g.rope_cols) {  // B tile row r = 64*wn + 32*half + i  <-  head 2*tn + (wn >> 1), dim 64*half + 32*(wn & 1) + i
-        const int r = ridx * 8 + (lane >> 3);
-        row = tn_ * BN + ((r >> 7) << 7) + ((r >> 5) & 1) * 64 + ((r >> 6) & 1) * 32 + (r & 31);
-      }
-      o1[j] = (unsigned)(((long)row * ld1 + lchunk * 8) * 2);
-      o2[j] = g.K2 > 0 ? (unsigned)(((long)row * ld2 + lchunk * 8) * 2) : 0u;
-    }
-  };
-  const int dst0 = (isA ? 0 : A_BYTES) + (wave & 7) * 4096;
-  // piece j of k-stage kt of the tile whose row offsets are (o1, o2) -> LDS buffer `buf`
-  auto issue_to = [&](const unsigned (&o1)[4], const unsigned (&o2)[4], int kt, int buf, int j) {
-    const char* p = kt < nk1 ? base1 + (long)kt * (BK * 2) + o1[j] : base2 + (long)(kt - nk1) * (BK * 2) + o2[j];
-    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + buf * STAGE + dst0 + j * 1024), 16, 0, 0);
-  };
-
-  const int wm = wave >> 2, wn = wave & 3;
-  const int fr = lane & 31, fh = lane >> 5;
-  const int sw = (fr >> 1) & 7;
-  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
-  const unsigned a_base = lds0 + (wm * 64 + fr) * 128;
-  const unsigned b_base = lds0 + A_BYTES + (wn * 64 + fr) * 128;
-  unsigned koff[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) koff[kk] = ((kk * 2 + fh) ^ sw) * 16;
-
-  int tm, tn;
-  tile_coords_lin(g, t, ntiles, tm, tn);
-  unsigned off1[4], off2[4];
-  dma_rows(tm, tn, off1, off2);
-  int pb = 0;  // LDS buffer of this tile's stage 0 (stage kt lives in buffer (kt + pb) & 1)
-#pragma unroll
-  for (int j = 0; j < 4; ++j) issue_to(off1, off2, 0, 0, j);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-  bf16x8 a0[2], b0[2], a1[2], b1[2];
-#define RDQ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
-#define MFQ(A_, B_, mi, ni) \
-  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B_[ni], A_[mi], acc[mi][ni], 0, 0, 0); __builtin_amdgcn_sched_barrier(0);
-#define SB __builtin_amdgcn_sched_barrier(0);
-  // one block: 4 MFMAs on (Ac, Bc); behind each: one fragment read of the next block and (DMA) one DMA piece, ISS(j) says which
-#define BLOCK(Ac, Bc, An, Bn, aa, ba, RD, DMA)                               \
-  MFQ(Ac, Bc, 0, 0) if (RD) RDQ(Bn[0], ba, 0);    if (DMA) { ISS(0) } SB     \
-  MFQ(Ac, Bc, 0, 1) if (RD) RDQ(Bn[1], ba, 4096); if (DMA) { ISS(1) } SB     \
-  MFQ(Ac, Bc, 1, 0) if (RD) RDQ(An[0], aa, 0);    if (DMA) { ISS(2) } SB     \
-  MFQ(Ac, Bc, 1, 1) if (RD) RDQ(An[1], aa, 4096); if (DMA) { ISS(3) } SB
-
-  for (;;) {
-    const int tnext = t + (int)gridDim.x;
-    const bool has_next = tnext < ntiles;  // workgroup-uniform
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // stage 0 of this tile is in LDS buffer pb (own pieces waited for; the barrier publishes everybody's and ends the previous tile's
-    // epilogue reads of the other buffer, which now takes stage 1)
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) issue_to(off1, off2, 1, pb ^ 1, j);
-    {
-      const unsigned so = pb * STAGE;
-      {
-        const unsigned aa = a_base + so + koff[0], ba = b_base + so + koff[0];
-        RDQ(b0[0], ba, 0); RDQ(b0[1], ba, 4096); RDQ(a0[0], aa, 0); RDQ(a0[1], aa, 4096);
-      }
-#define ISS(j)
-      lds_wait4(a0, b0);
-      { const unsigned aa = a_base + so + koff[1], ba = b_base + so + koff[1]; BLOCK(a0, b0, a1, b1, aa, ba, true, false) }
-      lds_wait4(a1, b1);
-      { const unsigned aa = a_base + so + koff[2], ba = b_base + so + koff[2]; BLOCK(a1, b1, a0, b0, aa, ba, true, false) }
-      lds_wait4(a0, b0);
-      { const unsigned aa = a_base + so + koff[3], ba = b_base + so + koff[3]; BLOCK(a0, b0, a1, b1, aa, ba, true, false) }
-#undef ISS
-    }
-
-    // a stage: finish the previous stage's last k-block while the first fragments of stage kt are read and (first block) the DMA of
-    // the following stage is issued into the buffer the barrier has just freed
-#define STAGE_BODY(kt, DMA)                                                                                                         \
-    {                                                                                                                               \
-      const unsigned so = (((kt) + pb) & 1) * STAGE;                                                                                \
-      lds_wait4(a1, b1);                                                                                                            \
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                              \
-      __builtin_amdgcn_s_barrier();                                                                                                 \
-      { const unsigned aa = a_base + so + koff[0], ba = b_base + so + koff[0]; BLOCK(a1, b1, a0, b0, aa, ba, true, DMA) }           \
-      lds_wait4(a0, b0);                                                                                                            \
-      { const unsigned aa = a_base + so + koff[1], ba = b_base + so + koff[1]; BLOCK(a0, b0, a1, b1, aa, ba, true, false) }         \
-      lds_wait4(a1, b1);                                                                                                            \
-      { const unsigned aa = a_base + so + koff[2], ba = b_base + so + koff[2]; BLOCK(a1, b1, a0, b0, aa, ba, true, false) }         \
-      lds_wait4(a0, b0);                                                                                                            \
-      { const unsigned aa = a_base + so + koff[3], ba = b_base + so + koff[3]; BLOCK(a0, b0, a1, b1, aa, ba, true, false) }         \
-    }
-#define ISS(j) issue_to(off1, off2, kt + 1, (kt + 1 + pb) & 1, j);
-    for (int kt = 1; kt < nk - 1; ++kt) STAGE_BODY(kt, true)
-#undef ISS
-    int ntm = 0, ntn = 0;
-    if (has_next) {  // this tile's DMA rows are not needed any more (its last stage is in flight): the offsets become the next tile's
-      tile_coords_lin(g, tnext, ntiles, ntm, ntn);
-      dma_rows(ntm, ntn, off1, off2);
-    }
-    // last stage of the tile: the freed buffer takes stage 0 of the NEXT tile
-#define ISS(j) if (has_next) issue_to(off1, off2, 0, (nk + pb) & 1, j);
-    STAGE_BODY(nk - 1, true)
-#undef ISS
-#define ISS(j)
-    lds_wait4(a1, b1);
-    { BLOCK(a1, b1, a0, b0, a_base, b_base, false, false) }
-#undef ISS
-#undef STAGE_BODY
-
-    if (g.out_f32) {
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int m = tm * BM + wm * 64 + mi * 32 + fr;
-        if (m >= g.M) continue;
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int n = tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4;
-            if (n >= g.N) continue;
-            store4<ACT>(g, m, n, f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]});
-          }
-      }
-    } else {
-      __builtin_amdgcn_s_barrier();  // every wave has read its last fragments: the last stage's buffer becomes the staging area
-      char* reg = smem + ((nk - 1 + pb) & 1) * STAGE + wave * 4096;  // [32 rows][64 cols] bf16, wave private, one pass per mi
-      const bool rope_tile = EPI == 3 && tn * BN < g.rope_cols;
-      const int rsub = lane >> 3, c = lane & 7;
-      // EPI 1: chunks 0-3 are gate columns, 4-7 the matching up columns of the [M, 2*ff] output
-      const int n = EPI == 1   ? (c < 4 ? 0 : g.ff) + tn * 128 + wn * 32 + (c & 3) * 8
-                    : rope_tile ? tn * BN + (wn >> 1) * 128 + (c < 4 ? 0 : 64) + (wn & 1) * 32 + (c & 3) * 8
-                                : tn * BN + wn * 64 + c * 8;
-      const int nlim = EPI == 2 ? g.ff : g.N;
-      const bool col_ok = n < nlim;
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int row = fr;  // row inside this 32-row pass
-        // the operands this pass reads back from HBM (saved gate / up for EPI 2, the residual for EPI 0) are requested for all four row
-        // groups up front: C may alias them (d(gate|up) overwrites gate|up in place, x += ...), so the compiler must keep every load
-        // behind the previous group's store and the round trips would otherwise run one after the other
-        uint4 pre_a[4], pre_b[4];
-        if (EPI == 2 || (EPI == 0 && g.res)) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int m = tm * BM + wm * 64 + mi * 32 + i * 8 + rsub;
-            pre_a[i] = make_uint4(0, 0, 0, 0); pre_b[i] = make_uint4(0, 0, 0, 0);
-            if (m < g.M && col_ok) {
-              if (EPI == 2) {
-                pre_a[i] = *reinterpret_cast<const uint4*>(g.aux + (long)m * g.ld_aux + n);
-                pre_b[i] = *reinterpret_cast<const uint4*>(g.aux + (long)m * g.ld_aux + g.ff + n);
-              } else {
-                pre_a[i] = *reinterpret_cast<const uint4*>(g.res + (long)m * g.ldr + n);
-              }
-            }
-          }
-        }
-        if (rope_tile) {
-          // acc[mi][0] holds dims d = 32*(wn & 1) + j of the head, acc[mi][1] their rotate_half partners d + 64: rotate the bf16-rounded
-          // projections exactly like the stand-alone rope kernel does on the stored q / k rows
-          const int pos = (tm * BM + wm * 64 + mi * 32 + row) % g.rope_mod + g.rope_pos0;
-          const float* cs = g.rope_cos + (long)pos * 64 + (wn & 1) * 32 + fh * 4;
-          const float* sn = g.rope_sin + (long)pos * 64 + (wn & 1) * 32 + fh * 4;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float4 c4 = *reinterpret_cast<const float4*>(cs + q * 8), s4 = *reinterpret_cast<const float4*>(sn + q * 8);
-            const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w};
-            float o1[4], o2[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              rope_pair(bf2f(f2bf(acc[mi][0][4 * q + i] * g.alpha)), bf2f(f2bf(acc[mi][1][4 * q + i] * g.alpha)), cv[i], sv[i], o1[i], o2[i]);
-            const int u = q * 2 + fh;
-            *reinterpret_cast<uint2*>(reg + row * 128 + ((u ^ ((row & 7) << 1)) << 3)) = make_uint2(pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3]));
-            *reinterpret_cast<uint2*>(reg + row * 128 + (((8 + u) ^ ((row & 7) << 1)) << 3)) = make_uint2(pack2bf(o2[0], o2[1]), pack2bf(o2[2], o2[3]));
-          }
-        } else {
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              float v[4];
-              uint2 bb = make_uint2(0, 0);
-              if (EPI == 0 && g.bias) bb = *reinterpret_cast<const uint2*>(g.bias + min(tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4, g.N - 4));
-              const float bias_v[4] = {bflo(bb.x), bfhi(bb.x), bflo(bb.y), bfhi(bb.y)};
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                v[i] = acc[mi][ni][4 * q + i] * g.alpha;
-                if (EPI == 0 && g.drop_thresh) {
-                  const long e = (long)(tm * BM + wm * 64 + mi * 32 + row) * g.N + tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4 + i;
-                  v[i] = drop_keep(g.drop_seed, e, g.drop_thresh) ? v[i] * g.drop_scale : 0.f;
-                }
-                v[i] += bias_v[i];
-                if (ACT) v[i] = apply_act(v[i], ACT);
-              }
-              const int u = ni * 8 + q * 2 + fh;
-              *reinterpret_cast<uint2*>(reg + row * 128 + ((u ^ ((row & 7) << 1)) << 3)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-            }
-        }
-        // own staging rows written; the next tile's stage-0 pieces and the read-back operands have landed long ago (issued a whole stage
-        // earlier): waiting for them HERE, in front of the first global store, keeps the stores out of every later vmcnt wait
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r32 = i * 8 + rsub;
-          const int m = tm * BM + wm * 64 + mi * 32 + r32;
-          uint4 val = *reinterpret_cast<const uint4*>(reg + r32 * 128 + ((c ^ (r32 & 7)) << 4));
-          if (m < g.M && col_ok) {
-            if (EPI == 2) {  // val = d_act (bf16-rounded like the unfused path): d(gate), d(up) from the saved gate|up
-              const uint4 gq = pre_a[i], uq = pre_b[i];
-              float d[8], gg[8], uu[8], dg[8], du[8];
-              unpack8(val, d); unpack8(gq, gg); unpack8(uq, uu);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const float sg = 1.f / (1.f + __expf(-gg[e]));
-                du[e] = d[e] * gg[e] * sg;
-                dg[e] = d[e] * uu[e] * sg * (1.f + gg[e] * (1.f - sg));
-              }
-              bf16_t* out = reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n;
-              *reinterpret_cast<uint4*>(out) = pack8(dg);
-              *reinterpret_cast<uint4*>(out + g.ff) = pack8(du);
-              continue;
-            }
-            if (EPI == 0 && g.res) {
-              const uint4 r = pre_a[i];
-              val.x = pack2bf(bflo(val.x) + bflo(r.x), bfhi(val.x) + bfhi(r.x));
-              val.y = pack2bf(bflo(val.y) + bflo(r.y), bfhi(val.y) + bfhi(r.y));
-              val.z = pack2bf(bflo(val.z) + bflo(r.z), bfhi(val.z) + bfhi(r.z));
-              val.w = pack2bf(bflo(val.w) + bflo(r.w), bfhi(val.w) + bfhi(r.w));
-            }
-            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n) = val;
-          }
-        }
-      }
-      if (EPI == 1) {
-        // second output: act = silu(gate) * up on the bf16-rounded gate / up (what the unfused kernel reads back), staged [64][32]
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          const int row = mi * 32 + fr;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float gv = bf2f(f2bf(acc[mi][0][4 * q + i] * g.alpha)), uv = bf2f(f2bf(acc[mi][1][4 * q + i] * g.alpha));
-              v[i] = silu(gv) * uv;
-            }
-            const int u = q * 2 + fh;  // 8-byte unit 0..7 of the 64-byte row
-            *reinterpret_cast<uint2*>(reg + row * 64 + ((u ^ ((row & 3) << 1)) << 3)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-          }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int rsub4 = lane >> 2, c4 = lane & 3;
-        const int n2 = tn * 128 + wn * 32 + c4 * 8;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = i * 16 + rsub4;
-          const int m = tm * BM + wm * 64 + row;
-          const uint4 val = *reinterpret_cast<const uint4*>(reg + row * 64 + ((c4 ^ (row & 3)) << 4));
-          if (m < g.M) *reinterpret_cast<uint4*>(g.aux_out + (long)m * g.ld_aux + n2) = val;
-        }
-      }
-    }
-    if (!has_next) break;
-    if (g.out_f32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no staged epilogue ran: the next tile's stage-0 pieces are awaited here
-    t = tnext; tm = ntm; tn = ntn;
-    pb = (pb + nk) & 1;
-  }
-#undef BLOCK
-#undef SB
-#undef MFQ
-#undef RDQ
-}
-
-// ------------------------------------------------------------------------------------------------
-// 256x256 "s" variant: the r kernel (16 waves, persistent, two 64 KiB DMA stages) with the OTHER dense bf16 MFMA shape,
-// v_mfma_f32_16x16x32_bf16.  Per FLOP that instruction moves half the accumulator data of v_mfma_f32_32x32x16_bf16 (4 accumulator VGPRs per
-// 16 KFLOP instead of 16 per 32 KFLOP) and under the 1400 W package cap a loop of nothing but MFMAs on random bf16 sustains 2.00 PFLOP/s
-// with it against 1.78 PFLOP/s (tools/mfma_peak.hip, alternating 0.2 s runs) - the GEMM is power-bound, so the cheaper instruction is the
-// faster one.  A wave still owns 64x64 of the tile: 4x4 fragments of 16x16, one k-block = 32 k = 16 MFMAs, a stage = 2 k-blocks.  Fragment
-// registers are single-buffered and roll - a fragment is re-read for the next block right behind the last MFMA that uses it - 32 VGPRs, as
-// many as the r kernel's double-buffered 32x32 fragments; the MFMA order walks the 2x2 quadrants of the fragment grid (block 0: Q00 Q01 Q11 Q10,
-// block 1: Q01 Q00 Q10 Q11) so that every fragment has >= 7 MFMA slots between its re-read and its next use, and the waits are counted
-// (LDS returns in order).  Order, re-reads, waits, barrier and DMA slots are generated: tools/gen_gemm16_sched.py -> gemm_256s_sched.inc.  The LDS image,
-// its swizzle (conflict-free for 16-row x 4-chunk reads as well), the DMA, the barrier placement and the epilogue's read-back half are the
-// r kernel's; the accumulator layout (lane: m = lane & 15, n = 4 * (lane >> 4) + i) changes the staging writes only.
+// The 16-wave 256x256 kernel (4x4 waves of 64x64, 128 VGPRs -> 4 waves per SIMD: while one wave sits in a DMA issue or at the barrier three
+// others feed the SIMD's MFMA pipe).  MFMA shape: v_mfma_f32_16x16x32_bf16, not the 32x32x16 this kernel used through round 2's first half
+// (gemm_nt_256r_kernel, in the history).  Per FLOP the 16x16x32 instruction moves half the accumulator data (4 accumulator VGPRs per 16 KFLOP
+// instead of 16 per 32 KFLOP) and under the 1400 W package cap a loop of nothing but MFMAs on random bf16 sustains 2.00 PFLOP/s with it
+// against 1.78 (tools/mfma_peak.hip) - the GEMM is power-bound, so the cheaper instruction is the faster one: +3.4 .. +4.9 % on the LLaMA
+// shapes, +3 % on the step, shader clock 1.87 -> 2.06 GHz under load, results bit-identical (profiles/r02_gemm_mfma_shape_ab.txt).
+// A wave's 64x64 is 4x4 fragments of 16x16; one k-block = 32 k = 16 MFMAs, a stage = 2 k-blocks.  Fragment registers are single-buffered and
+// ROLL - a fragment is re-read for the next block right behind the last MFMA that uses it (32 VGPRs; double-buffering 8 fragments of 4 VGPRs
+// does not fit beside 64 accumulators) - and the MFMA order walks the 2x2 quadrants of the fragment grid (block 0: Q00 Q01 Q11 Q10, block 1:
+// Q01 Q00 Q10 Q11) so that every fragment has >= 7 MFMA slots between its re-read and its next use; the waits are counted (LDS returns in
+// order).  Order, re-reads, waits, barrier and DMA slots are generated: tools/gen_gemm16_sched.py -> gemm_256s_sched.inc.
 // ------------------------------------------------------------------------------------------------
 #include "gemm_256s_sched.inc"
 __device__ __forceinline__ void lds_wait8(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
@@ -830,7 +509,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  // DMA: 64 pieces of 1 KiB per stage; wave w issues #4w..4w+3 (waves 0-7: A, 8-15: B) - identical to the r kernel
+  // DMA: 64 pieces of 1 KiB per stage; wave w issues #4w..4w+3 (waves 0-7: A, 8-15: B)
   const bool isA = wave < 8;
   const char* base1 = reinterpret_cast<const char*>(isA ? g.A : g.B);
   const char* base2 = reinterpret_cast<const char*>(isA ? g.A2 : g.B2);
@@ -1422,14 +1101,11 @@ static int g_gemm_allow_256 = 2;
 // workgroup b takes tiles b, b + grid, ...  0 = one workgroup per tile (kernel A/B tests: lhrs_gemm_set_persistent)
 static int g_gemm_persist = 1;
 extern "C" int lhrs_gemm_set_persistent(int on) { g_gemm_persist = on; return 0; }
-// MFMA shape of the 16-wave 256x256 kernel: 1 = v_mfma_f32_16x16x32_bf16 (gemm_nt_256s_kernel), 0 = v_mfma_f32_32x32x16_bf16 (gemm_nt_256r_kernel)
-static int g_gemm_mfma16 = 1;
-extern "C" int lhrs_gemm_set_mfma16(int on) { g_gemm_mfma16 = on; return 0; }
+// the 16-wave kernel; a second operand pair (K2 > 0: the fused LoRA product) is a template parameter of it
 #define LAUNCH_256(ACT_, EPI_, grid_, s_, g_)                                                                          \
   do {                                                                                                                 \
-    if (g_gemm_mfma16 && (g_).K2 > 0) hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT_, EPI_, true>), grid_, dim3(1024), 0, s_, g_);   \
-    else if (g_gemm_mfma16) hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT_, EPI_, false>), grid_, dim3(1024), 0, s_, g_);              \
-    else hipLaunchKernelGGL((gemm_nt_256r_kernel<ACT_, EPI_>), grid_, dim3(1024), 0, s_, g_);                          \
+    if ((g_).K2 > 0) hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT_, EPI_, true>), grid_, dim3(1024), 0, s_, g_);        \
+    else hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT_, EPI_, false>), grid_, dim3(1024), 0, s_, g_);                   \
   } while (0)
 static int num_cus() {
   static int n = 0;
@@ -1441,7 +1117,7 @@ static int num_cus() {
   }
   return n;
 }
-static dim3 grid_256r(long tiles) { return dim3((unsigned)(g_gemm_persist ? (tiles < num_cus() ? tiles : num_cus()) : tiles)); }
+static dim3 grid_256s(long tiles) { return dim3((unsigned)(g_gemm_persist ? (tiles < num_cus() ? tiles : num_cus()) : tiles)); }
 static int g_gemm_min256 = 128;  // fewest 256x256 tiles (half a round of the 256 CUs) for which the big-tile kernels are chosen: 2184 x 4096 (144
                                  // tiles, the reference's micro-batch 8) runs 20 % faster there than on 576 small tiles; A/B: lhrs_gemm_set_min_tiles
 extern "C" int lhrs_gemm_set_min_tiles(int n) { g_gemm_min256 = n; return 0; }
@@ -1525,7 +1201,7 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
   const bool al16 = out_f32 || (N % 8 == 0 && ldc % 8 == 0 && (residual == nullptr || ldr % 8 == 0));  // 16-B epilogue rows
   bool use256 = g_gemm_allow_256 && t256 >= g_gemm_min256 && K >= 96 && K % 32 == 0 && al16;  // ring prologue needs >= 3 stages
-  if (g.drop_thresh && !(g_gemm_allow_256 == 2 && K % 64 == 0 && K >= 128)) use256 = false;  // the mask lives in the r kernel and in store4
+  if (g.drop_thresh && !(g_gemm_allow_256 == 2 && K % 64 == 0 && K >= 128)) use256 = false;  // the mask lives in the 16-wave kernel and in store4
   if (K2 > 0 && !use256) {  // small problems: base GEMM, then the rank-K2 update accumulated on top of it
     if (gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, out_f32, accumulate, alpha, nullptr, 0, nullptr, 0, 0, stream))
       return -1;
@@ -1564,7 +1240,7 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   if (g_prof.on) {
     g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * (K + K2);
     const bool dominant = use256 && g_gemm_allow_256 == 2 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128;
-    if (dominant && g_prof.used < g_prof.cap) {  // time exactly the launches rocprof lists as gemm_nt_256r_kernel<ACT, 0>
+    if (dominant && g_prof.used < g_prof.cap) {  // time exactly the launches rocprof lists as gemm_nt_256s_kernel<ACT, 0, K2P>
       slot = g_prof.used++;
       g_prof.flops[slot] = 2.0 * M * N * (K + K2);
       g_prof.kind[slot] = 0;
@@ -1575,7 +1251,7 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
     g.tilesM = cdiv(M, 256); g.tilesN = cdiv(N, 256);
     const dim3 grid(g.tilesM * g.tilesN), blk(512);
     if (g_gemm_allow_256 == 2 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128) {
-      const dim3 grid16 = grid_256r((long)g.tilesM * g.tilesN);
+      const dim3 grid16 = grid_256s((long)g.tilesM * g.tilesN);
       switch (act) {
         case 0: LAUNCH_256(0, 0, grid16, s, g); break;
         case 1: LAUNCH_256(1, 0, grid16, s, g); break;
@@ -1621,7 +1297,7 @@ extern "C" int lhrs_gemm_swiglu_fusable(int M, int ff, int K_fwd, int K_bwd, int
 }
 
 // the fused-epilogue launches count towards the step's GEMM FLOPs but are NOT timed as "the dominant kernel": their epilogues do
-// elementwise work (SwiGLU) that has no FLOPs in the GEMM roofline - the live roofline figure is the plain gemm_nt_256r_kernel<ACT, 0>
+// elementwise work (SwiGLU) that has no FLOPs in the GEMM roofline - the live roofline figure is the plain gemm_nt_256s_kernel<ACT, 0, K2P>
 static int prof_count(int M, int N, int K, int kind, hipStream_t s) {
   if (!g_prof.on) return -1;
   g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * K;
@@ -1651,7 +1327,7 @@ extern "C" int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int
   g.tilesM = cdiv(M, 256); g.tilesN = ff / 128;
   hipStream_t s = (hipStream_t)stream;
   const int pslot = prof_count(M, 2 * ff, K + K2, 1, s);
-  LAUNCH_256(0, 1, grid_256r((long)g.tilesM * g.tilesN), s, g);
+  LAUNCH_256(0, 1, grid_256s((long)g.tilesM * g.tilesN), s, g);
   prof_end(pslot, s);
   LHRS_CHECK_LAUNCH("gemm_swiglu_fwd");
   return 0;
@@ -1681,7 +1357,7 @@ extern "C" int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw
   g.epi = 3; g.rope_cos = cos_t; g.rope_sin = sin_t; g.rope_mod = pos_mod; g.rope_pos0 = pos0; g.rope_cols = rope_cols;
   g.tilesM = cdiv(M, 256); g.tilesN = cdiv(N, 256);
   const int pslot = prof_count(M, N, K + K2, 3, (hipStream_t)stream);
-  LAUNCH_256(0, 3, grid_256r((long)g.tilesM * g.tilesN), (hipStream_t)stream, g);
+  LAUNCH_256(0, 3, grid_256s((long)g.tilesM * g.tilesN), (hipStream_t)stream, g);
   prof_end(pslot, (hipStream_t)stream);
   LHRS_CHECK_LAUNCH("gemm_rope_fwd");
   return 0;
@@ -1702,7 +1378,7 @@ extern "C" int lhrs_gemm_swiglu_bwd(const void* dY, int ldy, const void* WdT, in
   g.tilesM = cdiv(M, 256); g.tilesN = cdiv(ff, 256);
   hipStream_t s = (hipStream_t)stream;
   const int pslot = prof_count(M, ff, K + K2, 2, s);
-  LAUNCH_256(0, 2, grid_256r((long)g.tilesM * g.tilesN), s, g);
+  LAUNCH_256(0, 2, grid_256s((long)g.tilesM * g.tilesN), s, g);
   prof_end(pslot, s);
   LHRS_CHECK_LAUNCH("gemm_swiglu_bwd");
   return 0;

@@ -12,12 +12,12 @@ shutil.copy(stats, os.path.join(root, "profiles", f"{tag}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(trace)))
 name_key = "Kernel_Name" if "Kernel_Name" in rows[0] else "Name"
 import re
-dom = [r for r in rows if re.search(r"gemm_nt_256r_kernel<\d, 0>", r[name_key])]  # every activation variant of the plain-epilogue kernel
+dom = [r for r in rows if re.search(r"gemm_nt_256s_kernel<\d, 0, (false|true)>", r[name_key])]  # every activation variant of the plain-epilogue kernel
 dom.sort(key=lambda r: int(r["Start_Timestamp"]))
 per_step = len(dom) // (steps + warmup)
 timed = dom[-per_step * steps:]
 avg = lambda rs: sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs) / len(rs) / 1e3
-out = {"kernel": "gemm_nt_256r_kernel<ACT, 0>",
+out = {"kernel": "gemm_nt_256s_kernel<ACT, 0, K2P>",
        "command": f"rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps {steps} --warmup {warmup} --no-cpu-baseline",
        "launches_total": len(dom), "launches_per_step": per_step, "avg_us_all_launches": avg(dom), "avg_us_timed_steps_only": avg(timed),
        "note": "the *_kernel_stats.csv average covers warm-up (first-touch) launches too; the timed-steps average is the one bench.py "
