@@ -540,9 +540,13 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
   };
   const int dst0 = (isA ? 0 : A_BYTES) + (wave & 7) * 4096;
   auto issue_to = [&](const unsigned (&o1)[4], const unsigned (&o2)[K2P ? 4 : 1], int kt, int buf, int j) {
-    // wave-uniform 64-bit base (SGPR pair) + the lane's 32-bit row offset: the saddr form of global_load_lds
-    const char* sp = (!K2P || kt < nk1) ? base1 + (long)kt * (BK * 2) : base2 + (long)(kt - nk1) * (BK * 2);
-    const char* p = sp + ((!K2P || kt < nk1) ? o1[j] : o2[K2P ? j : 0]);
+    // wave-uniform 64-bit base (SGPR pair) + the lane's 32-bit row offset: the saddr form of global_load_lds.  The k offset goes through
+    // readfirstlane so that the loop strength reduction cannot fold it into four loop-carried 64-bit VGPR pointers (8 registers)
+    const int kb_ = __builtin_amdgcn_readfirstlane(((!K2P || kt < nk1) ? kt : kt - nk1) * (BK * 2));
+    const char* sp = ((!K2P || kt < nk1) ? base1 : base2) + kb_;
+    unsigned vo = (!K2P || kt < nk1) ? o1[j] : o2[K2P ? j : 0];
+    asm volatile("" : "+v"(vo));  // opaque at every use: base + offset cannot be hoisted out of the k-loop as a 64-bit VGPR pair per piece
+    const char* p = sp + vo;
     __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + buf * STAGE + dst0 + j * 1024), 16, 0, 0);
   };
 

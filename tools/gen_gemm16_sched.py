@@ -78,6 +78,9 @@ def emit_block(name, seq, prev_reads, do_reads, barrier):
             cons = ", ".join(f'"+v"({frag(f)})' for f in need)
             lines.append(f'  asm volatile("s_waitcnt lgkmcnt({n})" : {cons}); SB \\')
             outstanding = outstanding[pos + 1:]
+        while barrier and dma_pos < N_DMA and DMA_SLOTS[dma_pos] == t - 1 and t == 0:  # slot -1: in front of the block's first MFMA
+            lines.append(f"  {{ ISS({dma_pos}) }} SB \\")
+            dma_pos += 1
         lines.append(f"  MF({mi}, {ni}) \\")
         dead = [f for f in (("A", mi), ("B", ni)) if last[f] == t]
         if do_reads and dead:
@@ -86,7 +89,7 @@ def emit_block(name, seq, prev_reads, do_reads, barrier):
                 lines.append(f"  RDQ({frag(f)}, {addr}, {f[1] * FRAG_STRIDE}); SB \\")
                 outstanding.append(f)
                 issued.append(f)
-        if barrier and dma_pos < N_DMA and t == DMA_SLOTS[dma_pos]:
+        while barrier and dma_pos < N_DMA and t == DMA_SLOTS[dma_pos]:
             lines.append(f"  {{ ISS({dma_pos}) }} SB \\")
             dma_pos += 1
     lines.append("  ;")
