@@ -356,10 +356,10 @@ def main():
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         scale_layers = a.llama_layers / 32.0
         traffic, traffic_src = None, None  # L2-miss-side bytes per launch of the dominant kernel: separate rocprofv3 --pmc passes, NOT this run
-        tpath = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_mfma16_gemm_traffic.json")
         if os.path.exists(tpath) and B == 30 and scale_layers == 1.0 and a.stage == 1:
             traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
-            traffic_src = "profiles/r02_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command; a constant, not measured in this run)"
+            traffic_src = "profiles/r02_mfma16_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command; a constant, not measured in this run)"
         vnames = ("<ACT,0> plain", "<0,1> SwiGLU-fwd epilogue", "<0,2> SwiGLU-bwd epilogue", "<0,3> RoPE epilogue")
         variants = {}
         for k, nm in enumerate(vnames):
