@@ -58,6 +58,50 @@ template <int WAVES> void run16(const bf16x8* din, float* dout, int blocks) {
   double flops = (double)blocks * WAVES * iters * 32 * 2.0 * 16 * 16 * 32;
   printf("16x16x32 waves/block=%d blocks=%d: %.1f TFLOP/s (%.2f ms)\n", WAVES, blocks, flops / (ms * 1e-3) / 1e12, ms);
 }
+// the two block-scaled e4m3 shapes (unit scales), same FLOPs per loop iteration: 32x32x64 (16 accumulator VGPRs) vs 16x16x128 (4)
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+template <int SHAPE>
+__global__ __launch_bounds__(512, 2) void k8(const i32x8* in, float* out, int iters) {
+  i32x8 a[4], b[4];
+  for (int i = 0; i < 4; ++i) { a[i] = in[(threadIdx.x + i * 512) % 1536]; b[i] = in[(threadIdx.x + (4 + i) * 512) % 1536]; }
+  float s = 0;
+  if (SHAPE == 32) {
+    f32x16 acc[4][2];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b[j], a[i], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  } else {
+    f32x4 acc[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b[j], a[i], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) s += acc[i][j][r];
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int SHAPE> void run8(const void* din, float* dout) {
+  const int iters = g_iters;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(k8<SHAPE>, dim3(256), dim3(512), 0, 0, (const i32x8*)din, dout, 1000);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(k8<SHAPE>, dim3(256), dim3(512), 0, 0, (const i32x8*)din, dout, iters);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  double flops = 256.0 * 8 * iters * (SHAPE == 32 ? 16 * 2.0 * 32 * 32 * 64 : 32 * 2.0 * 16 * 16 * 128);
+  printf("e4m3 %s: %.1f TFLOP/s (%.2f ms)\n", SHAPE == 32 ? "32x32x64 " : "16x16x128", flops / (ms * 1e-3) / 1e12, ms);
+}
 template <int WAVES> void run(const bf16x8* din, float* dout, int blocks) {
   const int iters = g_iters;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -80,6 +124,12 @@ int main(int argc, char** argv) {
   if (argc > 1) g_iters = atoi(argv[1]);
   if (argc > 2) {  // long alternating runs: which shape sustains more under the power cap
     for (int r = 0; r < 4; ++r) { run<8>(din, dout, 256); run16<8>(din, dout, 256); }
+    {  // random e4m3 bytes (exponent field never all-ones: no NaN encodings)
+      unsigned char* hb = (unsigned char*)malloc(1536 * 32);
+      for (int i = 0; i < 1536 * 32; ++i) { unsigned char v = (unsigned char)(rand() & 0xff); if ((v & 0x7f) == 0x7f) v ^= 1; hb[i] = v; }
+      void* d8; hipMalloc(&d8, 1536 * 32); hipMemcpy(d8, hb, 1536 * 32, hipMemcpyHostToDevice);
+      for (int r = 0; r < 3; ++r) { run8<32>(d8, dout); run8<16>(d8, dout); }
+    }
     return 0;
   }
   run<8>(din, dout, 256);
