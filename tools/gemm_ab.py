@@ -30,4 +30,24 @@ for (m, n, k) in shapes:
     ms = e0.elapsed_time(e1) / 12
     tot_t += ms; tot_f += 2.0 * m * n * k
     line.append(f"{2.0 * m * n * k / (ms * 1e-3) / 1e12:6.1f}")
+if os.environ.get("GEMM_TORCH") == "1":  # the vendor library on the same operands (torch.mm -> hipBLASLt), for the record; never on the product path
+    tt = tf = 0
+    tl = []
+    for (m, n, k) in shapes:
+        z = 0 if os.environ.get("GEMM_ZERO") == "1" else 1
+        a = (torch.rand(m, k, device="cuda") * 2 - 1).to(torch.bfloat16) * z
+        bt = ((torch.rand(n, k, device="cuda") * 2 - 1).to(torch.bfloat16) * z)
+        for _ in range(3):
+            torch.mm(a, bt.t())
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(12):
+            torch.mm(a, bt.t())
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 12
+        tt += ms; tf += 2.0 * m * n * k
+        tl.append(f"{2.0 * m * n * k / (ms * 1e-3) / 1e12:6.1f}")
+    print(f"{'torch.mm (hipBLASLt)':28s} M={M}: " + " ".join(tl) + f" | all {tf / (tt * 1e-3) / 1e12:.1f} TF")
 print(f"{os.path.basename(_lib.LIB_PATH):28s} M={M}: " + " ".join(line) + f" | all {tot_f / (tot_t * 1e-3) / 1e12:.1f} TF")
