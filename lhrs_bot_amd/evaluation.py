@@ -297,6 +297,8 @@ def eval_parse_option(args=None, data_target: bool = False, data_type: bool = Fa
         for part in rest[:-1]:
             node = node.setdefault(part, ConfigDict())
         node[rest[-1]] = yaml.safe_load(v)
+    if config.get("batch_size") is None:
+        config.batch_size = 1
     return config
 
 

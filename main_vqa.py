@@ -36,7 +36,7 @@ def main(config):
     tokenizer = model.text.tokenizer
     cls = RSVQAHR if config.data_type == "HR" else RSVQALR
     dataset = cls(root=config.data_target, image_root=config.data_path, image_transform=build_vlp_transform(config, is_train=False), split="test",
-                  token_prefix="<image>[VQA] ", prompt_type=config.prompt_template, tokenizer=tokenizer)
+                  token_prefix="<image>[VQA] ", prompt_type=config.get("prompt_template", "llava_llama_2"), tokenizer=tokenizer)
     logger.info(f"Data Length: {len(dataset)}")
     data_loader = torch.utils.data.DataLoader(dataset, num_workers=int(config.workers), pin_memory=True, batch_size=int(config.batch_size), shuffle=False,
                                               collate_fn=DataCollatorForVQASupervisedDataset(tokenizer))
