@@ -248,3 +248,15 @@ def test_sampling_warpers_match_hf():
             keep = ~torch.isinf(want)
             assert torch.allclose(got[keep], want[keep], rtol=1e-6, atol=1e-6)
             assert (keep.sum(-1) >= 1).all()
+
+
+def test_generated_gemm_schedule_is_current():
+    """csrc/gemm_256s_sched.inc is generated: the committed file must be what tools/gen_gemm16_sched.py prints today."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_gemm16_sched.py")], capture_output=True, text=True, check=True,
+                         env={k: v for k, v in os.environ.items() if k != "DMA_SLOTS"}).stdout
+    assert out == open(os.path.join(root, "lhrs_bot_amd", "csrc", "gemm_256s_sched.inc")).read()
+    for name in ("S_BLOCK0", "S_BLOCK1"):  # 16 MFMAs per k-block, every fragment re-read exactly once per block
+        body = out.split(f"#define {name}(aa, ba)")[1].split("#define")[0]
+        assert body.count("MF(") == 16 and body.count("RDQ(") == 8
