@@ -544,10 +544,11 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
     // readfirstlane so that the loop strength reduction cannot fold it into four loop-carried 64-bit VGPR pointers (8 registers)
     const int kb_ = __builtin_amdgcn_readfirstlane(((!K2P || kt < nk1) ? kt : kt - nk1) * (BK * 2));
     const char* sp = ((!K2P || kt < nk1) ? base1 : base2) + kb_;
-    unsigned vo = (!K2P || kt < nk1) ? o1[j] : o2[K2P ? j : 0];
-    asm volatile("" : "+v"(vo));  // opaque at every use: base + offset cannot be hoisted out of the k-loop as a 64-bit VGPR pair per piece
-    const char* p = sp + vo;
-    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + buf * STAGE + dst0 + j * 1024), 16, 0, 0);
+    const unsigned vo = (!K2P || kt < nk1) ? o1[j] : o2[K2P ? j : 0];
+    // the instruction itself, in its saddr form (SGPR-pair base + 32-bit lane offset): through the builtin the compiler forms a 64-bit VGPR
+    // address with two v_lshl_add_u64 and a v_mov per piece - three VALU instructions in the MFMA stream for every DMA
+    const unsigned lds_dst = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + buf * STAGE + dst0 + j * 1024;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(sp), "s"(lds_dst) : "memory", "m0");
   };
 
   // fragment of 16 rows x 32 k: lane -> row (lane & 15), 16-byte chunk kb * 4 + (lane >> 4) of the 128-byte row (swizzled)

@@ -49,6 +49,9 @@ __global__ __launch_bounds__(256, 1) void gemm_u(Args g) {
     vo = 0;
 #endif
     asm volatile("" : "+v"(vo));
+#ifdef ABL_ONELANE
+    if (lane == 0)  // same instruction count, 16 bytes instead of 1 KiB per instruction
+#endif
     __builtin_amdgcn_global_load_lds((gptr_t)(base + kb_ + vo), (lptr_t)(smem + buf * STAGE + dst0 + j * 1024), 16, 0, 0);
   };
   const int wm = wave >> 1, wn = wave & 1;
