@@ -43,16 +43,9 @@ __global__ __launch_bounds__(256, 1) void gemm_u(Args g) {
 #ifdef ABL_NODMA
     return;
 #endif
-    const int kb_ = __builtin_amdgcn_readfirstlane(kt * (BK * 2));
-    unsigned vo = off[j];
-#ifdef ABL_SAMELINE
-    vo = 0;
-#endif
-    asm volatile("" : "+v"(vo));
-#ifdef ABL_ONELANE
-    if (lane == 0)  // same instruction count, 16 bytes instead of 1 KiB per instruction
-#endif
-    __builtin_amdgcn_global_load_lds((gptr_t)(base + kb_ + vo), (lptr_t)(smem + buf * STAGE + dst0 + j * 1024), 16, 0, 0);
+    const char* sp = base + (long)kt * (BK * 2);
+    const unsigned lds_dst = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + buf * STAGE + dst0 + j * 1024;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off[j]), "s"(sp), "s"(lds_dst) : "memory", "m0");
   };
   const int wm = wave >> 1, wn = wave & 1;
   const int sw = ((lane & 15) >> 1) & 7;
