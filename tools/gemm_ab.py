@@ -15,8 +15,9 @@ tot_t = tot_f = 0
 line = []
 for (m, n, k) in shapes:
     z = 0 if os.environ.get("GEMM_ZERO") == "1" else 1  # zeros: no power limit, the schedule alone
-    a = (torch.rand(m, k, device="cuda") * 2 - 1).to(torch.bfloat16) * z
-    b = (torch.rand(n, k, device="cuda") * 2 - 1).to(torch.bfloat16) * z
+    pad = int(os.environ.get("GEMM_PAD", "0"))  # extra elements in the leading dimension of both operands (power-of-two row strides vs not)
+    a = ((torch.rand(m, k + pad, device="cuda") * 2 - 1).to(torch.bfloat16) * z)[:, :k]
+    b = ((torch.rand(n, k + pad, device="cuda") * 2 - 1).to(torch.bfloat16) * z)[:, :k]
     c = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
     for _ in range(3):
         hk.gemm_nt(a, b, out=c)
