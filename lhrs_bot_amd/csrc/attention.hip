@@ -136,13 +136,21 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
   r[4] = (short)f2bf(b[0]); r[5] = (short)f2bf(b[1]); r[6] = (short)f2bf(b[2]); r[7] = (short)f2bf(b[3]);
   return r;
 }
-__device__ __forceinline__ float group_max(float v) {  // across the 4 lanes sharing (lane & 15)
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
+// Reductions across the 4 lanes that share (lane & 15), i.e. across the four 16-lane rows of the wavefront, WITHOUT the LDS crossbar
+// (ds_bpermute + s_waitcnt in the middle of a dependent softmax chain): gfx950's v_permlane16_swap (odd rows of the first operand <-> even
+// rows of the second) and v_permlane32_swap (upper half of the first <-> lower half of the second) applied to two copies of the value
+// leave in every lane the partner's value next to its own.
+__device__ __forceinline__ float group_max(float v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 __device__ __forceinline__ float group_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 __device__ __forceinline__ void store4bf(bf16_t* p, const f32x4& v, float s) {
   *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v[0] * s, v[1] * s), pack2bf(v[2] * s, v[3] * s));
@@ -518,6 +526,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_res_kernel(AttnArgs a) {
   __syncthreads();
   TrAddr<D> tv;
   tv.init(lds_v, lane);
+  const float c2 = a.scale * 1.4426950408889634f;  // scale * log2(e)
   const int G = (q_len + 15) >> 4;
   for (int p = 0;; ++p) {
     const int g = zigzag_group(p, wave, G, CAUSAL);
@@ -548,30 +557,39 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_res_kernel(AttnArgs a) {
       for (int db = 0; db < DB; ++db) tj.base[db] = tv.base[db] + j * TILE;
       bf16x4 v0lo[DB], v0hi[DB], v1lo[DB], v1hi[DB];
       tr_issue<D, 0>(tj, v0lo, v0hi);
+      // The kernel is VALU-bound (the softmax of a 64-key tile was ~200 VALU instructions against 32 MFMAs), so: (1) only a tile that
+      // crosses the causal diagonal or the end of the keys computes the mask - a wave-uniform test; (2) the running maximum m is kept in
+      // RAW score units and exp(scale * s - scale * m) is ONE fma into v_exp_f32 (exp2) with c2 = scale * log2(e)
+      const bool full = (j + 1) * 64 <= kv_len && (!CAUSAL || j * 64 + 63 <= g * 16 + coff);
+      if (!full) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = j * 64 + nb * 16 + fg * 4 + r;
+            const bool ok = key < kv_len && (!CAUSAL || key <= qrow + coff);
+            s[nb][r] = ok ? s[nb][r] : NEG_INF;
+          }
+      }
       float mx = NEG_INF;
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = j * 64 + nb * 16 + fg * 4 + r;
-          const bool ok = key < kv_len && (!CAUSAL || key <= qrow + coff);
-          s[nb][r] = ok ? s[nb][r] * a.scale : NEG_INF;
-          mx = fmaxf(mx, s[nb][r]);
-        }
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[nb][r]);
       mx = group_max(mx);
       const float m_new = fmaxf(m, mx);
       const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-      const float alpha = __expf(m - m_use);
+      const float mc = m_use * c2;
+      const float alpha = __builtin_amdgcn_exp2f(m * c2 - mc);
       float rs = 0.f;
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          s[nb][r] = __expf(s[nb][r] - m_use);
+          s[nb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[nb][r], c2, -mc));
           rs += s[nb][r];
         }
-      rs = group_sum(rs);
-      l = l * alpha + rs;
+      l = l * alpha + rs;  // this lane's 16 keys of the tile: the four lanes of a row are added up once, behind the last tile
       m = m_new;
 #pragma unroll
       for (int i = 0; i < DB; ++i) o[i] *= alpha;
@@ -585,12 +603,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_res_kernel(AttnArgs a) {
 #pragma unroll
       for (int db = 0; db < DB; ++db) o[db] = MFMA(join(v1lo[db], v1hi[db]), p1, o[db]);
     }
+    l = group_sum(l);
     if (qrow < q_len) {
       const float inv = l > 0.f ? 1.f / l : 0.f;
       bf16_t* op = a.o + (long)(q_off + qrow) * a.ldo + h * D + fg * 4;
 #pragma unroll
       for (int db = 0; db < DB; ++db) store4bf(op + db * 16, o[db], inv);
-      if (a.lse && fg == 0) a.lse[(long)(seq * a.H + h) * a.LTq + qrow] = (l > 0.f) ? m + __logf(l) : NEG_INF;
+      if (a.lse && fg == 0) a.lse[(long)(seq * a.H + h) * a.LTq + qrow] = (l > 0.f) ? m * a.scale + __logf(l) : NEG_INF;
     }
   }
 }
@@ -632,7 +651,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_res_kernel(AttnArgs a) {
       dof[ks] = *reinterpret_cast<const bf16x8*>(dop + ks * 32 + fg * 8);
     }
     const long stat = (long)(seq * a.H + h) * a.LTq + qrow_c;
-    const float lse_q = a.lse[stat], delta_q = a.delta[stat];
+    const float lse2 = a.lse[stat] * 1.4426950408889634f, delta_q = a.delta[stat], c2 = a.scale * 1.4426950408889634f;
     f32x4 dq[DB];
 #pragma unroll
     for (int i = 0; i < DB; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -658,15 +677,29 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_res_kernel(AttnArgs a) {
       for (int db = 0; db < DB; ++db) tj.base[db] = tk.base[db] + j * TILE;
       bf16x4 k0lo[DB], k0hi[DB], k1lo[DB], k1hi[DB];
       tr_issue<D, 0>(tj, k0lo, k0hi);
+      // VALU diet (see the forward kernel): P = exp2(s * c2 - lse * log2 e) is one fma + v_exp_f32, dS / scale = P * (dP - delta) (the
+      // scale goes on the finished dQ rows), and only a tile on the causal diagonal / past the last key computes the mask.  Rows beyond q_len compute
+      // garbage in their own lanes and are not stored.
+      const bool full = (j + 1) * 64 <= kv_len && (!CAUSAL || j * 64 + 63 <= g * 16 + coff);
+      if (full) {
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
+        for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = j * 64 + nb * 16 + fg * 4 + r;
-          const bool ok = key < kv_len && (!CAUSAL || key <= qrow + coff) && qrow < q_len;
-          const float pv = ok ? __expf(s[nb][r] * a.scale - lse_q) : 0.f;
-          s[nb][r] = ok ? pv * (dp[nb][r] - delta_q) * a.scale : 0.f;
-        }
+          for (int r = 0; r < 4; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[nb][r], c2, -lse2));
+            s[nb][r] = pv * (dp[nb][r] - delta_q);
+          }
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = j * 64 + nb * 16 + fg * 4 + r;
+            const bool ok = key < kv_len && (!CAUSAL || key <= qrow + coff) && qrow < q_len;
+            const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[nb][r], c2, -lse2));
+            s[nb][r] = ok ? pv * (dp[nb][r] - delta_q) : 0.f;
+          }
+      }
       const bf16x8 d0 = pack_frag(s[0], s[1]), d1 = pack_frag(s[2], s[3]);
       tr_wait<DB>(k0lo, k0hi);
       tr_issue<D, 1>(tj, k1lo, k1hi);
@@ -678,6 +711,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_res_kernel(AttnArgs a) {
       for (int db = 0; db < DB; ++db) dq[db] = MFMA(join(k1lo[db], k1hi[db]), d1, dq[db]);
     }
     if (qrow < q_len) {
+#pragma unroll
+      for (int db = 0; db < DB; ++db) dq[db] *= a.scale;
       if (a.rope_cos != nullptr) rope_bwd_inplace<DB>(dq, a, (long)q_off + qrow, fg);
       bf16_t* pq = a.dq + (long)(q_off + qrow) * a.ld_dq + h * D + fg * 4;
 #pragma unroll
