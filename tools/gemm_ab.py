@@ -16,8 +16,9 @@ line = []
 for (m, n, k) in shapes:
     z = 0 if os.environ.get("GEMM_ZERO") == "1" else 1  # zeros: no power limit, the schedule alone
     pad = int(os.environ.get("GEMM_PAD", "0"))  # extra elements in the leading dimension of both operands (power-of-two row strides vs not)
-    a = ((torch.rand(m, k + pad, device="cuda") * 2 - 1).to(torch.bfloat16) * z)[:, :k]
-    b = ((torch.rand(n, k + pad, device="cuda") * 2 - 1).to(torch.bfloat16) * z)[:, :k]
+    pad_a = int(os.environ.get("GEMM_PAD_A", pad)); pad_b = int(os.environ.get("GEMM_PAD_B", pad))
+    a = ((torch.rand(m, k + pad_a, device="cuda") * 2 - 1).to(torch.bfloat16) * z)[:, :k]
+    b = ((torch.rand(n, k + pad_b, device="cuda") * 2 - 1).to(torch.bfloat16) * z)[:, :k]
     c = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
     for _ in range(3):
         hk.gemm_nt(a, b, out=c)
