@@ -764,6 +764,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_res_kernel(AttnArgs a) {
     for (int i = i0; i < nq_tiles; ++i) {
       const char* qt = lds_q + i * TILE;
       const char* dot = lds_do + i * TILE;
+      // the row statistics of the tile's 64 queries (HBM / L2; the LDS is full) are requested in FRONT of the tile's 32 S / dP MFMAs; their
+      // 32 registers are paid for by ONE set of transposed-operand registers below instead of two
+      f32x4 lq[4], dl[4];
+#pragma unroll
+      for (int qb = 0; qb < 4; ++qb) {
+        lq[qb] = *reinterpret_cast<const f32x4*>(lsebase + i * 64 + qb * 16 + fg * 4);
+        dl[qb] = *reinterpret_cast<const f32x4*>(deltabase + i * 64 + qb * 16 + fg * 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       f32x4 s[4], dp[4];
 #pragma unroll
       for (int qb = 0; qb < 4; ++qb) {
@@ -778,41 +787,42 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_res_kernel(AttnArgs a) {
       TrAddr<D> tqi, tdi;
 #pragma unroll
       for (int db = 0; db < DB; ++db) { tqi.base[db] = tq.base[db] + i * TILE; tdi.base[db] = tdo.base[db] + i * TILE; }
-      bf16x4 alo[DB], ahi[DB], blo[DB], bhi[DB];
-      tr_issue<D, 0>(tdi, alo, ahi);
+      bf16x4 alo[DB], ahi[DB];
 #pragma unroll
       for (int qb = 0; qb < 4; ++qb) {
-        const f32x4 lq = *reinterpret_cast<const f32x4*>(lsebase + i * 64 + qb * 16 + fg * 4);
-        const f32x4 dl = *reinterpret_cast<const f32x4*>(deltabase + i * 64 + qb * 16 + fg * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int q = i * 64 + qb * 16 + fg * 4 + r;
           const bool ok = q < q_len && key < kv_len && (!CAUSAL || key <= q + coff);
-          const float pv = ok ? __expf(s[qb][r] * a.scale - lq[r]) : 0.f;
-          dp[qb][r] = ok ? pv * (dp[qb][r] - dl[r]) * a.scale : 0.f;
+          const float pv = ok ? __expf(s[qb][r] * a.scale - lq[qb][r]) : 0.f;
+          dp[qb][r] = ok ? pv * (dp[qb][r] - dl[qb][r]) * a.scale : 0.f;
           s[qb][r] = pv;
         }
       }
       const bf16x8 p0 = pack_frag(s[0], s[1]), p1 = pack_frag(s[2], s[3]);
       const bf16x8 d0 = pack_frag(dp[0], dp[1]), d1 = pack_frag(dp[2], dp[3]);
+      // one register set: the next transposed read goes out right behind the MFMAs that consume the previous one (an MFMA has read its
+      // operands long before an LDS read returns) and its latency runs under those eight MFMAs
+      tr_issue<D, 0>(tdi, alo, ahi);
       tr_wait<DB>(alo, ahi);
-      tr_issue<D, 0>(tqi, blo, bhi);
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int db = 0; db < DB; ++db) dv[db] = MFMA(join(alo[db], ahi[db]), p0, dv[db]);
-      tr_wait<DB>(blo, bhi);
-      tr_issue<D, 1>(tdi, alo, ahi);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int db = 0; db < DB; ++db) dk[db] = MFMA(join(blo[db], bhi[db]), d0, dk[db]);
+      tr_issue<D, 0>(tqi, alo, ahi);
       tr_wait<DB>(alo, ahi);
-      tr_issue<D, 1>(tqi, blo, bhi);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) dk[db] = MFMA(join(alo[db], ahi[db]), d0, dk[db]);
       __builtin_amdgcn_sched_barrier(0);
+      tr_issue<D, 1>(tdi, alo, ahi);
+      tr_wait<DB>(alo, ahi);
 #pragma unroll
       for (int db = 0; db < DB; ++db) dv[db] = MFMA(join(alo[db], ahi[db]), p1, dv[db]);
-      tr_wait<DB>(blo, bhi);
+      __builtin_amdgcn_sched_barrier(0);
+      tr_issue<D, 1>(tqi, alo, ahi);
+      tr_wait<DB>(alo, ahi);
 #pragma unroll
-      for (int db = 0; db < DB; ++db) dk[db] = MFMA(join(blo[db], bhi[db]), d1, dk[db]);
+      for (int db = 0; db < DB; ++db) dk[db] = MFMA(join(alo[db], ahi[db]), d1, dk[db]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (key < kv_rows) {
       if (a.rope_cos != nullptr) rope_bwd_inplace<DB>(dk, a, (long)kv_off + key, fg);
