@@ -175,6 +175,13 @@ int lhrs_attn_bwd_rope(const void* q, long ldq, const void* k, long ldk, const v
                        long ld_do, const float* lse, const float* delta, void* dq, long ld_dq, void* dk, long ld_dk, void* dv,
                        long ld_dv, const int* desc, int nseq, int H, int D, int max_q, int max_kv, int LTq, int causal,
                        float scale, const float* cos_t, const float* sin_t, int pos_mod, int pos0, long rows, void* stream);
+/* lhrs_attn_delta + lhrs_attn_bwd[_rope] in one call (same reference lines): o = forward output rows, delta is WRITTEN.  With LDS-resident
+ * operands (the training path) the dQ kernel computes delta = rowsum(dO * O) itself - one launch and one pass over O / dO less per layer;
+ * longer sequences launch the delta kernel internally.  cos_t == NULL: no rotation. */
+int lhrs_attn_bwd_o(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long ld_do,
+                    const void* o, long ldo, const float* lse, float* delta, void* dq, long ld_dq, void* dk, long ld_dk, void* dv,
+                    long ld_dv, const int* desc, int nseq, int H, int D, int max_q, int max_kv, int LTq, int causal, float scale,
+                    const float* cos_t, const float* sin_t, int pos_mod, int pos0, long rows, void* stream);
 
 /* ---- element-wise / layout -------------------------------------------------------------------------- *
  * patchify/assemble: HF CLIPVisionEmbeddings (rgb_vision_modal.py:166-172); rope: HF apply_rotary_pos_emb;

@@ -48,6 +48,11 @@ struct AttnArgs {
   const float* rope_cos;
   const float* rope_sin;
   int rope_mod, rope_pos0;
+  // backward, resident dQ kernel only (lhrs_attn_bwd_o): the forward output rows - delta = rowsum(dO * O) is then computed by the kernel for the
+  // rows it loads anyway and written to delta_w (which the dK/dV kernel, launched behind it, reads) instead of by a launch of its own
+  const bf16_t* o_in;
+  long ld_oin;
+  float* delta_w;
 };
 
 constexpr float NEG_INF = -__builtin_huge_valf();
@@ -651,7 +656,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_res_kernel(AttnArgs a) {
       dof[ks] = *reinterpret_cast<const bf16x8*>(dop + ks * 32 + fg * 8);
     }
     const long stat = (long)(seq * a.H + h) * a.LTq + qrow_c;
-    const float lse2 = a.lse[stat] * 1.4426950408889634f, delta_q = a.delta[stat], c2 = a.scale * 1.4426950408889634f;
+    float delta_q;
+    if (a.o_in != nullptr) {  // delta of this row from the dO fragments already in registers and the matching O fragments
+      const bf16_t* op = a.o_in + (long)(q_off + qrow_c) * a.ld_oin + h * D;
+      float part = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 of = *reinterpret_cast<const bf16x8*>(op + ks * 32 + fg * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part += bf2f((bf16_t)dof[ks][e]) * bf2f((bf16_t)of[e]);
+      }
+      delta_q = group_sum(part);
+      if (fg == 0 && qrow < q_len) a.delta_w[stat] = delta_q;
+    } else {
+      delta_q = a.delta[stat];
+    }
+    const float lse2 = a.lse[stat] * 1.4426950408889634f, c2 = a.scale * 1.4426950408889634f;
     f32x4 dq[DB];
 #pragma unroll
     for (int i = 0; i < DB; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -966,8 +986,15 @@ static int attn_bwd_impl(const void* q, long ldq, const void* k, long ldk, const
                          const void* dout, long ld_do, const float* lse, const float* delta, void* dq, long ld_dq,
                          void* dk, long ld_dk, void* dv, long ld_dv, const int* desc, int nseq, int H, int D,
                          int max_q, int max_kv, int LTq, int causal, float scale, const float* rope_cos, const float* rope_sin,
-                         int rope_mod, int rope_pos0, long rope_rows, void* stream) {
+                         int rope_mod, int rope_pos0, long rope_rows, void* stream, const void* o = nullptr, long ldo = 0) {
   AttnArgs a; memset(&a, 0, sizeof(a));
+  if (o != nullptr) {
+    // delta is an OUTPUT here: by the resident dQ kernel when it runs (it is launched in front of the dK/dV kernel), by a launch of the
+    // delta kernel otherwise
+    const int rmax0 = D == 128 ? res_rows<128>() : res_rows<64>();
+    if (max_kv <= rmax0) { a.o_in = (const bf16_t*)o; a.ld_oin = ldo; a.delta_w = const_cast<float*>(delta); }
+    else if (lhrs_attn_delta(o, ldo, dout, ld_do, const_cast<float*>(delta), desc, nseq, H, D, max_q, LTq, stream)) return -1;
+  }
   const bool rope = rope_cos != nullptr;
   const int rmax_ = D == 128 ? res_rows<128>() : res_rows<64>();
   const bool fuse_rope = rope && max_kv <= rmax_ && max_q <= rmax_;  // both resident kernels run: the rotation rides in their stores
@@ -1029,4 +1056,17 @@ extern "C" int lhrs_attn_bwd_rope(const void* q, long ldq, const void* k, long l
   LHRS_REQUIRE(cos_t && sin_t && pos_mod > 0 && rows > 0, "attn_bwd_rope: cos/sin tables, pos_mod=%d, rows=%ld", pos_mod, rows);
   return attn_bwd_impl(q, ldq, k, ldk, v, ldv, dout, ld_do, lse, delta, dq, ld_dq, dk, ld_dk, dv, ld_dv, desc, nseq, H, D, max_q, max_kv, LTq,
                        causal, scale, cos_t, sin_t, pos_mod, pos0, rows, stream);
+}
+
+// lhrs_attn_delta + lhrs_attn_bwd / lhrs_attn_bwd_rope as ONE call: o [tokens, ldo] are the forward output rows, delta [nseq][H][LTq] is
+// WRITTEN (workspace).  When both operand matrices fit the LDS (every attention of the training path) the resident dQ kernel computes
+// delta = rowsum(dO * O) for the rows it loads anyway - one launch and one pass over O and dO per layer less; cos_t == nullptr: no rotation.
+extern "C" int lhrs_attn_bwd_o(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long ld_do,
+                               const void* o, long ldo, const float* lse, float* delta, void* dq, long ld_dq, void* dk, long ld_dk,
+                               void* dv, long ld_dv, const int* desc, int nseq, int H, int D, int max_q, int max_kv, int LTq, int causal,
+                               float scale, const float* cos_t, const float* sin_t, int pos_mod, int pos0, long rows, void* stream) {
+  LHRS_REQUIRE(o != nullptr && delta != nullptr, "attn_bwd_o: o=%p delta=%p", o, (void*)delta);
+  LHRS_REQUIRE(cos_t == nullptr || (sin_t && pos_mod > 0 && rows > 0), "attn_bwd_o: cos/sin tables, pos_mod=%d, rows=%ld", pos_mod, rows);
+  return attn_bwd_impl(q, ldq, k, ldk, v, ldv, dout, ld_do, lse, delta, dq, ld_dq, dk, ld_dk, dv, ld_dv, desc, nseq, H, D, max_q, max_kv, LTq,
+                       causal, scale, cos_t, sin_t, cos_t ? pos_mod : 1, cos_t ? pos0 : 0, cos_t ? rows : 0, stream, o, ldo);
 }

@@ -376,6 +376,17 @@ def attn_bwd(q, k, v, dout, lse, delta, dq, dk, dv, desc, nseq, H, D, max_q, max
     _lib.check(st, "attn_bwd")
 
 
+def attn_bwd_o(q, k, v, dout, o, lse, delta, dq, dk, dv, desc, nseq, H, D, max_q, max_kv, LTq, causal, scale, rope=None):
+    """attn_delta + attn_bwd in one call: `o` are the forward output rows, `delta` [nseq, H, LTq] fp32 is WRITTEN (the resident dQ kernel
+    computes rowsum(dO * O) for the rows it loads anyway; longer sequences launch the delta kernel inside)."""
+    cos_t, sin_t, pos_mod, pos0 = rope if rope is not None else (None, None, 1, 0)
+    st = _L().lhrs_attn_bwd_o(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), dout.data_ptr(),
+                              dout.stride(0), o.data_ptr(), o.stride(0), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dq.stride(0),
+                              dk.data_ptr(), dk.stride(0), dv.data_ptr(), dv.stride(0), desc.data_ptr(), nseq, H, D, max_q, max_kv, LTq,
+                              int(causal), float(scale), _p(cos_t), _p(sin_t), int(pos_mod), int(pos0), dq.shape[0], _stream())
+    _lib.check(st, "attn_bwd_o")
+
+
 # --------------------------------------------------------------------------------------------- element-wise
 def patchify(rgb, P=14, KP=640):
     B, C, H, W = rgb.shape

@@ -920,9 +920,9 @@ class TextModal:
                 do = hk.scatter_rows(do, rows_t, torch.empty((M, d), device=self.device, dtype=torch.bfloat16))   # only query rows are read
                 dx_mid = hk.scatter_rows(dx_mid, rows_t, torch.zeros((M, d), device=self.device, dtype=torch.bfloat16))  # residual path: 0 elsewhere
                 dqkv[:, :d].zero_()                                                                                # dq exists for the query rows only
-            hk.attn_delta(s["o_full"], do, delta, adesc, B, H, hd, max_q, LT)
-            hk.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], do, s["lse"], delta, dqkv[:, :d], dqkv[:, d:2 * d],
-                        dqkv[:, 2 * d:], adesc, B, H, hd, max_q, S, LT, True, scale, rope=(self.cos, self.sin, S, 0))  # inverse RoPE in the dq / dk stores
+            # delta = rowsum(dO * O) inside the dQ kernel (one launch and one pass over O / dO less), inverse RoPE in the dq / dk stores
+            hk.attn_bwd_o(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], do, s["o_full"], s["lse"], delta, dqkv[:, :d], dqkv[:, d:2 * d],
+                          dqkv[:, 2 * d:], adesc, B, H, hd, max_q, S, LT, True, scale, rope=(self.cos, self.sin, S, 0))
             h1 = hk.rmsnorm_fwd(s["x_in"], L["ln1_w"], self.eps) if lo is not None and "qkv" in lo.groups else None
             dh1 = self._lin_bwd(li, "qkv", dqkv, L["qkv_wT"], h1, s.get("T_qkv"), q8=self._q8(L, "qkv_wT"), drop=self._drop(s, "qkv"))
             if self.base8:

@@ -273,6 +273,43 @@ def test_attention_long_sequences_use_tiled_kernels():
     run_attention_case(64, 4, [(100, 900, 900)], causal=False, same_qkv_buffer=False)
 
 
+@pytest.mark.parametrize("D,H,seqs,causal", [(128, 4, [(273, 273, 273), (273, 273, 250), (65, 65, 3)], True), (64, 4, [(64, 320, 320), (48, 304, 304)], False),
+                                              (128, 2, [(700, 700, 650)], True)])
+def test_attention_backward_with_fused_delta(D, H, seqs, causal):
+    """lhrs_attn_bwd_o (delta = rowsum(dO * O) inside the resident dQ kernel; the delta kernel launched internally for long sequences) against
+    lhrs_attn_delta + lhrs_attn_bwd: delta to fp32 summation-order noise, dq / dk / dv to bf16 rounding, with and without the fused inverse RoPE."""
+    g = torch.Generator().manual_seed(D + len(seqs))
+    tq, tk = sum(s[0] for s in seqs), sum(s[1] for s in seqs)
+    scale = 1.0 / math.sqrt(D)
+    q, k, v, do = (bf(torch.randn(n, H * D, generator=g)).to(DEV) for n in (tq, tk, tk, tq))
+    entries, qo, ko = [], 0, 0
+    for (lq, lk, kvl) in seqs:
+        entries.append((qo, lq, ko, kvl, lk, 0)); qo += lq; ko += lk
+    nseq, desc = len(seqs), hk.make_desc(entries, DEV)
+    max_q, max_kv = max(s[0] for s in seqs), max(s[1] for s in seqs)
+    LTq = hk.pad64(max_q)
+    o = torch.zeros(tq, H * D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(nseq, H, LTq, device=DEV)
+    hk.attn_fwd(q, k, v, o, lse, desc, nseq, H, D, max_q, max_kv, LTq, causal, scale)
+    S = seqs[0][0]
+    ropes = [None]
+    if D == 128 and all(s_[0] == s_[1] == S for s_ in seqs):
+        pos = torch.arange(S, device=DEV, dtype=torch.float32)[:, None] * (10000.0 ** (-torch.arange(0, D, 2, device=DEV, dtype=torch.float32) / D))[None]
+        ropes.append((pos.cos().contiguous(), pos.sin().contiguous(), S, 0))
+    for rope in ropes:
+        delta_a = torch.zeros(nseq, H, LTq, device=DEV)
+        hk.attn_delta(o, do, delta_a, desc, nseq, H, D, max_q, LTq)
+        ga = [torch.zeros_like(t) for t in (q, k, v)]
+        hk.attn_bwd(q, k, v, do, lse, delta_a, *ga, desc, nseq, H, D, max_q, max_kv, LTq, causal, scale, rope=rope)
+        delta_b = torch.full((nseq, H, LTq), float("nan"), device=DEV)
+        gb = [torch.zeros_like(t) for t in (q, k, v)]
+        hk.attn_bwd_o(q, k, v, do, o, lse, delta_b, *gb, desc, nseq, H, D, max_q, max_kv, LTq, causal, scale, rope=rope)
+        for i, (lq, _, _) in enumerate(seqs):
+            assert torch.allclose(delta_b[i, :, :lq], delta_a[i, :, :lq], rtol=1e-5, atol=1e-5)
+        for x, y, name in zip(gb, ga, ("dq", "dk", "dv")):
+            assert rel_err(x, y) < 2e-3, name
+
+
 def test_attention_small_ragged():
     run_attention_case(128, 2, [(1, 1, 1), (17, 17, 17), (64, 64, 64), (65, 65, 3)], causal=True, same_qkv_buffer=False)
 

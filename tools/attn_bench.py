@@ -39,3 +39,10 @@ t = timeit(lambda: hk.attn_delta(o, do, delta, desc, B, H, D, S, LT))
 print(f"delta {t:8.1f} us")
 t = timeit(lambda: hk.attn_bwd(q, k, v, do, lse, delta, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], desc, B, H, D, S, S, LT, True, sc))
 print(f"bwd   {t:8.1f} us  {2.5 * f_fwd / t / 1e6:7.1f} TF (causal-counted)")
+def both():
+    hk.attn_delta(o, do, delta, desc, B, H, D, S, LT)
+    hk.attn_bwd(q, k, v, do, lse, delta, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], desc, B, H, D, S, S, LT, True, sc)
+t = timeit(both)
+print(f"delta + bwd          {t:8.1f} us")
+t = timeit(lambda: hk.attn_bwd_o(q, k, v, do, o, lse, delta, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], desc, B, H, D, S, S, LT, True, sc))
+print(f"bwd_o (fused delta)  {t:8.1f} us")
