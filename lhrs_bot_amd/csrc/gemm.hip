@@ -517,38 +517,48 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
   const int rmax = (isA ? g.M : g.N) - 1;
   const int nk1 = g.K / BK;
   const int nk = (g.K + (K2P ? g.K2 : 0)) / BK;  // >= 2 (host guarantees)
-  // global byte offsets of this lane's four DMA rows for tile (tm_, tn_); K2P: a second operand pair (the fused LoRA product) follows the
-  // first in the k-loop - a template parameter so that the plain product does not carry four more offset registers through the main loop
-  auto dma_rows = [&](int tm_, int tn_, unsigned (&o1)[4], unsigned (&o2)[K2P ? 4 : 1]) {
+  // row of the operand that piece j of this lane reads for tile (tm_, tn_)
+  auto dma_row = [&](int tm_, int tn_, int j) {
     const int row0 = isA ? tm_ * BM : tn_ * BN;
+    const int ridx = (wave & 7) * 4 + j;
+    int row = min(row0 + ridx * 8 + (lane >> 3), rmax);
+    if (EPI == 1 && !isA) {  // B tile row r = 64*wn + 32*half + i  <-  weight row half*ff + tn*128 + wn*32 + i
+      const int r = ridx * 8 + (lane >> 3);
+      row = ((r >> 5) & 1) * g.ff + tn_ * 128 + (r >> 6) * 32 + (r & 31);
+    }
+    if (EPI == 3 && !isA && tn_ * BN < g.rope_cols) {  // B tile row r = 64*wn + 32*half + i  <-  head 2*tn + (wn >> 1), dim 64*half + 32*(wn & 1) + i
+      const int r = ridx * 8 + (lane >> 3);
+      row = tn_ * BN + ((r >> 7) << 7) + ((r >> 5) & 1) * 64 + ((r >> 6) & 1) * 32 + (r & 31);
+    }
+    return row;
+  };
+  // global byte offsets of this lane's four DMA rows for tile (tm_, tn_) in the FIRST operand pair.  The second pair (K2P: the fused LoRA
+  // product, one or two stages at the end of the k-loop) gets its offsets where its pieces are issued: four more registers carried
+  // through the main loop spilled there, and a scratch reload in the MFMA stream is followed by a full `vmcnt` wait - behind fresh DMA
+  auto dma_rows = [&](int tm_, int tn_, unsigned (&o1)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int ridx = (wave & 7) * 4 + j;
       const int lchunk = (lane & 7) ^ ((((j & 1) << 2) + (lane >> 4)) & 7);
-      int row = min(row0 + ridx * 8 + (lane >> 3), rmax);
-      if (EPI == 1 && !isA) {  // B tile row r = 64*wn + 32*half + i  <-  weight row half*ff + tn*128 + wn*32 + i
-        const int r = ridx * 8 + (lane >> 3);
-        row = ((r >> 5) & 1) * g.ff + tn_ * 128 + (r >> 6) * 32 + (r & 31);
-      }
-      if (EPI == 3 && !isA && tn_ * BN < g.rope_cols) {  // B tile row r = 64*wn + 32*half + i  <-  head 2*tn + (wn >> 1), dim 64*half + 32*(wn & 1) + i
-        const int r = ridx * 8 + (lane >> 3);
-        row = tn_ * BN + ((r >> 7) << 7) + ((r >> 5) & 1) * 64 + ((r >> 6) & 1) * 32 + (r & 31);
-      }
-      o1[j] = (unsigned)(((long)row * ld1 + lchunk * 8) * 2);
-      if (K2P) o2[j] = (unsigned)(((long)row * ld2 + lchunk * 8) * 2);
+      o1[j] = (unsigned)(((long)dma_row(tm_, tn_, j) * ld1 + lchunk * 8) * 2);
     }
   };
   const int dst0 = (isA ? 0 : A_BYTES) + (wave & 7) * 4096;
-  auto issue_to = [&](const unsigned (&o1)[4], const unsigned (&o2)[K2P ? 4 : 1], int kt, int buf, int j) {
-    // wave-uniform 64-bit base (SGPR pair) + the lane's 32-bit row offset: the saddr form of global_load_lds.  The k offset goes through
-    // readfirstlane so that the loop strength reduction cannot fold it into four loop-carried 64-bit VGPR pointers (8 registers)
-    const int kb_ = __builtin_amdgcn_readfirstlane(((!K2P || kt < nk1) ? kt : kt - nk1) * (BK * 2));
-    const char* sp = ((!K2P || kt < nk1) ? base1 : base2) + kb_;
-    const unsigned vo = (!K2P || kt < nk1) ? o1[j] : o2[K2P ? j : 0];
-    // the instruction itself, in its saddr form (SGPR-pair base + 32-bit lane offset): through the builtin the compiler forms a 64-bit VGPR
-    // address with two v_lshl_add_u64 and a v_mov per piece - three VALU instructions in the MFMA stream for every DMA
+  // wave-uniform 64-bit base (SGPR pair) + the lane's 32-bit row offset: the saddr form of global_load_lds.  The k offset goes through
+  // readfirstlane so that the loop strength reduction cannot fold it into four loop-carried 64-bit VGPR pointers (8 registers).  The
+  // instruction itself is inline asm: through the builtin the compiler forms a 64-bit VGPR address with two v_lshl_add_u64 and a v_mov per
+  // piece - three VALU instructions in the MFMA stream for every DMA
+  auto dma_piece = [&](const char* sp, unsigned vo, int buf, int j) {
     const unsigned lds_dst = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + buf * STAGE + dst0 + j * 1024;
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(sp), "s"(lds_dst) : "memory", "m0");
+  };
+  auto issue1 = [&](const unsigned (&o1)[4], int kt, int buf, int j) {  // stage kt < nk1 of the first pair
+    const int kb_ = __builtin_amdgcn_readfirstlane(kt * (BK * 2));
+    dma_piece(base1 + kb_, o1[j], buf, j);
+  };
+  auto issue2 = [&](int tm_, int tn_, int kt2, int buf, int j) {        // stage kt2 of the second pair (K2P)
+    const int kb_ = __builtin_amdgcn_readfirstlane(kt2 * (BK * 2));
+    const int lchunk = (lane & 7) ^ ((((j & 1) << 2) + (lane >> 4)) & 7);
+    dma_piece(base2 + kb_, (unsigned)(((long)dma_row(tm_, tn_, j) * ld2 + lchunk * 8) * 2), buf, j);
   };
 
   // fragment of 16 rows x 32 k: lane -> row (lane & 15), 16-byte chunk kb * 4 + (lane >> 4) of the 128-byte row (swizzled)
@@ -563,11 +573,11 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
 
   int tm, tn;
   tile_coords_lin(g, t, ntiles, tm, tn);
-  unsigned off1[4], off2[K2P ? 4 : 1];
-  dma_rows(tm, tn, off1, off2);
+  unsigned off1[4];
+  dma_rows(tm, tn, off1);
   int pb = 0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) issue_to(off1, off2, 0, 0, j);
+  for (int j = 0; j < 4; ++j) issue1(off1, 0, 0, j);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   bf16x8 A[4], B[4];
@@ -587,7 +597,10 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
     // stage 0 of this tile is in LDS buffer pb; the barrier publishes it and ends the previous tile's epilogue reads of the other buffer
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) issue_to(off1, off2, 1, pb ^ 1, j);
+    for (int j = 0; j < 4; ++j) {
+      if (!K2P || nk1 > 1) issue1(off1, 1, pb ^ 1, j);
+      else issue2(tm, tn, 0, pb ^ 1, j);
+    }
     {
       const unsigned aa = a0 ^ (unsigned)(pb * STAGE), ba = b0 ^ (unsigned)(pb * STAGE);
       RDQ(A[0], aa, 0); RDQ(A[1], aa, 2048); RDQ(A[2], aa, 4096); RDQ(A[3], aa, 6144);
@@ -603,16 +616,21 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
       { const unsigned aa = a0 ^ (so | 64u), ba = b0 ^ (so | 64u); S_BLOCK0(aa, ba) }                           \
       { const unsigned aa = a0 ^ sn, ba = b0 ^ sn; S_BLOCK1(aa, ba) }                                           \
     }
-#define ISS(j) issue_to(off1, off2, s + 2, (s + pb) & 1, j);
-    for (int s = 0; s < nk - 2; ++s) STAGE_S(s)
+#define ISS(j) issue1(off1, s + 2, (s + pb) & 1, j);
+    for (int s = 0; s < nk1 - 2; ++s) STAGE_S(s)   // !K2P: nk1 == nk, every stage but the last two
 #undef ISS
+    if (K2P) {  // the stages whose DMA slot fetches the second pair
+#define ISS(j) issue2(tm, tn, s + 2 - nk1, (s + pb) & 1, j);
+      for (int s = max(nk1 - 2, 0); s < nk - 2; ++s) STAGE_S(s)
+#undef ISS
+    }
     int ntm = 0, ntn = 0;
     if (has_next) {  // this tile's DMA rows are not needed any more (its last stage is in flight): the offsets become the next tile's
       tile_coords_lin(g, tnext, ntiles, ntm, ntn);
-      dma_rows(ntm, ntn, off1, off2);
+      dma_rows(ntm, ntn, off1);
     }
     // stage nk - 2: the buffer its barrier frees takes stage 0 of the NEXT tile
-#define ISS(j) if (has_next) issue_to(off1, off2, 0, (nk + pb) & 1, j);
+#define ISS(j) if (has_next) issue1(off1, 0, (nk + pb) & 1, j);
     STAGE_S(nk - 2)
 #undef ISS
 #undef STAGE_S
