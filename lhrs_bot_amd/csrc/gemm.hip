@@ -1343,6 +1343,29 @@ extern "C" int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int
     LHRS_REQUIRE(ld_gu == 2 * ff && ld_act == ff, "gemm_swiglu_fwd: the unfused fallback needs dense gu / act");
     return lhrs_swiglu_fwd(gu, act, M, ff, stream);
   }
+  // Tail rows, as in gemm_launch: when the tile rows that spill over the last full round of the 256 CUs are cheaper as a small-tile launch
+  // (M = 2184, the reference's micro-batch 8: 9 x 86 = 774 tiles = 3 rounds + SIX tiles), the fused kernel takes the whole tile rows and the
+  // remaining rows go through the plain GEMM + the SwiGLU kernel - the same bf16 gate|up rows, the same silu(gate) * up on them
+  if (t_split_ok && g_gemm_tail_split && ld_gu == 2 * ff && ld_act == ff) {
+    const int tm = cdiv(M, 256), tn = ff / 128;
+    const long T = (long)tm * tn, rounds = (T + 255) / 256, full = T / 256;
+    const int tm_main = (int)(full * 256 / tn);
+    if (full >= 1 && T % 256 != 0 && tm_main >= 1 && tm_main < tm) {
+      const long t_main = (long)tm_main * tn, t_tail = T - t_main;
+      if ((double)((t_main + 255) / 256) + 2.5 * (double)t_tail / 256.0 + 0.05 < (double)rounds) {
+        const int M_main = tm_main * 256, M_tail = M - M_main;
+        t_split_ok = false;
+        int rc = lhrs_gemm_swiglu_fwd(X, ldx, Wgu, ldw, A2, lda2, B2, ldb2, K2, gu, ld_gu, act, ld_act, M_main, ff, K, stream);
+        t_split_ok = true;
+        if (rc) return rc;
+        bf16_t* gu_t = (bf16_t*)gu + (long)M_main * ld_gu;
+        if (gemm_launch((const bf16_t*)X + (long)M_main * ldx, ldx, Wgu, ldw, gu_t, ld_gu, M_tail, 2 * ff, K, nullptr, nullptr, 0, 0, 0, 0, 1.f,
+                        A2 ? (const bf16_t*)A2 + (long)M_main * lda2 : nullptr, lda2, B2, ldb2, K2, stream))
+          return -1;
+        return lhrs_swiglu_fwd(gu_t, (bf16_t*)act + (long)M_main * ld_act, M_tail, ff, stream);
+      }
+    }
+  }
   GemmArgs g; memset(&g, 0, sizeof(g));
   g.A = (const bf16_t*)X; g.B = (const bf16_t*)Wgu; g.C = gu; g.M = M; g.N = 2 * ff; g.K = K; g.lda = ldx; g.ldb = ldw; g.ldc = ld_gu;
   g.alpha = 1.f; g.A2 = (const bf16_t*)A2; g.B2 = (const bf16_t*)B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;

@@ -437,9 +437,10 @@ def test_adan_and_clip_match_restatement():
     assert torch.equal(shadow, dp.to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("M,lora", [(8190, False), (8190, True), (4095, False), (300, True)])
+@pytest.mark.parametrize("M,lora", [(8190, False), (8190, True), (4095, False), (300, True), (2184, False), (2184, True)])
 def test_gemm_fused_swiglu_bit_identical_to_unfused(M, lora):
-    """lhrs_gemm_swiglu_fwd / _bwd == GEMM + swiglu kernels, bit for bit (fused 16-wave kernel at M >= 4095, fallback below)."""
+    """lhrs_gemm_swiglu_fwd / _bwd == GEMM + swiglu kernels, bit for bit (fused 16-wave kernel at M >= 4095, fallback below; M = 2184, the
+    reference's micro-batch 8: 774 tiles = 3 rounds + 6 - the tail-row rule sends rows 2048.. through the small-tile GEMM + SwiGLU kernel)."""
     g = torch.Generator().manual_seed(M + lora)
     d, ff, KP = 4096, 11008, 128
     x = torch.randn(M, d, generator=g).to(DEV, torch.bfloat16)
