@@ -1638,11 +1638,13 @@ extern "C" int lhrs_gemm_bf16_nt_skinny(const void* A, int lda, const void* B, i
   GemmArgs g; memset(&g, 0, sizeof(g));
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = workspace; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = N;
   g.alpha = 1.f; g.out_f32 = 1; g.ksplit = ks;
-  g.tilesM = cdiv(M, 64); g.tilesN = cdiv(N, 64);
+  const bool wide = N % 128 == 0;  // 64x128 tiles: the rows of A are read once per 128 columns, not per 64 (M = 8190: 5-11 % faster)
+  g.tilesM = cdiv(M, 64); g.tilesN = cdiv(N, wide ? 128 : 64);
   const int used = cdiv(K, ks);
   hipStream_t s = (hipStream_t)stream;
   if (g_prof.on) { g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * K; }
-  hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 0>), dim3(g.tilesM * g.tilesN, used), dim3(256), 0, s, g);
+  if (wide) hipLaunchKernelGGL((gemm_nt_kernel<2, 4, 0>), dim3(g.tilesM * g.tilesN, used), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 0>), dim3(g.tilesM * g.tilesN, used), dim3(256), 0, s, g);
   LHRS_CHECK_LAUNCH("gemm_skinny");
   const long work = (long)M * (N / 4);
   int rg = (int)((work + 255) / 256); if (rg > 8192) rg = 8192;

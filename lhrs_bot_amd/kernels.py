@@ -136,7 +136,7 @@ def gemm_nt_skinny(a, b, alpha=1.0):
     """out[M, N] bf16 = alpha * a[M, K] @ b[N, K]^T for a skinny N (64..384): split-K launch + reduction (LoRA down-projections)."""
     M, K = a.shape
     N = b.shape[0]
-    if N > 384 or N % 64 or M < 1024 or K < 1024:
+    if N > 256 or N % 64 or M < 1024 or K < 1024:  # N = 384 at K = 4096: 54.5 us here against 42.8 us on the plain path (M = 8190)
         return gemm_nt(a, b, alpha=alpha)
     out = torch.empty((M, N), device=a.device, dtype=torch.bfloat16)
     ws = torch.empty(_L().lhrs_gemm_skinny_splits(K, N) * M * N, device=a.device, dtype=torch.float32)
