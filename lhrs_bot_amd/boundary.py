@@ -69,21 +69,31 @@ _IGNORED_ZERO_KEYS = ("stage", "sub_group_size", "contiguous_gradients", "overla
 
 
 def initialize(args=None, model=None, optimizer=None, model_parameters=None, training_data=None, lr_scheduler=None, config=None,
-               config_params=None, comm_dtype=torch.bfloat16, **_unused):
+               config_params=None, comm_dtype=None, **_unused):
     """`model_engine, optimizer, _, _ = initialize(config=build_ds_config(cfg), model=model, optimizer=opt_or_None, model_parameters=None)`.
 
     config keys honoured: `optimizer.{type,params.{lr,eps,betas,weight_decay}}` (the AdamW branch of build_ds_config), or an
     `OptimizerSpec` from `build_optimizer` (the Adan branch); `gradient_accumulation_steps`; `gradient_clipping`;
-    `train_micro_batch_size_per_gpu` (recorded); `fp16.enabled` is refused (the engine computes in bf16 with fp32 accumulation - loss
-    scaling has nothing to scale), `bf16` is what always happens.  `zero_optimization.*`, `zero_force_ds_cpu_optimizer`,
-    `zero_allow_untested_optimizer` are accepted and ignored (logged once).  The gradient all-reduce runs in `comm_dtype` (bf16: what
-    DeepSpeed's bf16 ZeRO-2 moves)."""
+    `train_micro_batch_size_per_gpu` (recorded).  16-bit switches: the engine computes in bf16 with fp32 accumulation whatever they say.
+    `fp16.enabled` (the shipped stage-2/3 YAMLs: `fp16: True, bf16: False`, Config/multi_modal_stage2.yaml:75-80) is taken as "16-bit
+    compute" and answered with ONE warning naming the deviation - bf16 has fp32's exponent, so DeepSpeed's dynamic loss scaling
+    (`initial_scale_power`, `loss_scale_window`) has nothing to scale and is not run; the reference itself forces bf16 for its non-AdamW
+    branch (main_pretrain_stage1.py:66-71).  `engine.precision_request` records what was asked for.  `zero_optimization.*`, `zero_force_ds_cpu_optimizer`,
+    `zero_allow_untested_optimizer` are accepted and ignored (logged once).  The gradient all-reduce runs in fp32 (320 MB per step over xGMI for
+    the projector: cheap) unless DeepSpeed's `communication_data_type` key ("bf16" / "fp16" -> bf16 wire) or `comm_dtype=` asks otherwise."""
     from .engine import LHRSEngine
     cfg: Dict = dict(config if config is not None else (config_params or {}))
     if model is None:
         raise ValueError("initialize() needs model=<UniBind>")
-    if (cfg.get("fp16") or {}).get("enabled"):
-        raise ValueError("fp16 with dynamic loss scaling is not part of this engine: run the YAMLs' bf16 setting (fp16: False, bf16: True)")
+    fp16_req, bf16_req = bool((cfg.get("fp16") or {}).get("enabled")), bool((cfg.get("bf16") or {}).get("enabled"))
+    if fp16_req:
+        logger.warning("initialize: fp16.enabled=True is run as bf16 compute with fp32 accumulation and fp32 master weights (this engine has one "
+                       "16-bit path); DeepSpeed's dynamic loss scaling (initial_scale_power / loss_scale_window) is not needed at bf16 range and is skipped")
+    elif not bf16_req and ("fp16" in cfg or "bf16" in cfg):
+        logger.warning("initialize: fp16 and bf16 both disabled (fp32 training requested): the engine still computes in bf16 with fp32 accumulation")
+    if comm_dtype is None:
+        cdt = str(cfg.get("communication_data_type") or "fp32").lower()
+        comm_dtype = torch.bfloat16 if cdt in ("bf16", "bfloat16", "fp16", "float16", "half") else torch.float32
     zero = cfg.get("zero_optimization") or {}
     ignored = [f"zero_optimization.{k}" for k in zero if k in _IGNORED_ZERO_KEYS] + [k for k in ("zero_force_ds_cpu_optimizer", "zero_allow_untested_optimizer") if k in cfg]
     if ignored:
@@ -104,6 +114,7 @@ def initialize(args=None, model=None, optimizer=None, model_parameters=None, tra
     engine = LHRSEngine(model, optimizer=name, lr=lr, weight_decay=wd, max_grad_norm=float(cfg.get("gradient_clipping", 0.0) or 0.0), betas=betas,
                         eps=eps, gradient_accumulation_steps=int(cfg.get("gradient_accumulation_steps", 1) or 1), comm_dtype=comm_dtype)
     engine.train_micro_batch_size_per_gpu = cfg.get("train_micro_batch_size_per_gpu")
+    engine.precision_request = "fp16" if fp16_req else ("bf16" if bf16_req or not ("fp16" in cfg or "bf16" in cfg) else "fp32")
     return engine, engine.optimizer, None, None
 
 

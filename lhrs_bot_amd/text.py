@@ -616,8 +616,12 @@ class TextModal:
         skips it) gets OCP e4m3 copies with one fp32 scale per output row - of W for the forward product and of W^T for the dX product -
         and TRAINING runs both on the 2x-rate block-scaled MFMA with activations quantised per row on the fly.  LoRA adapters, norms,
         attention and the loss stay bf16 / fp32.  bitsandbytes is not importable here: the scheme is ours, parity vs LLM.int8 unpinned."""
+        if bits == 4:  # text_modal.py:91-107 `load_in_4bit` (nf4 storage, 16-bit compute): gfx950 has no 4-bit bf16-compute MFMA path worth
+            import logging  # a kernel family here; the 8-bit base is the closest resident format and is what runs
+            logging.getLogger("train").warning("bits=4 (bitsandbytes nf4) is run as the 8-bit e4m3 base: 4-bit storage is not built")
+            bits = 8
         if bits not in (8, 16):
-            raise NotImplementedError(f"bits={bits}: 16 (bf16) or 8 (e4m3 base weights)")
+            raise NotImplementedError(f"bits={bits}: 16 (bf16), 8 (e4m3 base weights) or 4 (run as 8)")
         if bits == 16:
             self.base8 = False
             return self

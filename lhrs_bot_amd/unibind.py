@@ -51,12 +51,37 @@ class UniBind:
                                   dim=_get(config, "text.hidden_size", 4096), eps=eps)
         self.training = True
         self._image_embedding = None
+        self._log_precision_keys(config)
+
+    def _log_precision_keys(self, config):
+        """The YAMLs' precision keys (Config/multi_modal_stage2.yaml:75-80: `dtype`, `bits`, `double_quant`, `quant_type`, `fp16`, `bf16`;
+        consumed at text_modal.py:79-131).  One INFO line saying what each means HERE, so that a shipped YAML runs unchanged and nothing is
+        dropped silently."""
+        import logging
+        if config is None:
+            return
+        log = logging.getLogger("train")
+        dt = _get(config, "dtype", None)
+        if dt is not None and str(dt) not in ("bfloat16", "bf16"):
+            log.info("config dtype=%s: frozen towers are stored and multiplied in bf16 (fp32 accumulation); the key selects no other path", dt)
+        if self.bits in (4, 8):
+            log.info("config bits=%d: frozen decoder linears kept as %s; double_quant=%s / quant_type=%s are bitsandbytes 4-bit options "
+                     "(text_modal.py:97-101) and do not apply to the 8-bit base", self.bits,
+                     "e4m3 rows + fp32 row scales (lhrs_gemm_fp8_nt)" if self.bits == 8 else "e4m3 rows (no 4-bit MFMA path: 8-bit is used)",
+                     _get(config, "double_quant", None), _get(config, "quant_type", None))
 
     # ------------------------------------------------------------------ reference surface
     def prepare_for_training(self, freeze_vision=True, freeze_text=True, tune_rgb_pooler=True, model_path=None,
                              tune_im_start=False, compute_dtype=torch.bfloat16):
         if not freeze_vision or tune_im_start:
             raise NotImplementedError("the ViT and the embedding tables stay frozen (every shipped stage: tune_rgb_bk / tune_im_start False)")
+        # UniBind.py:119-141 casts the towers to `compute_dtype`.  This engine has ONE arithmetic: bf16 storage / MFMA operands, fp32
+        # accumulation, fp32 masters for what trains.  fp16 (the stage-2/3 YAMLs) and fp32 requests are answered with a warning, not an error
+        self.compute_dtype_request = compute_dtype
+        if compute_dtype not in (torch.bfloat16, None):
+            import logging
+            logging.getLogger("train").warning("prepare_for_training(compute_dtype=%s): running the bf16 path (fp32 accumulation, fp32 master "
+                                               "weights); fp16 range handling / loss scaling is not needed and not run", compute_dtype)
         if not freeze_text and self.text.lora is None and _get(self.config, "lora.enable", False):
             # TextModal.__init__ LoRA branch (text_modal.py:133-151): LoraConfig(r, lora_alpha, lora_dropout) on every linear of the decoder
             self.enable_lora(r=int(_get(self.config, "lora.lora_r", 128)), alpha=float(_get(self.config, "lora.lora_alpha", 256)),
@@ -68,8 +93,8 @@ class UniBind:
         self.train()
         if model_path is not None:
             self.custom_load_state_dict(model_path)
-        if self.bits == 8 and not self.text.base8 and self.text.p.get("layers"):
-            self.text.quantize_base(8)  # the YAML's `bits: 8`: e4m3 copies of the (now loaded) frozen decoder linears
+        if self.bits in (4, 8) and not self.text.base8 and self.text.p.get("layers"):
+            self.text.quantize_base(self.bits)  # the YAML's `bits: 8`: e4m3 copies of the (now loaded) frozen decoder linears
 
     def train(self):
         self.training = True

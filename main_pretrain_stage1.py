@@ -35,19 +35,28 @@ from lhrs.optimizer import build_optimizer  # noqa: E402
 logger = logging.getLogger("train")
 
 
+_ZERO2 = {"adamw": dict(stage=2, sub_group_size=1e9, contiguous_gradients=True, overlap_comm=True, stage3_gather_16bit_weights_on_model_save=True),
+          "other": dict(stage=2, offload_optimizer={"device": "cpu"}, offload_param={"device": "cpu"})}
+
+
 def build_ds_config(config):
-    """The engine configuration in DeepSpeed's vocabulary (main_pretrain_stage1.py:28-85): AdamW is described inside the dict, any other
-    optimizer arrives as the object `build_optimizer` made; accumulation and clipping ride along.  The ZeRO / offload keys the
-    reference adds exist to fit 80 GB parts and are left out (`initialize` would ignore them)."""
+    """The engine configuration in DeepSpeed's vocabulary, key for key what main_pretrain_stage1.py:28-85 hands to `deepspeed.initialize`
+    (pinned by tests/golden/yaml_surface.json): AdamW is described inside the dict with the YAML's fp16 / bf16 switches passed through as
+    they are, any other optimizer arrives as the object `build_optimizer` made and forces bf16 autocast; accumulation and clipping ride
+    along.  The ZeRO / offload sections are emitted too - `initialize` names them in its "ignored" log line instead of this function
+    deciding what the engine gets to see."""
+    adamw = str(config.optimizer).lower() == "adamw"
     ds = {"train_micro_batch_size_per_gpu": config.batch_size,
-          "bf16": {"enabled": True, "auto_cast": str(config.optimizer).lower() != "adamw"},
           "gradient_accumulation_steps": config.get("accumulation_steps", 1),
-          "gradient_clipping": config.max_grad_norm}
-    if str(config.optimizer).lower() == "adamw":
-        ds["optimizer"] = {"type": "AdamW", "params": {"lr": config.lr, "eps": 1e-8, "betas": tuple(config.get("betas") or (0.9, 0.95)),
-                                                        "weight_decay": config.wd}}
+          "gradient_clipping": config.max_grad_norm,
+          "zero_optimization": dict(_ZERO2["adamw" if adamw else "other"])}
+    if adamw:
+        ds["optimizer"] = {"type": "AdamW", "params": {"lr": config.lr, "eps": 1e-8, "betas": (0.9, 0.95), "weight_decay": config.wd}}
         ds["fp16"] = {"enabled": bool(config.get("fp16", False)), "auto_cast": False, "initial_scale_power": 16, "loss_scale_window": 500}
-        ds["bf16"] = {"enabled": bool(config.get("bf16", True)), "auto_cast": False}
+        ds["bf16"] = {"enabled": bool(config.get("bf16", False)), "auto_cast": False}
+    else:
+        ds["bf16"] = {"enabled": True, "auto_cast": True}
+        ds.update(zero_force_ds_cpu_optimizer=False, zero_allow_untested_optimizer=True)
     return ds
 
 
@@ -70,6 +79,9 @@ def parse_option(args=None):
     p.add_argument("--inf_sampler", type=str2bool, default=False, help="infinite sampler (iteration-based training)")
     p.add_argument("--torch-compile", type=str2bool, default=False, help="accepted and ignored: the engine is hand-written HIP")
     p.add_argument("--wandb", type=str2bool, default=False, help="wandb logger (not available offline: must stay False)")
+    for flag, default in (("--entity", "pumpkinn"), ("--project", "MultiModal"), ("--job-type", "vlm_test"), ("--name", "first_run"), ("--notes", None)):
+        p.add_argument(flag, type=str, default=default, help="wandb run metadata (accepted for flag compatibility; wandb is not available offline)")
+    p.add_argument("--tags", type=str, default="MultiModal", nargs="+", help="wandb tags (accepted, unused)")
     p.add_argument("--accelerator", default="gpu", type=str, choices=["cpu", "gpu", "mps"], help="accelerator")
     p.add_argument("--local_rank", type=int)
     # knobs of this engine's offline runs

@@ -124,10 +124,83 @@ def test_engine_object_has_the_deepspeed_surface_the_trainer_and_hooks_use():
 
 def test_initialize_rejects_what_it_cannot_honour():
     from lhrs.CustomTrainer import initialize
-    with pytest.raises(ValueError, match="fp16"):
-        initialize(config={"fp16": {"enabled": True}}, model=object(), optimizer=None)
     with pytest.raises(ValueError, match="no optimizer"):
         initialize(config={"bf16": {"enabled": True}}, model=object(), optimizer=None)
     with pytest.raises(TypeError, match="OptimizerSpec"):
         import torch
         initialize(config={}, model=object(), optimizer=torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=0.1))
+
+
+# ------------------------------------------------------------------------------------------------ the shipped YAMLs, unchanged
+def _yaml_surface():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "yaml_surface.json")))
+
+
+def _tuples_to_lists(o):
+    if isinstance(o, dict):
+        return {k: _tuples_to_lists(v) for k, v in o.items()}
+    return [_tuples_to_lists(v) for v in o] if isinstance(o, (list, tuple)) else o
+
+
+@pytest.mark.parametrize("name", ["stage1", "stage2", "stage3"])
+def test_shipped_yaml_through_parse_build_ds_config_initialize(name, tmp_path, monkeypatch, caplog):
+    """Config/multi_modal_stage{1,2,3}.yaml as the reference ships them (tests/golden/yaml_surface.json holds their parsed trees and what the
+    reference's own build_ds_config returns for them): parse_option -> build_ds_config gives the SAME dict, and `initialize` takes it -
+    `fp16: True, bf16: False, optimizer: adamw` of stages 2/3 included - with a warning naming the bf16 deviation, never an error
+    (main_pretrain_stage2.py:28-85, Config/multi_modal_stage2.yaml:75-89)."""
+    import logging
+    import yaml
+    import main_pretrain_stage1 as drv
+    import lhrs_bot_amd.engine as eng
+    from lhrs.CustomTrainer import initialize
+    from lhrs.optimizer import build_optimizer
+    z = _yaml_surface()
+    path = tmp_path / f"multi_modal_{name}.yaml"
+    path.write_text(yaml.safe_dump(z["yaml"][name]))
+    launch = z["launch"][name]
+    config = drv.parse_option(["-c", str(path), "--batch-size", str(launch["batch_size"]), "--accumulation-steps", str(launch["accumulation_steps"]),
+                               "--output", str(tmp_path / "out"), "--accelerator", "gpu", "--enable-amp", "True", "--use-checkpoint"])
+    for k, v in z["yaml"][name].items():                      # every YAML key reaches the config, unmodified
+        assert _tuples_to_lists(config[k]) == v, k
+    ds = drv.build_ds_config(config)
+    assert _tuples_to_lists(ds) == z["ds_config"][name]
+
+    seen = {}
+
+    class FakeEngine:                                          # no GPU here: record what `initialize` derives from the dict
+        def __init__(self, model, **kw):
+            seen.update(kw)
+            self.optimizer = object()
+
+    class FakeModel:
+        def named_parameters(self):
+            import torch
+            return [("rgb_pooler.out_proj.weight", torch.zeros(2, 2)), ("rgb_pooler.out_proj.bias", torch.zeros(2))]
+
+    monkeypatch.setattr(eng, "LHRSEngine", FakeEngine)
+    model = FakeModel()
+    opt = None if str(config.optimizer).lower() == "adamw" else build_optimizer(model, config, is_pretrain=True)
+    logging.getLogger("train").propagate = True
+    with caplog.at_level(logging.INFO, logger="train"):
+        engine, optimizer, _, _ = initialize(config=ds, model=model, optimizer=opt, model_parameters=None)
+    y = z["yaml"][name]
+    assert seen["optimizer"] == {"adanp": "adanp", "adamw": "adamw"}[y["optimizer"]]
+    assert seen["lr"] == y["lr"] and seen["weight_decay"] == y["wd"] and seen["max_grad_norm"] == y["max_grad_norm"]
+    assert seen["gradient_accumulation_steps"] == 1 and seen["comm_dtype"] is __import__("torch").float32
+    if y["optimizer"] == "adamw":
+        assert tuple(seen["betas"]) == (0.9, 0.95)
+        assert engine.precision_request == "fp16" and any("fp16.enabled=True is run as bf16" in r.message for r in caplog.records)
+    else:
+        assert engine.precision_request == "bf16"
+    assert any("ignoring zero_optimization.stage" in r.getMessage() for r in caplog.records)
+
+
+def test_eval_yaml_keys_reach_the_model_config():
+    """Config/multi_modal_eval.yaml: the keys cli_qa.py / the evaluation scripts hand to build_model are the ones UniBind reads."""
+    from lhrs_bot_amd.unibind import _get
+    y = _yaml_surface()["yaml"]["eval"]
+    assert _get(y, "rgb_vision.attn_pooler.num_query", None) == 144 and _get(y, "rgb_vision.attn_pooler.num_layers", None) == 6
+    assert float(_get(y, "text.rms_norm_eps", 0)) == 1e-5 and _get(y, "text.hidden_size", None) == 4096
+    assert {"dtype", "bits", "double_quant", "quant_type", "fp16", "bf16", "lora", "stage"} <= set(y)

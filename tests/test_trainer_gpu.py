@@ -117,3 +117,35 @@ def test_stage2_and_stage3_drivers_from_yaml_keys(tmp_path):
     assert m3.text.lora is not None and m3.text.lora.r == 8 and m3.text.base8        # adapters came from TextLoRA/, base re-quantised
     assert {s.name for s in t3.model.stores} == {"lora"} and t3.model.global_steps == 4
     assert len(t3.history) == 4 and all(torch.isfinite(torch.tensor(h["loss"])) for h in t3.history)
+
+
+def test_stage2_and_stage3_drivers_from_the_shipped_yaml_trees(tmp_path):
+    """Boundary (b), config surface: Config/multi_modal_stage{2,3}.yaml AS SHIPPED (`fp16: True, bf16: False, optimizer: adamw, bits: 8,
+    dtype: float16, double_quant, quant_type, lora r=128`; trees from tests/golden/yaml_surface.json) through the reference's call sequence
+    parse_option -> build_model -> prepare_for_training -> build_ds_config -> initialize -> trainer (main_pretrain_stage2.py:28-85,178-258).
+    Only launcher flags are added (1 decoder layer, 3 / 4 iterations, synthetic batches)."""
+    import json
+    import yaml
+    import main_pretrain_stage1 as drv
+    z = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "yaml_surface.json")))
+
+    def run(name, stage, out, *extra):
+        path = tmp_path / f"multi_modal_{name}.yaml"
+        path.write_text(yaml.safe_dump(z["yaml"][name]))
+        config = drv.parse_option(["-c", str(path), "--batch-size", "2", "--output", str(out), "--accelerator", "gpu", "--enable-amp", "True",
+                                   "--use-checkpoint", "--llama-layers", "1", "--epoch-len", "3", "--data-path", "synthetic", *extra])
+        assert config.fp16 is True and config.bf16 is False and config.optimizer == "adamw" and config.bits == 8 and config.stage == stage
+        config.rank, config.local_rank, config.world_size, config.is_distribute = 0, 0, 1, False
+        os.makedirs(os.path.join(config.output, "checkpoints"), exist_ok=True)
+        return drv.main(config)
+
+    t2 = run("stage2", 2, tmp_path / "s2")
+    m2 = t2.model.module
+    assert m2.text.lora is not None and m2.text.lora.r == 128 and m2.text.lora.dropout == 0.05 and m2.text.base8
+    assert t2.model.opt_name == "adamw" and t2.model.precision_request == "fp16" and t2.model.max_grad_norm == 1.0
+    assert {s.name for s in t2.model.stores} == {"rgb_pooler", "lora"} and t2.model.global_steps == 3
+    assert all(torch.isfinite(torch.tensor(h["loss"])) for h in t2.history)
+    t3 = run("stage3", 3, tmp_path / "s3", "--model-path", str(tmp_path / "s2" / "checkpoints" / "FINAL.pt"), "--opts", "epochs", "4")
+    m3 = t3.model.module
+    assert m3.text.lora is not None and m3.text.lora.r == 128 and m3.text.base8          # adapters from TextLoRA/, `lora.enable: False` in the YAML
+    assert {s.name for s in t3.model.stores} == {"lora"} and t3.model.global_steps == 4 and len(t3.history) == 4
