@@ -173,7 +173,8 @@ _GROUP_OF = {"q": "qkv", "k": "qkv", "v": "qkv", "o": "o", "gate": "gu", "up": "
 
 
 def _lora(L, proj, x):
-    """peft lora.Linear delta (peft 0.7.1, absent here - PARITY UNPINNED): s * (dropout(x) A^T) B^T with s = lora_alpha / r; call site
+    """peft lora.Linear delta (peft 0.7.1 is absent here; pinned through the merged-weight identity against the reference LLaMA:
+    tests/golden/make_golden_lora.py, test_lora_restatement_pinned_to_the_reference_llama_with_merged_weights): s * (dropout(x) A^T) B^T with s = lora_alpha / r; call site
     lhrs/models/text_modal.py:133-151.  L["lora"] = {"scale": s, proj: (A [r,in], B [out,r])}; optional L["lora"]["drop"] =
     {group: mask of x's shape holding 0 or 1/(1-p)} reproduces a given dropout draw (the engine's counter-based masks, one per fused
     group - peft itself draws one per wrapped nn.Linear)."""

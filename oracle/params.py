@@ -14,8 +14,12 @@ from typing import Dict
 import torch
 
 
+def _seed_of(name: str, seed: int) -> int:
+    return (zlib.crc32(name.encode()) + seed * 1000003) % (2 ** 31)
+
+
 def _rand(name: str, shape, seed: int, std: float = 0.02, mean: float = 0.0) -> torch.Tensor:
-    g = torch.Generator().manual_seed((zlib.crc32(name.encode()) + seed * 1000003) % (2 ** 31))
+    g = torch.Generator().manual_seed(_seed_of(name, seed))
     return torch.randn(*shape, generator=g) * std + mean
 
 
@@ -127,3 +131,47 @@ def llama_to_hf(p: Dict) -> Dict[str, torch.Tensor]:
         sd[b + "mlp.gate_proj.weight"] = L["gu_w"][:ff]; sd[b + "mlp.up_proj.weight"] = L["gu_w"][ff:]
         sd[b + "mlp.down_proj.weight"] = L["down_w"]
     return sd
+
+
+# ------------------------------------------------------------------------------------------------- LoRA adapters (stages 2/3)
+LORA_DIMS = {"q": (4096, 4096), "k": (4096, 4096), "v": (4096, 4096), "o": (4096, 4096),        # proj -> (in_features, out_features)
+             "gate": (4096, 11008), "up": (4096, 11008), "down": (11008, 4096)}
+
+
+def make_lora_params(seed: int, layers: int, r: int, alpha: float, targets) -> list:
+    """Per layer {"scale": alpha / r, proj: (A [r, in], B [out, r])}: A as peft initialises it (kaiming-uniform(a=sqrt 5) = U(-1/sqrt(in),
+    1/sqrt(in)); text_modal.py:133-151), B NON-zero (N(0, 0.02); peft starts it at 0, which would leave dA = 0 untested)."""
+    out = []
+    for l in range(layers):
+        d = {"scale": float(alpha) / float(r)}
+        for pr in targets:
+            fin, fout = LORA_DIMS[pr]
+            g = torch.Generator().manual_seed(_seed_of(f"lora.{l}.{pr}", seed))
+            A = (torch.rand(r, fin, generator=g) * 2 - 1) / fin ** 0.5
+            B = torch.randn(fout, r, generator=g) * 0.02
+            d[pr] = (A, B)
+        out.append(d)
+    return out
+
+
+def merged_lora_weights(p: Dict, lora: list) -> Dict:
+    """The decoder after peft `merge_and_unload()` (UniBind.custom_load_state_dict, UniBind.py:105-115): W' = W + s * B @ A on every
+    adapted projection; a copy of `p` with merged stacked weights (q|k|v and gate|up stay stacked)."""
+    q = dict(p)
+    q["layers"] = []
+    for L, lo in zip(p["layers"], lora):
+        M = dict(L)
+        dim, ff = L["o_w"].shape[0], L["gu_w"].shape[0] // 2
+        delta = lambda pr: lo["scale"] * (lo[pr][1] @ lo[pr][0]) if pr in lo else None  # noqa: E731
+        qkv = L["qkv_w"].clone()
+        for i, pr in enumerate(("q", "k", "v")):
+            if pr in lo:
+                qkv[i * dim:(i + 1) * dim] += delta(pr)
+        gu = L["gu_w"].clone()
+        for i, pr in enumerate(("gate", "up")):
+            if pr in lo:
+                gu[i * ff:(i + 1) * ff] += delta(pr)
+        M.update(qkv_w=qkv, gu_w=gu, o_w=L["o_w"] + delta("o") if "o" in lo else L["o_w"],
+                 down_w=L["down_w"] + delta("down") if "down" in lo else L["down_w"])
+        q["layers"].append(M)
+    return q

@@ -1,5 +1,7 @@
 """Stage-2/3 path: LoRA adapters fused into the LLaMA GEMMs (forward, dX, dA, dB) + AdamW, against oracle autograd.
 peft / deepspeed are not importable anywhere (parity unpinned w.r.t. them); the oracle restates lora.Linear."""
+import os
+
 import pytest
 import torch
 
@@ -157,3 +159,48 @@ def test_generate_with_unmerged_adapters_uses_them_and_leaves_the_base_untouched
     assert model.text.lora is None
     ids2, logits2 = model.generate(ids, images=rgb, do_sample=False, max_new_tokens=4, return_logits=True, eos_token_id=None)
     assert torch.equal(ids2, new_ids) and torch.equal(logits2, logits)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name", ["lora_r8_qkvo.npz", "lora_r128_all.npz"])
+def test_lora_kernels_pinned_to_the_reference_llama_with_merged_weights(name):
+    """SURVEY §8 a7 against the REFERENCE: tests/golden/make_golden_lora.py ran the reference's own UniBind / CustomLlamaForCausalLM with
+    W' = W + s B A loaded (what peft's merge_and_unload leaves, UniBind.py:105-115) and stored loss, hidden states, d loss / d image and
+    dA = s B^T dW', dB = s dW' A^T from its dW'.  The engine runs the UN-merged adapters through lhrs_gemm_bf16_nt_lora (forward, dX) and
+    tn_skinny (dA, dB): r = 8 on q,k,v,o (BASELINE configs[3]) and r = 128 on every decoder linear (the stage-2 YAML).  bf16 tolerances."""
+    import numpy as np
+    from test_oracle_cpu import lora_case
+    z, P, lora_p, batch, targets = lora_case(name)
+    nl, r = int(z["n_llama_layers"]), int(z["r"])
+    model = UniBind(("rgb", "text"), None, device=DEV, llama_layers=nl).load_params(P)
+    lora = model.enable_lora(r=r, alpha=float(z["alpha"]), targets=targets, seed=0)
+    for l in range(nl):
+        for pr in targets:
+            lora.set_adapter(l, pr, *lora_p[l][pr])
+    hk_cast = __import__("lhrs_bot_amd.kernels", fromlist=["x"]).cast_f32_to_bf16
+    hk_cast(lora.master, lora.shadow)
+    lora.refresh()
+    model.prepare_for_training(freeze_vision=True, freeze_text=False, tune_rgb_pooler=True)
+    out = model(batch)
+    want = float(z["loss"])
+    assert abs(out["total_loss"].item() - want) < 2e-3 * want
+    hid = model.text.last_hidden.reshape(2, -1, 4096)[:, ::4].float().cpu()
+    S = model.text.last_hidden.shape[0] // 2
+    vis = torch.cat([torch.ones(2, S - batch["attention_mask"].shape[1], dtype=torch.bool), batch["attention_mask"]], dim=1)[:, ::4]
+    assert rel(hid[vis], torch.from_numpy(z["hidden_sample"]).float()[vis]) < 2e-2
+    d_image = model.text.backward()
+    assert rel(d_image[:, ::4], torch.from_numpy(z["d_image"])) < 5e-2
+    model.rgb_pooler.backward(d_image)
+    torch.cuda.synchronize()
+    names = np.load(os.path.join(os.path.dirname(__file__), "golden", "unibind_e2e.npz"))["grad_names"].tolist()   # AttnPooler.named_parameters() order
+    bad = [(n, model.rgb_pooler.g[n].double().norm().item(), w) for n, w in zip(names, z["pooler_grad_norms"].tolist())
+           if abs(model.rgb_pooler.g[n].double().norm().item() - w) > 6e-2 * w]
+    assert not bad, bad
+    full = r <= 16
+    for l in range(nl):
+        for pr in targets:
+            dA, dB = lora.grad_adapter(l, pr)
+            assert abs(dA.norm().item() - float(z[f"dA_norm.{l}.{pr}"])) < 5e-2 * float(z[f"dA_norm.{l}.{pr}"]), (l, pr)
+            assert abs(dB.norm().item() - float(z[f"dB_norm.{l}.{pr}"])) < 5e-2 * float(z[f"dB_norm.{l}.{pr}"]), (l, pr)
+            assert rel(dA if full else dA[::16, ::16], torch.from_numpy(z[f"dA.{l}.{pr}"])) < 6e-2, (l, pr, "dA")
+            assert rel(dB if full else dB[::16, ::16], torch.from_numpy(z[f"dB.{l}.{pr}"])) < 6e-2, (l, pr, "dB")

@@ -233,3 +233,49 @@ def test_llama_oracle_with_int8_base_stays_close_to_fp32():
         h32 = O.llama_hidden(P, x, None)
         h8 = O.llama_hidden(I8.int8_llama_params(P), x, None)
     assert 1e-3 < rel(h8, h32) < 8e-2   # measured 4.3e-2 on N(0,1) activations: what vector-wise int8 costs two decoder layers
+
+
+# ------------------------------------------------------------------------------------------------- LoRA pinned to the reference LLaMA
+def lora_case(name):
+    """Fixture + the seeded parameters / adapters / batch it was made from (tests/golden/make_golden_lora.py).  Shared with test_lora_gpu.py."""
+    z = np.load(os.path.join(G, name))
+    nl, r, alpha, targets = int(z["n_llama_layers"]), int(z["r"]), float(z["alpha"]), tuple(str(t) for t in z["targets"])
+    P = {"vit": OP.make_vit_params(seed=2), "pooler": OP.make_pooler_params(seed=1), "llama": OP.make_llama_params(seed=3, layers=nl)}
+    lora = OP.make_lora_params(seed=int(z["adapter_seed"]), layers=nl, r=r, alpha=alpha, targets=targets)
+    g = torch.Generator().manual_seed(int(z["batch_seed"]))
+    B, T = 2, 20
+    ids = torch.randint(3, 32000, (B, T), generator=g)
+    ids[:, 0] = 1
+    ids[:, 1] = -200
+    ids[1, T - 4:] = 0
+    labels = ids.clone()
+    labels[:, :2] = -100
+    labels[ids == 0] = -100
+    batch = dict(rgb=torch.randn(B, 3, 224, 224, generator=g), input_ids=ids, labels=labels, attention_mask=ids.ne(0))
+    return z, P, lora, batch, targets
+
+
+@pytest.mark.parametrize("name", ["lora_r8_qkvo.npz", "lora_r128_all.npz"])
+def test_lora_restatement_pinned_to_the_reference_llama_with_merged_weights(name):
+    """oracle._lora (y = W x + s B A x, UN-merged) against the reference's own LLaMA carrying W' = W + s B A: same loss, hidden states and
+    d loss / d image; the oracle's autograd dA, dB against s B^T dW' and s dW' A^T formed from the reference's dW' (SURVEY §8 a7)."""
+    z, P, lora, batch, targets = lora_case(name)
+    for L, lo in zip(P["llama"]["layers"], lora):
+        L["lora"] = {"scale": lo["scale"], **{pr: (lo[pr][0].clone().requires_grad_(True), lo[pr][1].clone().requires_grad_(True)) for pr in targets}}
+    P["pooler"]["out_proj_b"].requires_grad_(True)            # makes the image embedding part of the graph (d loss / d image)
+    col = {}
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    loss = O.unibind_forward(P, batch, collect=col)
+    col["image"].retain_grad()
+    loss.backward()
+    assert abs(loss.item() - float(z["loss"])) < 2e-5 * float(z["loss"])
+    assert rel(col["hidden"][:, ::4], z["hidden_sample"].astype(np.float32)) < 2e-3      # fixture stored in fp16
+    assert rel(col["image"].grad[:, ::4], z["d_image"]) < 2e-4
+    full = int(z["r"]) <= 16
+    for l, L in enumerate(P["llama"]["layers"]):
+        for pr in targets:
+            A, B = L["lora"][pr]
+            assert abs(A.grad.norm().item() - float(z[f"dA_norm.{l}.{pr}"])) < 2e-4 * float(z[f"dA_norm.{l}.{pr}"]), (l, pr)
+            assert abs(B.grad.norm().item() - float(z[f"dB_norm.{l}.{pr}"])) < 2e-4 * float(z[f"dB_norm.{l}.{pr}"]), (l, pr)
+            assert rel(A.grad if full else A.grad[::16, ::16], z[f"dA.{l}.{pr}"]) < 5e-4, (l, pr)
+            assert rel(B.grad if full else B.grad[::16, ::16], z[f"dB.{l}.{pr}"]) < 5e-4, (l, pr)
