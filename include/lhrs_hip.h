@@ -115,6 +115,11 @@ int lhrs_gemm_set_tail_split(int on);
  * first operands are fetched under the current tile's epilogue); 0 = one workgroup per tile */
 int lhrs_gemm_set_persistent(int on);
 
+/* tile height of the persistent GEMM kernels: 0 = always 256 rows (gemm_nt_256s_kernel), 1 (default) = 144 rows (gemm_nt_144s_kernel, 12 waves)
+ * whenever ceil(tiles / CUs) rounds of the smaller tile finish first - M = 2184, the reference's micro-batch 8 (Script/train_stage1.sh:11),
+ * is 16 x 16 = 256 tiles of 144 x 256 instead of 144 tiles of 256 x 256 -, 2 = 144 rows wherever the kernel applies (A/B tests).  Results
+ * are bit-identical between the two tile heights. */
+int lhrs_gemm_set_bm144(int mode);
 /* kernel A/B tests only: fewest 256x256 tiles for which lhrs_gemm_bf16_nt picks the big-tile kernel (default 128) */
 int lhrs_gemm_set_min_tiles(int n);
 /* live HIP-event timing of the 16-wave 256x256 GEMM launches, on their launch stream, for bench.py's roofline leg (gemm.hip):

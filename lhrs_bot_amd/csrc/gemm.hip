@@ -802,6 +802,8 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
 
 
 
+#include "gemm_144s_kernel.inc"
+
 // ------------------------------------------------------------------------------------------------
 // e4m3 x e4m3 -> bf16 GEMM for FROZEN base weights in 8-bit (the reference trains stages 2/3 with `bits: 8` base weights,
 // lhrs/models/text_modal.py:91-131 -> bitsandbytes LLM.int8): C[m][n] = sa[m] * sb[n] * sum_k A8[m][k] * B8[n][k]
@@ -1130,6 +1132,7 @@ extern "C" int lhrs_gemm_set_persistent(int on) { g_gemm_persist = on; return 0;
     if ((g_).K2 > 0) hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT_, EPI_, true>), grid_, dim3(1024), 0, s_, g_);        \
     else hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT_, EPI_, false>), grid_, dim3(1024), 0, s_, g_);                   \
   } while (0)
+#define LAUNCH_144(ACT_, EPI_, grid_, s_, g_) hipLaunchKernelGGL((gemm_nt_144s_kernel<ACT_, EPI_>), grid_, dim3(768), 0, s_, g_)
 static int num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -1141,6 +1144,18 @@ static int num_cus() {
   return n;
 }
 static dim3 grid_256s(long tiles) { return dim3((unsigned)(g_gemm_persist ? (tiles < num_cus() ? tiles : num_cus()) : tiles)); }
+// Tile height of the persistent kernels: 256 rows (16 waves) or 144 rows (12 waves, gemm_144s_kernel.inc).  Both walk ceil(tiles / CUs) rounds; a
+// 144-row tile is 0.5625 of the MFMA work of a 256-row tile and runs that work ~8 % less efficiently (more DMA per MFMA) - take whichever
+// finishes first.  M = 2184 (micro-batch 8): 144 tiles -> 256 (N = 4096), 432 -> 768, 774 -> 1376, 387 -> 688.  0 = never, 1 = cost model, 2 = whenever legal
+static int g_gemm_bm144 = 1;
+static double g_gemm_bm144_cost = 0.5625 * 1.08;
+extern "C" int lhrs_gemm_set_bm144(int mode) { g_gemm_bm144 = mode; return 0; }
+static bool pick_144(int M, long tiles_n, int K2, bool drop) {
+  if (g_gemm_bm144 == 0 || K2 > 0 || drop) return false;   // the second operand pair (fused LoRA) and the dropout mask live in the 256-row kernel only
+  if (g_gemm_bm144 == 2) return true;
+  const long P = num_cus(), t256 = (long)cdiv(M, 256) * tiles_n, t144 = (long)cdiv(M, 144) * tiles_n;
+  return (double)((t144 + P - 1) / P) * g_gemm_bm144_cost < (double)((t256 + P - 1) / P);
+}
 static int g_gemm_min256 = 128;  // fewest 256x256 tiles (half a round of the 256 CUs) for which the big-tile kernels are chosen: 2184 x 4096 (144
                                  // tiles, the reference's micro-batch 8) runs 20 % faster there than on 576 small tiles; A/B: lhrs_gemm_set_min_tiles
 extern "C" int lhrs_gemm_set_min_tiles(int n) { g_gemm_min256 = n; return 0; }
@@ -1236,8 +1251,9 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   // much as a full one (M = 8736, N = 4096: 560 tiles = 2.19 rounds -> 3).  When the tile rows that spill over the last full round
   // are cheaper as a separate small-tile launch (~2.5x the time per FLOP, but no idle CUs), the row range is cut there: whole
   // 256-row tile rows for the 16-wave kernel, the remaining rows for the 64x128 / 128x128 kernel.  Disjoint rows of C, no partials.
-  if (use256 && t_split_ok && g_gemm_tail_split && g_gemm_allow_256 == 2 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128 &&
-      !g.drop_thresh) {
+  const bool s_kernel = use256 && g_gemm_allow_256 == 2 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128;
+  const bool bm144 = s_kernel && !out_f32 && pick_144(M, cdiv(N, 256), K2, g.drop_thresh != 0);
+  if (s_kernel && !bm144 && t_split_ok && g_gemm_tail_split && !g.drop_thresh) {
     const int tm = cdiv(M, 256), tn = cdiv(N, 256);
     const long T = (long)tm * tn, rounds = (T + 255) / 256, full = T / 256;
     const int tm_main = (int)(full * 256 / tn);
@@ -1273,7 +1289,16 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   if (use256) {
     g.tilesM = cdiv(M, 256); g.tilesN = cdiv(N, 256);
     const dim3 grid(g.tilesM * g.tilesN), blk(512);
-    if (g_gemm_allow_256 == 2 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128) {
+    if (bm144) {
+      g.tilesM = cdiv(M, 144);
+      const dim3 grid12 = grid_256s((long)g.tilesM * g.tilesN);
+      switch (act) {
+        case 0: LAUNCH_144(0, 0, grid12, s, g); break;
+        case 1: LAUNCH_144(1, 0, grid12, s, g); break;
+        case 2: LAUNCH_144(2, 0, grid12, s, g); break;
+        default: LAUNCH_144(3, 0, grid12, s, g); break;
+      }
+    } else if (s_kernel) {
       const dim3 grid16 = grid_256s((long)g.tilesM * g.tilesN);
       switch (act) {
         case 0: LAUNCH_256(0, 0, grid16, s, g); break;
@@ -1346,7 +1371,8 @@ extern "C" int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int
   // Tail rows, as in gemm_launch: when the tile rows that spill over the last full round of the 256 CUs are cheaper as a small-tile launch
   // (M = 2184, the reference's micro-batch 8: 9 x 86 = 774 tiles = 3 rounds + SIX tiles), the fused kernel takes the whole tile rows and the
   // remaining rows go through the plain GEMM + the SwiGLU kernel - the same bf16 gate|up rows, the same silu(gate) * up on them
-  if (t_split_ok && g_gemm_tail_split && ld_gu == 2 * ff && ld_act == ff) {
+  const bool bm144 = pick_144(M, ff / 128, K2, false);
+  if (!bm144 && t_split_ok && g_gemm_tail_split && ld_gu == 2 * ff && ld_act == ff) {
     const int tm = cdiv(M, 256), tn = ff / 128;
     const long T = (long)tm * tn, rounds = (T + 255) / 256, full = T / 256;
     const int tm_main = (int)(full * 256 / tn);
@@ -1370,10 +1396,11 @@ extern "C" int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int
   g.A = (const bf16_t*)X; g.B = (const bf16_t*)Wgu; g.C = gu; g.M = M; g.N = 2 * ff; g.K = K; g.lda = ldx; g.ldb = ldw; g.ldc = ld_gu;
   g.alpha = 1.f; g.A2 = (const bf16_t*)A2; g.B2 = (const bf16_t*)B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
   g.epi = 1; g.ff = ff; g.aux_out = (bf16_t*)act; g.ld_aux = ld_act;
-  g.tilesM = cdiv(M, 256); g.tilesN = ff / 128;
+  g.tilesM = cdiv(M, bm144 ? 144 : 256); g.tilesN = ff / 128;
   hipStream_t s = (hipStream_t)stream;
   const int pslot = prof_count(M, 2 * ff, K + K2, 1, s);
-  LAUNCH_256(0, 1, grid_256s((long)g.tilesM * g.tilesN), s, g);
+  if (bm144) LAUNCH_144(0, 1, grid_256s((long)g.tilesM * g.tilesN), s, g);
+  else LAUNCH_256(0, 1, grid_256s((long)g.tilesM * g.tilesN), s, g);
   prof_end(pslot, s);
   LHRS_CHECK_LAUNCH("gemm_swiglu_fwd");
   return 0;
@@ -1401,9 +1428,11 @@ extern "C" int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw
   g.A = (const bf16_t*)X; g.B = (const bf16_t*)W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = ldw; g.ldc = ldc;
   g.alpha = 1.f; g.A2 = (const bf16_t*)A2; g.B2 = (const bf16_t*)B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
   g.epi = 3; g.rope_cos = cos_t; g.rope_sin = sin_t; g.rope_mod = pos_mod; g.rope_pos0 = pos0; g.rope_cols = rope_cols;
-  g.tilesM = cdiv(M, 256); g.tilesN = cdiv(N, 256);
+  const bool bm144 = pick_144(M, cdiv(N, 256), K2, false);
+  g.tilesM = cdiv(M, bm144 ? 144 : 256); g.tilesN = cdiv(N, 256);
   const int pslot = prof_count(M, N, K + K2, 3, (hipStream_t)stream);
-  LAUNCH_256(0, 3, grid_256s((long)g.tilesM * g.tilesN), (hipStream_t)stream, g);
+  if (bm144) LAUNCH_144(0, 3, grid_256s((long)g.tilesM * g.tilesN), (hipStream_t)stream, g);
+  else LAUNCH_256(0, 3, grid_256s((long)g.tilesM * g.tilesN), (hipStream_t)stream, g);
   prof_end(pslot, (hipStream_t)stream);
   LHRS_CHECK_LAUNCH("gemm_rope_fwd");
   return 0;
@@ -1421,10 +1450,12 @@ extern "C" int lhrs_gemm_swiglu_bwd(const void* dY, int ldy, const void* WdT, in
   g.A = (const bf16_t*)dY; g.B = (const bf16_t*)WdT; g.C = dgu; g.M = M; g.N = ff; g.K = K; g.lda = ldy; g.ldb = ldw; g.ldc = ld_gu;
   g.alpha = 1.f; g.A2 = (const bf16_t*)A2; g.B2 = (const bf16_t*)B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
   g.epi = 2; g.ff = ff; g.aux = (const bf16_t*)gu; g.ld_aux = ld_gu;
-  g.tilesM = cdiv(M, 256); g.tilesN = cdiv(ff, 256);
+  const bool bm144 = pick_144(M, cdiv(ff, 256), K2, false);
+  g.tilesM = cdiv(M, bm144 ? 144 : 256); g.tilesN = cdiv(ff, 256);
   hipStream_t s = (hipStream_t)stream;
   const int pslot = prof_count(M, ff, K + K2, 2, s);
-  LAUNCH_256(0, 2, grid_256s((long)g.tilesM * g.tilesN), s, g);
+  if (bm144) LAUNCH_144(0, 2, grid_256s((long)g.tilesM * g.tilesN), s, g);
+  else LAUNCH_256(0, 2, grid_256s((long)g.tilesM * g.tilesN), s, g);
   prof_end(pslot, s);
   LHRS_CHECK_LAUNCH("gemm_swiglu_bwd");
   return 0;

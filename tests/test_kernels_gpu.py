@@ -642,3 +642,49 @@ def test_gemm_tn_f32_weight_gradient_from_token_major_operands(T, Mo, No):
     assert torch.equal(again, out[4:4 + Mo])                                   # ordered slab sum: bit-reproducible
     with pytest.raises(RuntimeError):
         hk.gemm_tn_f32(dy[:, :Mo - 64], x, torch.empty(Mo - 64, No, device=DEV))   # Mo % 128 != 0 is rejected at the ABI
+
+
+@pytest.mark.parametrize("M", [2184, 1000, 145, 144, 8190])
+def test_gemm_144_row_tiles_bit_identical_to_256_row_tiles(M):
+    """gemm_nt_144s_kernel (12 waves, 144 x 256 tiles: 256 tiles instead of 144 at M = 2184, the reference's micro-batch 8) against
+    gemm_nt_256s_kernel on the same operands: every epilogue family - plain, bias + activation, residual, fused SwiGLU forward / backward,
+    fused RoPE - must agree bit for bit (same k order, same fp32 accumulation per element), ragged last tile rows and columns included."""
+    from lhrs_bot_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M)
+    d, ff, hd = 4096, 2048, 128
+    x = torch.randn(M, d, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(3 * d + 136, d, generator=g) * 0.02).to(DEV, torch.bfloat16)     # N = 12424: ragged last tile column
+    wo = (torch.randn(d, d, generator=g) * 0.02).to(DEV, torch.bfloat16)
+    bias = torch.randn(d, generator=g).to(DEV, torch.bfloat16)
+    res = torch.randn(M, d, generator=g).to(DEV, torch.bfloat16)
+    wgu = (torch.randn(2 * ff, d, generator=g) * 0.02).to(DEV, torch.bfloat16)
+    wdT = (torch.randn(ff, d, generator=g) * 0.02).to(DEV, torch.bfloat16)
+    dy = (torch.randn(M, d, generator=g) * 0.1).to(DEV, torch.bfloat16)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    fr = torch.outer(torch.arange(512).float(), inv)
+    cos, sin = fr.cos().to(DEV).contiguous(), fr.sin().to(DEV).contiguous()
+
+    def run():
+        out = [hk.gemm_nt(x, w), hk.gemm_nt(x, wo, bias=bias, act=hk.ACT_GELU_ERF), hk.gemm_nt(x, wo, residual=res),
+               hk.gemm_nt(x, wo, bias=bias, act=hk.ACT_QUICK_GELU, residual=res)]
+        gu, act = hk.gemm_swiglu_fwd(x, wgu, ff)
+        out += [gu.clone(), act]
+        out.append(hk.gemm_swiglu_bwd(dy, wdT, gu, ff).clone())
+        out.append(hk.gemm_rope_fwd(x, w[:3 * d], cos, sin, pos_mod=273, pos0=0, rope_cols=2 * d, head_dim=hd))
+        return out
+
+    try:
+        lib.lhrs_gemm_set_min_tiles(1)       # both tile heights are legal from one tile on (the default threshold would take the small-tile kernel at M <= 1000)
+        lib.lhrs_gemm_set_tail_split(0)
+        lib.lhrs_gemm_set_bm144(0)
+        ref = run()
+        lib.lhrs_gemm_set_bm144(2)
+        got = run()
+    finally:
+        lib.lhrs_gemm_set_bm144(1)
+        lib.lhrs_gemm_set_tail_split(1)
+        lib.lhrs_gemm_set_min_tiles(128)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert torch.equal(a, b), (i, (a.float() - b.float()).abs().max().item())
+    assert rel_err(ref[0], x.float() @ w.float().t()) < 4e-3

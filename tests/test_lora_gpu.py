@@ -59,7 +59,7 @@ def test_lora_forward_backward_and_adamw(targets, r, train_pooler):
     torch.cuda.synchronize()
     loss = O.unibind_forward(P, batch)
     loss.backward()
-    assert abs(out["total_loss"].item() - loss.item()) < 3e-3 * loss.item()
+    assert abs(out["total_loss"].item() - loss.item()) < 1e-3 * loss.item()
     for l in range(2):
         for pr in targets:
             dA, dB = lora.grad_adapter(l, pr)
@@ -118,7 +118,7 @@ def test_lora_dropout_matches_oracle_with_the_same_masks(bits):
     torch.cuda.synchronize()
     loss = O.unibind_forward(P, batch)
     loss.backward()
-    tol = 3e-3 if bits == 16 else 3e-2
+    tol = 1e-3 if bits == 16 else 3e-2
     assert abs(out["total_loss"].item() - loss.item()) < tol * loss.item()
     if bits == 16:
         for l in range(2):

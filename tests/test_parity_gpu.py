@@ -1,6 +1,6 @@
 """Parity of the HIP hot path against (a) the golden vectors produced by the reference's own modules and (b) the CPU
 oracle on the same seeded parameters.  The engine computes in bf16 (fp32 accumulation / statistics); the reference
-vectors are fp32.  Tolerances (relative L2 unless stated): activations 2e-2, loss 3e-3 relative, gradients 4e-2.
+vectors are fp32.  Tolerances (relative L2 unless stated): activations 2e-2, loss 1e-3 relative, gradients 4e-2.
 Token / label / mask indexing is bit-exact."""
 import os
 
@@ -97,7 +97,7 @@ def test_unibind_end_to_end_vs_reference_golden_and_oracle():
     assert rel(image[:, ::2], torch.from_numpy(z["image"]).float()) < 2e-2
     out = model(batch)
     loss = out["total_loss"].item()
-    assert abs(loss - float(z["loss"])) < 3e-3 * float(z["loss"]), (loss, float(z["loss"]))
+    assert abs(loss - float(z["loss"])) < 1e-3 * float(z["loss"]), (loss, float(z["loss"]))
     hid = model.text.last_hidden.reshape(2, -1, 4096)[:, ::8]          # final-norm hidden rows (reference: forward hook on LlamaModel)
     valid = torch.from_numpy(z["attention_mask"])                      # rows under the right padding are arbitrary on both sides
     S = model.text.last_hidden.shape[0] // 2
@@ -147,7 +147,7 @@ def test_ragged_right_padded_batch_vs_oracle():
     embeds = torch.where((src <= -10 ** 8)[..., None], torch.zeros_like(embeds), embeds)
     want = O.causal_lm_loss(P["llama"], O.llama_hidden(P["llama"], embeds, mask), lab)
     want.backward()
-    assert abs(loss - want.item()) < 3e-3 * want.item(), (loss, want.item())
+    assert abs(loss - want.item()) < 1e-3 * want.item(), (loss, want.item())
     assert rel(d_image, img.grad) < 5e-2
     # the value of the padding positions does not matter: junk ids under the mask give the same loss bit for bit
     ids2 = ids.clone()
@@ -172,7 +172,7 @@ def test_unibind_eight_layers_vs_reference_golden():
     assert abs(rgb.double().sum().item() - float(z["rgb_checksum"])) < 1e-6
     out = model(dict(rgb=rgb, input_ids=ids, labels=labels, attention_mask=ids.ne(0)))
     loss = out["total_loss"].item()
-    assert abs(loss - float(z["loss"])) < 3e-3 * float(z["loss"]), (loss, float(z["loss"]))
+    assert abs(loss - float(z["loss"])) < 1e-3 * float(z["loss"]), (loss, float(z["loss"]))
     d_image = model.text.backward()
     assert rel(d_image[:, ::4, ::4], torch.from_numpy(z["d_image"])) < 6e-2
     model.rgb_pooler.backward(d_image)
@@ -201,7 +201,7 @@ def test_unibind_headline_shape_s273_vs_reference_golden():
     rgb = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(int(z["rgb_seed"])))
     assert abs(rgb.double().sum().item() - float(z["rgb_checksum"])) < 1e-6
     loss = model(dict(rgb=rgb, input_ids=ids, labels=labels, attention_mask=ids.ne(0)))["total_loss"].item()
-    assert abs(loss - float(z["loss"])) < 3e-3 * float(z["loss"]), (loss, float(z["loss"]))
+    assert abs(loss - float(z["loss"])) < 1e-3 * float(z["loss"]), (loss, float(z["loss"]))
     hid = model.text.last_hidden.reshape(2, 273, 4096)
     assert rel(hid[:, ::8, ::4], torch.from_numpy(z["hidden_sample"]).float()) < 2e-2
     d_image = model.text.backward()
@@ -220,7 +220,7 @@ def test_full_depth_32_layers_s273_vs_oracle_on_host_cpu():
     """The MEASURED workload at full depth: B = 1, S = 273, all 32 LLaMA-2-7B layers (bench.py's model, one sample), HIP path in bf16
     against the fp32 oracle run on the GPU box's HOST cores with the same seeded parameters (27 GB fp32; the oracle is pinned to the
     reference at this sequence length by tests/test_oracle_cpu.py::test_unibind_headline_shape_s273_matches_reference and at depth by the
-    8-layer fixture).  Checks bf16 drift over 32 residual layers: loss 3e-3, final-norm hidden 3e-2, d loss / d image 6e-2, every one
+    8-layer fixture).  Checks bf16 drift over 32 residual layers: loss 1e-3, final-norm hidden 3e-2, d loss / d image 6e-2, every one
     of the 87 projector gradient norms 6e-2."""
     import gc
     torch.set_num_threads(min(64, os.cpu_count() or 1))
@@ -254,7 +254,7 @@ def test_full_depth_32_layers_s273_vs_oracle_on_host_cpu():
     want = O.unibind_forward(P, batch, col)
     col["image"].retain_grad()
     want.backward()
-    assert abs(loss - want.item()) < 3e-3 * want.item(), (loss, want.item())
+    assert abs(loss - want.item()) < 1e-3 * want.item(), (loss, want.item())
     # 32 residual layers forward and 32 backward: bf16 rounding accumulates (2 layers: hidden < 2e-2, d_image < 5e-2).  Yardstick = the SAME
     # oracle code run with torch-CPU bf16 tensors and autograd on the same embeddings (what the reference's own bf16 path does: one
     # rounding per op): the HIP path, which rounds once per fused kernel, must not sit further from fp32 than 1.5x that (measured: hidden 0.0428 vs 0.0349, d_image 0.0767 vs 0.0619)
@@ -268,14 +268,23 @@ def test_full_depth_32_layers_s273_vs_oracle_on_host_cpu():
     yard_h = rel(hb.detach().float(), col["hidden"].detach())
     yard_g = rel(eb.grad[:, pos:pos + 144].float(), col["image"].grad)
     err_h, err_g = rel(hid, col["hidden"].detach()), rel(d_image, col["image"].grad)
-    msg = (f"32 layers, S=273: loss HIP {loss:.5f} / fp32 oracle {want.item():.5f}; hidden rel-L2 HIP {err_h:.4f} vs torch-bf16 {yard_h:.4f}; "
-           f"d loss/d image HIP {err_g:.4f} vs torch-bf16 {yard_g:.4f}")
+    # the yardstick starts from the fp32 oracle's embeddings rounded ONCE; the end-to-end HIP numbers above also carry the bf16 error of the
+    # ViT + projector in their 144 image rows.  Like for like: the HIP decoder alone on the SAME bf16-rounded oracle embeddings
+    model.text.tail_rows_only = False
+    model.text.decode(batch["input_ids"], image_embedding=col["image"].detach().to(DEV, torch.bfloat16), attention_mask=batch["attention_mask"],
+                      labels=batch["labels"])
+    hid2 = model.text.last_hidden.float().cpu().reshape(1, 273, 4096)
+    d_image2 = model.text.backward().float().cpu()
+    err_h2, err_g2 = rel(hid2, col["hidden"].detach()), rel(d_image2, col["image"].grad)
+    msg = (f"32 layers, S=273: loss HIP {loss:.5f} / fp32 oracle {want.item():.5f}; end to end: hidden rel-L2 HIP {err_h:.4f}, d loss/d image HIP {err_g:.4f}; "
+           f"decoder alone on the oracle's embeddings: hidden HIP {err_h2:.4f} vs torch-bf16 {yard_h:.4f}; d loss/d image HIP {err_g2:.4f} vs torch-bf16 {yard_g:.4f}")
     print(msg)
     out_dir = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     open(os.path.join(out_dir, "full_depth_parity.txt"), "w").write(msg + "\n")
     assert err_h < max(3e-2, 1.5 * yard_h), msg
     assert err_g < max(6e-2, 1.5 * yard_g), msg
+    assert err_h2 < 1.1 * yard_h and err_g2 < 1.1 * yard_g, msg   # one rounding per fused kernel: not further from fp32 than op-by-op bf16
     ref_sd = OP.pooler_to_ref(P["pooler"])
     bad = []
     for name, got in got_norms.items():
@@ -332,3 +341,52 @@ def test_last_layer_on_supervised_rows_only_equals_every_row(ragged):
     model.text.tail_rows_only = True
     model(dict(batch, labels=labels2))
     assert model.text.last_hidden.shape[0] == B * S
+
+
+@pytest.mark.timeout(2400)
+@pytest.mark.parametrize("B", [8, 30])
+def test_measured_micro_batches_end_to_end_vs_oracle(B):
+    """The micro-batches bench.py measures - 8 (Script/train_stage1.sh:11) and 30 (the bench default) - at the
+    headline sequence length S = 273 with 2 decoder layers, default engine settings (persistent 256x256 GEMM at M = 2184 / 8190 with its
+    tail-row rule, fused RoPE / SwiGLU epilogues, last layer on the supervised rows): loss, d loss / d image and all 87 projector
+    gradient norms against oracle autograd (fp32, host cores) on the same seeded parameters."""
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    P = {"vit": OP.make_vit_params(seed=2), "pooler": OP.make_pooler_params(seed=1), "llama": OP.make_llama_params(seed=3, layers=2)}
+    model = UniBind(("rgb", "text"), None, device=DEV, llama_layers=2).load_params(P)
+    model.prepare_for_training()
+    g = torch.Generator().manual_seed(8000 + B)
+    T = 130
+    ids = torch.randint(3, 32000, (B, T), generator=g)
+    ids[:, 0], ids[:, 1] = 1, -200
+    labels = ids.clone()
+    labels[:, :2] = -100
+    batch = dict(rgb=torch.randn(B, 3, 224, 224, generator=g), input_ids=ids, labels=labels, attention_mask=ids.ne(0))
+    loss = model(batch)["total_loss"].item()
+    d_image = model.text.backward()
+    model.rgb_pooler.backward(d_image)
+    torch.cuda.synchronize()
+    got = {n: model.rgb_pooler.g[n].double().cpu() for n, _ in model.rgb_pooler.named_parameters()}
+    d_image = d_image.float().cpu()
+    for k, v in P["pooler"].items():
+        if torch.is_tensor(v):
+            v.requires_grad_(True)
+    for L in P["pooler"]["layers"]:
+        for v in L.values():
+            v.requires_grad_(True)
+    col = {}
+    want = O.unibind_forward(P, batch, col)
+    col["image"].retain_grad()
+    want.backward()
+    assert abs(loss - want.item()) < 1e-3 * want.item(), (loss, want.item())
+    assert rel(d_image, col["image"].grad) < 5e-2
+    ref_sd = OP.pooler_to_ref(P["pooler"])
+    bad = []
+    for name, gv in got.items():
+        t = ref_sd[name]
+        base = t if t.is_leaf else t._base
+        w = (P["pooler"]["query"].grad if name == "query" else base.grad).double()
+        if abs(gv.norm().item() - w.norm().item()) > 5e-2 * w.norm().item():
+            bad.append((name, gv.norm().item(), w.norm().item()))
+    assert len(got) == 87 and not bad, bad
+    assert rel(got["out_proj.bias"], P["pooler"]["out_proj_b"].grad) < 5e-2
+    assert rel(got["query"], P["pooler"]["query"].grad.reshape(got["query"].shape)) < 5e-2
