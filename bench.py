@@ -45,48 +45,49 @@ def make_batch(B, T, device, seed):
     return dict(rgb=rgb.to(device), input_ids=ids.to(device), labels=labels.to(device), attention_mask=ids.ne(0).to(device))
 
 
-def cpu_baseline(S: int, budget_s: float = 25.0):
-    """Oracle (CPU restatement of the reference, fp32 torch) on a bounded sample (~10-15 s of CPU work): eight samples through ViT +
-    pooler (fwd+bwd) + FOUR LLaMA-7B-width decoder layers (fwd + activation-gradient bwd) + final norm/lm_head/CE, the per-layer time
-    extrapolated to 32 layers.  Reported, not optimised-for."""
+def cpu_baseline(S: int, layers: int = 32):
+    """The CPU oracle (oracle/lhrs_oracle.py: the restatement of the reference's fp32 PyTorch path that tests/ pin to the imported reference) timed
+    on this box's host cores, UN-extrapolated: one whole stage-1 step - ViT-L/14 forward, AttnPooler forward + backward, splice, all 32
+    LLaMA-2-7B-width decoder layers forward + activation-gradient backward, lm_head + shifted CE - through `unibind_forward` + autograd.
+      * `value`:   the headline shape (S = 273: 128-token captions), 2 samples, one step
+      * `config1`: BASELINE configs[0] / SURVEY §8(d) config 1 (B = 4, T = 34 -> S = 177), one step
+    32 distinct fp32 weight buffers per decoder tensor (27 GB; 4 seeded layers, each copied 8 times - the values do not matter to a clock, the
+    memory traffic does).  One untimed single-sample step on ONE layer warms the thread pool and the allocator.  Reported, not optimised-for."""
     from oracle import lhrs_oracle as O
     from oracle import params as OP
 
-    NL = 4  # decoder layers actually timed
-    threads = min(32, os.cpu_count() or 1)  # 256 OpenMP threads on these shapes are slower than 32 (measured)
+    threads = min(32, os.cpu_count() or 1)  # 256 OpenMP threads on these shapes are slower than 32 (measured in round 1)
     torch.set_num_threads(threads)
-    P = {"vit": OP.make_vit_params(seed=2), "pooler": OP.make_pooler_params(seed=1), "llama": OP.make_llama_params(seed=3, layers=NL)}
+    t_build = time.perf_counter()
+    P = {"vit": OP.make_vit_params(seed=2), "pooler": OP.make_pooler_params(seed=1), "llama": OP.make_llama_params(seed=3, layers=4)}
+    seeded = P["llama"]["layers"]
+    P["llama"]["layers"] = [seeded[i % 4] if i < 4 else {k: v.clone() for k, v in seeded[i % 4].items()} for i in range(layers)]
     for L in [P["pooler"]] + P["pooler"]["layers"]:
         for v in L.values():
             if torch.is_tensor(v):
                 v.requires_grad_(True)
-    g = torch.Generator().manual_seed(0)
-    NB = 8  # samples in the CPU sample
-    rgb = torch.randn(NB, 3, 224, 224, generator=g)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        taps = O.vit_forward(P["vit"], rgb)
-    t_vit = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    img = O.pooler_forward(P["pooler"], taps)
-    img.backward(torch.randn(img.shape, generator=g) * 0.01)
-    t_pool = time.perf_counter() - t0
-    x = torch.randn(NB, S, 4096, generator=g).requires_grad_(True)
-    labels = torch.randint(3, 32000, (NB, S), generator=g)
-    labels[:, :146] = -100
-    t0 = time.perf_counter()
-    h = O.llama_hidden(P["llama"], x, None)
-    loss = O.causal_lm_loss(P["llama"], h, labels)
-    loss.backward()
-    t_l1 = time.perf_counter() - t0
-    # the same without the decoder layer = norm + lm_head + CE
-    x2 = torch.randn(NB, S, 4096, generator=g).requires_grad_(True)
-    t0 = time.perf_counter()
-    h2 = O._rms(x2, P["llama"]["norm_w"], 1e-5)
-    O.causal_lm_loss(P["llama"], h2, labels).backward()
-    t_head = time.perf_counter() - t0
-    t_layer = max(t_l1 - t_head, 1e-6) / NL
-    t_full = t_vit + t_pool + t_head + 32 * t_layer
+    t_build = time.perf_counter() - t_build
+
+    def zero():
+        for L in [P["pooler"]] + P["pooler"]["layers"]:
+            for v in L.values():
+                if torch.is_tensor(v):
+                    v.grad = None
+
+    def one_step(B, T, layers=None):
+        batch = make_batch(B, T, "cpu", seed=322)
+        Q = P if layers is None else {**P, "llama": {**P["llama"], "layers": P["llama"]["layers"][:layers]}}
+        t0 = time.perf_counter()
+        loss = O.unibind_forward(Q, batch)
+        loss.backward()
+        dt = time.perf_counter() - t0
+        zero()
+        return dt, float(loss)
+
+    one_step(1, 34, layers=1)                       # warm-up (thread pool, allocator): not timed
+    T_head = S - 143
+    t_head, loss_head = one_step(2, T_head)
+    t_c1, loss_c1 = one_step(4, 34)
     cpu_model = "unknown CPU"
     try:
         for line in open("/proc/cpuinfo"):
@@ -95,27 +96,13 @@ def cpu_baseline(S: int, budget_s: float = 25.0):
                 break
     except OSError:
         pass
-    # BASELINE configs[0] (B = 4, T = 34 => S = 177) on the same oracle and threads: ViT + pooler scale with the
-    # sample count, the LLaMA part is re-timed at the shorter sequence on the same 4 layers
-    B1, S1 = 4, 177
-    x1 = torch.randn(B1, S1, 4096, generator=g).requires_grad_(True)
-    lab1 = torch.randint(3, 32000, (B1, S1), generator=g)
-    lab1[:, :146] = -100
-    t0 = time.perf_counter()
-    O.causal_lm_loss(P["llama"], O.llama_hidden(P["llama"], x1, None), lab1).backward()
-    t_l1c = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    O.causal_lm_loss(P["llama"], O._rms(x1.detach().requires_grad_(True), P["llama"]["norm_w"], 1e-5), lab1).backward()
-    t_h1c = time.perf_counter() - t0
-    t_c1 = (t_vit + t_pool) * B1 / NB + t_h1c + 32 * max(t_l1c - t_h1c, 1e-6) / NL
-    return {"value": NB / t_full, "unit": "samples/s", "cores": threads, "kind": "port", "cpu_model": cpu_model,
+    return {"value": round(2 / t_head, 4), "unit": "samples/s", "cores": threads, "kind": "port", "cpu_model": cpu_model,
             "host_logical_cpus": os.cpu_count(),
             "cores_note": "32 OpenMP threads: on these shapes torch's CPU GEMMs are slower with all hardware threads than with 32 (measured in round 1)",
-            "sample": (f"{NB} samples, S={S}: ViT-L/14 fwd {t_vit:.2f}s + AttnPooler fwd+bwd {t_pool:.2f}s + lm_head/CE fwd+bwd {t_head:.2f}s "
-                       f"+ {NL} of 32 LLaMA-7B layers fwd+dX-bwd {NL * t_layer:.2f}s, per-layer time extrapolated x32 (oracle/lhrs_oracle.py, fp32 torch CPU)"),
-            "config1": {"value": B1 / t_c1, "unit": "samples/s", "cores": threads,
-                        "sample": f"BASELINE configs[0] (B=4, T=34, S=177): ViT + pooler scaled from the {NB}-sample timing, lm_head/CE {t_h1c:.2f}s, "
-                                  f"{NL} of 32 LLaMA layers {t_l1c - t_h1c:.2f}s extrapolated x32"}}
+            "sample": (f"ONE full stage-1 step of 2 samples at S={S} through oracle.unibind_forward + autograd, all {layers} decoder layers of this run's model, nothing extrapolated: "
+                       f"{t_head:.1f} s (loss {loss_head:.3f}); fp32 torch CPU; building the fp32 weights ({0.81 * layers + 1.5:.0f} GB) took {t_build:.1f} s (not timed)"),
+            "config1": {"value": round(4 / t_c1, 4), "unit": "samples/s", "cores": threads,
+                        "sample": f"BASELINE configs[0] (B=4, T=34, S=177), ONE full step, all {layers} layers, nothing extrapolated: {t_c1:.1f} s (loss {loss_c1:.3f})"}}
 
 
 
@@ -204,6 +191,76 @@ def decode_probe(model, dev, weights="bf16", prompt_tokens=60, new_tokens=256, s
                          "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_token": int(w_bytes + kv_bytes),
                          "timing": f"wall clock (synchronised) of generate() at {n_short} and {new_tokens} new tokens; per-token = difference / {new_tokens - n_short}"}}
+
+
+def timed_run(engine, batch, steps, warmup, world, lib, on_timed_start=None):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; the GEMM launches inside the timed region are timed live
+    with HIP events on their launch stream (lhrs_gemm_profile_*), every step boundary carries an event (median step time)."""
+    import ctypes
+    from lhrs_bot_amd import _lib
+
+    def step():
+        out = engine(batch)
+        engine.backward(out["total_loss"])
+        engine.step()
+        return out["total_loss"]
+
+    loss = None
+    for _ in range(warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    _lib.check(lib.lhrs_gemm_profile_enable(16000), "gemm_profile_enable")
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    if on_timed_start is not None:
+        on_timed_start()
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(steps):
+        loss = step()
+        marks[i + 1].record()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = (ctypes.c_double * 5)()
+    _lib.check(lib.lhrs_gemm_profile_read(ctypes.addressof(prof)), "gemm_profile_read")
+    kinds = (ctypes.c_double * 12)()
+    _lib.check(lib.lhrs_gemm_profile_read_kinds(ctypes.addressof(kinds)), "gemm_profile_read_kinds")
+    lib.lhrs_gemm_profile_enable(0)
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    median = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
+    return dict(dt=dt, loss=loss, prof=list(prof), kinds=list(kinds), median_ms=median)
+
+
+GEMM_KERNEL_DESC = ("gemm_nt_256s_kernel<ACT, 0, K2P> (256x256 tile, 16 waves) / gemm_nt_144s_kernel<ACT, 0> (144x256 tile, 12 waves; chosen per launch "
+                    "when its rounds finish first): BK=64 double-buffered LDS stages via global_load_lds DMA, v_mfma_f32_16x16x32_bf16, persistent over "
+                    "tiles; the launches with a fused SwiGLU / RoPE epilogue are timed separately under `variants`")
+
+
+def roofline_block(prof, kinds, steps, B, S, scale_layers, sclk=None, watts=None):
+    n_samp, ms, fl = prof[0], prof[1], prof[2]
+    ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    vnames = ("<ACT,0> plain", "<0,1> SwiGLU-fwd epilogue", "<0,2> SwiGLU-bwd epilogue", "<0,3> RoPE epilogue")
+    variants = {}
+    for k, nm in enumerate(vnames):
+        n_k, ms_k, fl_k = kinds[3 * k], kinds[3 * k + 1], kinds[3 * k + 2]
+        if n_k > 0 and ms_k > 0:
+            tf = fl_k / (ms_k * 1e-3) / 1e12
+            variants[nm] = {"launches": int(n_k), "avg_launch_us": round(1e3 * ms_k / n_k, 2), "achieved_tflops": round(tf, 1),
+                            "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
+    all_ms = sum(kinds[3 * k + 1] for k in range(4))
+    all_fl = sum(kinds[3 * k + 2] for k in range(4))
+    return {"bound": "mfma", "kernel": GEMM_KERNEL_DESC, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "traffic_note": "not measured in this run (PMC passes are separate rocprofv3 runs: profiles/*gemm_traffic.json)",
+            "variants": variants, "all_variants_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else None,
+            "launches_timed": int(n_samp), "avg_launch_us": round(1e3 * ms / max(n_samp, 1), 2),
+            "sclk_mhz_during_timed_region": round(sclk) if sclk else None, "package_power_w": round(watts) if watts else None,
+            "frac_of_peak_at_measured_clock": round(ach / (PEAK_BF16_TFLOPS * sclk / 2400.0), 4) if sclk else None,
+            "gemm_flops_share_of_step": round(prof[4] / steps / (B * f_alg(S)), 3) if scale_layers == 1.0 else None}
 
 
 def spawn_ranks(n: int):
@@ -314,36 +371,10 @@ def main():
                             comm_dtype=getattr(torch, a.comm_dtype))
     batch = make_batch(B, T, dev, seed=322 + rank)  # reference seed convention (main_pretrain_stage1.py:281-287)
 
-    def step():
-        out = engine(batch)
-        engine.backward(out["total_loss"])
-        engine.step()
-        return out["total_loss"]
-
-    for _ in range(a.warmup):
-        loss = step()
-    torch.cuda.synchronize()
-    import ctypes
-    _lib.check(lib.lhrs_gemm_profile_enable(16000), "gemm_profile_enable")
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
     smi = _SmiSampler() if rank == 0 else None
-    if smi is not None:
-        smi.start()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    run = timed_run(engine, batch, a.steps, a.warmup, world, lib, on_timed_start=smi.start if smi is not None else None)
     sclk, watts = smi.stop() if smi is not None else (None, None)
-    prof = (ctypes.c_double * 5)()
-    _lib.check(lib.lhrs_gemm_profile_read(ctypes.addressof(prof)), "gemm_profile_read")
-    kinds = (ctypes.c_double * 12)()
-    _lib.check(lib.lhrs_gemm_profile_read_kinds(ctypes.addressof(kinds)), "gemm_profile_read_kinds")
-    lib.lhrs_gemm_profile_enable(0)
+    dt, loss, prof, kinds = run["dt"], run["loss"], run["prof"], run["kinds"]
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -352,22 +383,7 @@ def main():
 
     if rank == 0:
         sps = world * B * a.steps / dt
-        n_samp, ms, fl = prof[0], prof[1], prof[2]
-        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         scale_layers = a.llama_layers / 32.0
-        traffic, traffic_src = None, None  # L2-miss-side bytes per launch of the dominant kernel: separate rocprofv3 --pmc passes, NOT this run
-        tpath = os.path.join(ROOT, "profiles", "r02_mfma16_gemm_traffic.json")
-        if os.path.exists(tpath) and B == 30 and scale_layers == 1.0 and a.stage == 1:
-            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
-            traffic_src = "profiles/r02_mfma16_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command; a constant, not measured in this run)"
-        vnames = ("<ACT,0> plain", "<0,1> SwiGLU-fwd epilogue", "<0,2> SwiGLU-bwd epilogue", "<0,3> RoPE epilogue")
-        variants = {}
-        for k, nm in enumerate(vnames):
-            n_k, ms_k, fl_k = kinds[3 * k], kinds[3 * k + 1], kinds[3 * k + 2]
-            if n_k > 0 and ms_k > 0:
-                tf = fl_k / (ms_k * 1e-3) / 1e12
-                variants[nm] = {"launches": int(n_k), "avg_launch_us": round(1e3 * ms_k / n_k, 2), "achieved_tflops": round(tf, 1),
-                                "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
         # FLOPs the step EXECUTES: F_alg counts lm_head forward + backward on all S positions; the engine runs it on the
         # rows that have a target only (caption tokens), so the executed share is lower
         tgt_rows = a.caption_tokens
@@ -378,7 +394,7 @@ def main():
         res = {
             "metric": ("stage-1 pretrain samples/sec (224^2 image + 128-tok caption)" if a.stage == 1 else
                        f"stage-{a.stage} LoRA train samples/sec (224^2 image + 128-tok sequence)"), "value": round(sps, 3), "unit": "samples/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "ms_per_step_median": round(run["median_ms"], 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.bits == 16 or a.stage == 1 else "e4m3 base weights + bf16", "data": "synthetic",
             "config": {"workload": (("BASELINE configs[1]: stage-1 projector-only" if world == 1 else "BASELINE configs[2]: stage-1 projector-only, DDP") if a.stage == 1
                                     else ("BASELINE configs[3]: stage-3 SFT, LoRA r=8 on q,k,v,o" if a.stage == 3 else "stage-2 (Config/multi_modal_stage2.yaml): LoRA r=128 on all linears + projector"))
@@ -392,41 +408,31 @@ def main():
             "loss": round(final_loss, 4),
             "step_mfma_frac": round(sps / world * f_alg(S) / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 and a.stage == 1 else None,
             "step_mfma_frac_executed": round(sps / world * f_exec / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 and a.stage == 1 else None,
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_256s_kernel<ACT, 0, K2P> (256x256 tile, 16 waves, BK=64 double-buffered LDS stages via global_load_lds DMA, v_mfma_f32_16x16x32_bf16; the launches with a fused SwiGLU / RoPE epilogue are timed separately under `variants`)", "achieved": round(ach, 1),
-                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "variants": variants,
-                         "launches_timed": int(n_samp), "avg_launch_us": round(1e3 * ms / max(n_samp, 1), 2),
-                         "sclk_mhz_during_timed_region": round(sclk) if sclk else None, "package_power_w": round(watts) if watts else None,
-                         "frac_of_peak_at_measured_clock": round(ach / (PEAK_BF16_TFLOPS * sclk / 2400.0), 4) if sclk else None,
-                         "gemm_flops_share_of_step": round(prof[4] / a.steps / (B * f_alg(S)), 3) if scale_layers == 1.0 else None},
+            "roofline": roofline_block(prof, kinds, a.steps, B, S, scale_layers, sclk, watts),
         }
         if world == 1 and not a.no_extra and a.stage == 1:
             extra = {}
-            try:  # the reference script's micro-batch (Script/train_stage1.sh:11), same engine, a few steps after the headline run
+            try:  # the reference script's micro-batch (Script/train_stage1.sh:11), same engine, its own timed region
                 if B != 8:
-                    b8 = make_batch(8, T, dev, seed=322)
-                    for _ in range(2):
-                        out = engine(b8); engine.backward(out["total_loss"]); engine.step()
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    n8 = 6
-                    for _ in range(n8):
-                        out = engine(b8); engine.backward(out["total_loss"]); engine.step()
-                    torch.cuda.synchronize()
-                    d8 = time.perf_counter() - t1
-                    extra["micro_batch_8"] = {"value": round(8 * n8 / d8, 2), "unit": "samples/s", "ms_per_step": round(1e3 * d8 / n8, 3), "steps": n8,
-                                              "step_mfma_frac": round(8 * n8 / d8 * f_alg(S) / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 else None,
-                                              "note": "the reference script's per-GPU batch (an 80 GB-GPU constraint): M = 2184 fills 56 % of one round of 256x256 tiles"}
+                    r8 = timed_run(engine, make_batch(8, T, dev, seed=322), 12, 3, 1, lib)
+                    sps8 = 8 * 12 / r8["dt"]
+                    res["micro_batch_8"] = {
+                        "value": round(sps8, 2), "unit": "samples/s", "ms_per_step": round(1e3 * r8["dt"] / 12, 3), "ms_per_step_median": round(r8["median_ms"], 3),
+                        "steps": 12, "warmup": 3, "micro_batch_per_gpu": 8, "loss": round(float(r8["loss"].item()), 4),
+                        "step_mfma_frac": round(sps8 * f_alg(S) / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 else None,
+                        "roofline": roofline_block(r8["prof"], r8["kinds"], 12, 8, S, scale_layers),
+                        "note": "the reference script's per-GPU batch (an 80 GB-GPU constraint): M = 2184 rows = sixteen 144-row tile rows"}
                 del engine
                 torch.cuda.empty_cache()
-                extra["generate_bf16"] = decode_probe(model, dev, "bf16", new_tokens=128)
-                extra["generate_fp8"] = decode_probe(model, dev, "fp8", new_tokens=128)
+                # one image, ~60-token prompt, 512 new tokens, greedy
+                extra["generate_bf16"] = decode_probe(model, dev, "bf16", new_tokens=512)
+                extra["generate_fp8"] = decode_probe(model, dev, "fp8", new_tokens=512)
             except Exception as e:  # extras must never take the headline number down
                 extra["error"] = f"{type(e).__name__}: {e}"
             res["extra"] = extra
         if world == 1 and not a.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(S)
+                res["cpu_baseline"] = cpu_baseline(S, a.llama_layers)
             except Exception as e:  # the checker must never take the product number down with it
                 res["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(res), flush=True)

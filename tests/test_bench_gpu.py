@@ -27,16 +27,18 @@ def test_bench_emits_the_contract_line():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and 0 < r["achieved"] < r["peak"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["launches_timed"] > 0
-    assert "not measured in this run" in (r["traffic_source"] or "not measured in this run")
+    assert r["traffic"] is None and "not measured in this run" in r["traffic_note"] and d["ms_per_step_median"] > 0
     v = r["variants"]
     assert {"<ACT,0> plain", "<0,1> SwiGLU-fwd epilogue", "<0,2> SwiGLU-bwd epilogue", "<0,3> RoPE epilogue"} <= set(v), v
     assert all(0 < x["frac"] < 1 and x["launches"] > 0 for x in v.values())
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "samples/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
-    assert c["config1"]["value"] > 0 and "B=4, T=34" in c["config1"]["sample"]
+    assert c["config1"]["value"] > 0 and "B=4, T=34" in c["config1"]["sample"] and "nothing extrapolated" in c["sample"]
     e = d["extra"]
     assert "error" not in e, e
-    assert e["micro_batch_8"]["value"] > 0 and e["generate_bf16"]["value"] > 0 and e["generate_fp8"]["value"] > 0
+    m8 = d["micro_batch_8"]                      # the reference script's micro-batch: a first-class block with its own roofline
+    assert m8["value"] > 0 and m8["micro_batch_per_gpu"] == 8 and m8["roofline"]["bound"] == "mfma" and 0 < m8["roofline"]["frac"] < 1
+    assert e["generate_bf16"]["value"] > 0 and e["generate_fp8"]["value"] > 0 and e["generate_bf16"]["new_tokens"] == 512
     assert e["generate_bf16"]["roofline"]["bound"] == "hbm" and 0 < e["generate_bf16"]["roofline"]["frac"] < 1
 
 
