@@ -1144,14 +1144,16 @@ static int num_cus() {
   return n;
 }
 static dim3 grid_256s(long tiles) { return dim3((unsigned)(g_gemm_persist ? (tiles < num_cus() ? tiles : num_cus()) : tiles)); }
-// Tile height of the persistent kernels: 256 rows (16 waves) or 144 rows (12 waves, gemm_144s_kernel.inc).  Both walk ceil(tiles / CUs) rounds; a
-// 144-row tile is 0.5625 of the MFMA work of a 256-row tile and runs that work ~8 % less efficiently (more DMA per MFMA) - take whichever
-// finishes first.  M = 2184 (micro-batch 8): 144 tiles -> 256 (N = 4096), 432 -> 768, 774 -> 1376, 387 -> 688.  0 = never, 1 = cost model, 2 = whenever legal
+// Tile height of the persistent kernels: 256 rows (16 waves) or 144 rows (12 waves, gemm_144s_kernel.inc).  Both walk ceil(tiles / CUs) rounds.  A
+// 144-row tile is 0.5625 of the MFMA work of a 256-row tile but costs ~0.8 of its time: more DMA per MFMA (1050 against 1300 TFLOP/s at
+// M = 8190), and a 256-row launch that leaves CUs idle runs its busy CUs at a higher clock (measured at M = 2184, one round each: 73 / 174 / 350
+// / 69 / 191 us against 98 / 205 / 482 / 86 / 225 us for o / down / d-gate|up / d-o / d-qkv).  Take whichever finishes first: at M = 2184 the five
+// N = 4096 products (144 tiles -> 256) go to 144 rows, qkv / gate|up / d-down (432 / 774 / 387 tiles) stay.  0 = never, 1 = cost model, 2 = whenever legal
 static int g_gemm_bm144 = 1;
-static double g_gemm_bm144_cost = 0.5625 * 1.08;
+static double g_gemm_bm144_cost = 0.8;
 extern "C" int lhrs_gemm_set_bm144(int mode) { g_gemm_bm144 = mode; return 0; }
-static bool pick_144(int M, long tiles_n, int K2, bool drop) {
-  if (g_gemm_bm144 == 0 || K2 > 0 || drop) return false;   // the second operand pair (fused LoRA) and the dropout mask live in the 256-row kernel only
+static bool pick_144(int M, long tiles_n, int K, int K2, bool drop) {
+  if (g_gemm_bm144 == 0 || K2 > 0 || drop || K < 192) return false;   // the second operand pair (fused LoRA) and the dropout mask live in the 256-row kernel only
   if (g_gemm_bm144 == 2) return true;
   const long P = num_cus(), t256 = (long)cdiv(M, 256) * tiles_n, t144 = (long)cdiv(M, 144) * tiles_n;
   return (double)((t144 + P - 1) / P) * g_gemm_bm144_cost < (double)((t256 + P - 1) / P);
@@ -1252,7 +1254,7 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   // are cheaper as a separate small-tile launch (~2.5x the time per FLOP, but no idle CUs), the row range is cut there: whole
   // 256-row tile rows for the 16-wave kernel, the remaining rows for the 64x128 / 128x128 kernel.  Disjoint rows of C, no partials.
   const bool s_kernel = use256 && g_gemm_allow_256 == 2 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128;
-  const bool bm144 = s_kernel && !out_f32 && pick_144(M, cdiv(N, 256), K2, g.drop_thresh != 0);
+  const bool bm144 = s_kernel && !out_f32 && pick_144(M, cdiv(N, 256), K, K2, g.drop_thresh != 0);
   if (s_kernel && !bm144 && t_split_ok && g_gemm_tail_split && !g.drop_thresh) {
     const int tm = cdiv(M, 256), tn = cdiv(N, 256);
     const long T = (long)tm * tn, rounds = (T + 255) / 256, full = T / 256;
@@ -1371,7 +1373,7 @@ extern "C" int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int
   // Tail rows, as in gemm_launch: when the tile rows that spill over the last full round of the 256 CUs are cheaper as a small-tile launch
   // (M = 2184, the reference's micro-batch 8: 9 x 86 = 774 tiles = 3 rounds + SIX tiles), the fused kernel takes the whole tile rows and the
   // remaining rows go through the plain GEMM + the SwiGLU kernel - the same bf16 gate|up rows, the same silu(gate) * up on them
-  const bool bm144 = pick_144(M, ff / 128, K2, false);
+  const bool bm144 = pick_144(M, ff / 128, K, K2, false);
   if (!bm144 && t_split_ok && g_gemm_tail_split && ld_gu == 2 * ff && ld_act == ff) {
     const int tm = cdiv(M, 256), tn = ff / 128;
     const long T = (long)tm * tn, rounds = (T + 255) / 256, full = T / 256;
@@ -1428,7 +1430,7 @@ extern "C" int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw
   g.A = (const bf16_t*)X; g.B = (const bf16_t*)W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = ldw; g.ldc = ldc;
   g.alpha = 1.f; g.A2 = (const bf16_t*)A2; g.B2 = (const bf16_t*)B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
   g.epi = 3; g.rope_cos = cos_t; g.rope_sin = sin_t; g.rope_mod = pos_mod; g.rope_pos0 = pos0; g.rope_cols = rope_cols;
-  const bool bm144 = pick_144(M, cdiv(N, 256), K2, false);
+  const bool bm144 = pick_144(M, cdiv(N, 256), K, K2, false);
   g.tilesM = cdiv(M, bm144 ? 144 : 256); g.tilesN = cdiv(N, 256);
   const int pslot = prof_count(M, N, K + K2, 3, (hipStream_t)stream);
   if (bm144) LAUNCH_144(0, 3, grid_256s((long)g.tilesM * g.tilesN), (hipStream_t)stream, g);
@@ -1450,7 +1452,7 @@ extern "C" int lhrs_gemm_swiglu_bwd(const void* dY, int ldy, const void* WdT, in
   g.A = (const bf16_t*)dY; g.B = (const bf16_t*)WdT; g.C = dgu; g.M = M; g.N = ff; g.K = K; g.lda = ldy; g.ldb = ldw; g.ldc = ld_gu;
   g.alpha = 1.f; g.A2 = (const bf16_t*)A2; g.B2 = (const bf16_t*)B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
   g.epi = 2; g.ff = ff; g.aux = (const bf16_t*)gu; g.ld_aux = ld_gu;
-  const bool bm144 = pick_144(M, cdiv(ff, 256), K2, false);
+  const bool bm144 = pick_144(M, cdiv(ff, 256), K, K2, false);
   g.tilesM = cdiv(M, bm144 ? 144 : 256); g.tilesN = cdiv(ff, 256);
   hipStream_t s = (hipStream_t)stream;
   const int pslot = prof_count(M, ff, K + K2, 2, s);

@@ -666,7 +666,7 @@ def test_gemm_144_row_tiles_bit_identical_to_256_row_tiles(M):
     cos, sin = fr.cos().to(DEV).contiguous(), fr.sin().to(DEV).contiguous()
 
     def run():
-        out = [hk.gemm_nt(x, w), hk.gemm_nt(x, wo, bias=bias, act=hk.ACT_GELU_ERF), hk.gemm_nt(x, wo, residual=res),
+        out = [hk.gemm_nt(x, w), hk.gemm_nt(x, wo, bias=bias, act=hk.ACT_GELU), hk.gemm_nt(x, wo, residual=res),
                hk.gemm_nt(x, wo, bias=bias, act=hk.ACT_QUICK_GELU, residual=res)]
         gu, act = hk.gemm_swiglu_fwd(x, wgu, ff)
         out += [gu.clone(), act]
