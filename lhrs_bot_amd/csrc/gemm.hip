@@ -342,7 +342,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256p_kernel(GemmArgs g) {
   for (int s = 0; s < NS - 2; ++s)
 #pragma unroll
     for (int j = 0; j < 4; ++j) issue1(s, j);
-  if constexpr (NS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  // NOT a counted vmcnt(4 / 8): the LDS-DMA pieces of one wave do not retire in issue order (round 3: a counted wait on the older of two
+  // stages in flight produced wrong tiles in gemm_nt_144s_kernel, 10 of 12 repetitions).  This fallback kernel therefore waits for everything
+  // it has issued; its ring still spreads the issue, but a stage has one stage time to land, like in the two-buffer kernels
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int j = 0; j < 4; ++j) issue1(NS - 2, j);
@@ -357,9 +360,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256p_kernel(GemmArgs g) {
   auto body = [&](auto dma_c, auto vm_c, int kt) {
     constexpr bool DMA = decltype(dma_c)::value;
     constexpr int VM = decltype(vm_c)::value;  // DMA pieces that may still be in flight: the stages after kt+1
-    if constexpr (VM == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (VM == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    (void)VM;  // see the prologue: counted waits on LDS-DMA are not safe
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const unsigned so = ((unsigned)(kt + 1) % NS) * STAGE;
     const unsigned aa0 = a_base + so + koff0, ba0 = b_base + so + koff0;
