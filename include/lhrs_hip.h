@@ -120,6 +120,8 @@ int lhrs_gemm_set_persistent(int on);
  * is 16 x 16 = 256 tiles of 144 x 256 instead of 144 tiles of 256 x 256 -, 2 = 144 rows wherever the kernel applies (A/B tests).  Results
  * are bit-identical between the two tile heights. */
 int lhrs_gemm_set_bm144(int mode);
+/* kernel A/B tests only: fewest 64x128 tiles for which the small-tile GEMM takes 64x128 tiles instead of 64x64 (default 256) */
+int lhrs_gemm_set_small_thresh(int n);
 /* kernel A/B tests only: fewest 256x256 tiles for which lhrs_gemm_bf16_nt picks the big-tile kernel (default 128) */
 int lhrs_gemm_set_min_tiles(int n);
 /* live HIP-event timing of the 16-wave 256x256 GEMM launches, on their launch stream, for bench.py's roofline leg (gemm.hip):

@@ -1160,6 +1160,9 @@ static bool pick_144(int M, long tiles_n, int K, int K2, bool drop) {
   const long P = num_cus(), t256 = (long)cdiv(M, 256) * tiles_n, t144 = (long)cdiv(M, 144) * tiles_n;
   return (double)((t144 + P - 1) / P) * g_gemm_bm144_cost < (double)((t256 + P - 1) / P);
 }
+// fewest 64x128 tiles for which the 64x128 small-tile kernel is taken over the 64x64 one (A/B: lhrs_gemm_set_small_thresh)
+static int g_gemm_small_thresh = 256;
+extern "C" int lhrs_gemm_set_small_thresh(int n) { g_gemm_small_thresh = n; return 0; }
 static int g_gemm_min256 = 128;  // fewest 256x256 tiles (half a round of the 256 CUs) for which the big-tile kernels are chosen: 2184 x 4096 (144
                                  // tiles, the reference's micro-batch 8) runs 20 % faster there than on 576 small tiles; A/B: lhrs_gemm_set_min_tiles
 extern "C" int lhrs_gemm_set_min_tiles(int n) { g_gemm_min256 = n; return 0; }
@@ -1319,7 +1322,7 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
       }
     }
   } else if (big) LAUNCH_TILE(4, 4);
-  else if (t64x128 >= 256) LAUNCH_TILE(2, 4);
+  else if (t64x128 >= g_gemm_small_thresh) LAUNCH_TILE(2, 4);
   else LAUNCH_TILE(2, 2);
 #undef LAUNCH_TILE
   if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], s);
