@@ -296,7 +296,7 @@ def main():
     ap.add_argument("--stage", type=int, default=1, choices=[1, 2, 3],
                     help="1: projector-only + Adan (the headline metric, BASELINE configs[1..2]); 3: LoRA r=8 on q,k,v,o + AdamW, projector "
                          "frozen (BASELINE configs[3]); 2: LoRA r=128 on every linear + projector, AdamW (Config/multi_modal_stage2.yaml)")
-    ap.add_argument("--comm-dtype", default="bfloat16", choices=["float32", "bfloat16"],
+    ap.add_argument("--comm-dtype", default="float32", choices=["float32", "bfloat16"],
                     help="dtype of the gradient all-reduce (N > 1): bfloat16 = 160 MB per step at stage 1, what DeepSpeed bf16 ZeRO-2 moves (SURVEY §8e)")
     ap.add_argument("--bits", type=int, default=16, choices=[16, 8],
                     help="stages 2/3 only: 8 = frozen decoder linears in e4m3 (the reference's `bits: 8` base weights)")

@@ -16,6 +16,7 @@ Averaging is folded into the optimizer kernel (grad_scale = 1/world); the global
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -62,6 +63,22 @@ def bucket_ranges(pool):
     return [(k, first[k], ends[k]) for k in order]
 
 
+def merged_buckets(buckets, min_numel: int = 1 << 20):
+    """Greedy fold of the signal-ordered buckets: a bucket joins the one signalled right before it while that one is still smaller than
+    `min_numel` elements and the two are adjacent in the flat buffer; the fused range is issued at the LAST of its keys (the projector's
+    147 k-element `query` would otherwise be a collective of its own - here layer 0 waits the few microseconds for it; r = 8 LoRA layers of
+    262 k elements travel four at a time).  -> (buckets, skipped keys)."""
+    out, skipped = [], set()
+    for k, s, e in buckets:
+        if out and (out[-1][2] - out[-1][1] < min_numel or e - s < min_numel // 4) and (out[-1][2] == s or out[-1][1] == e):
+            pk, ps, pe = out[-1]
+            skipped.add(pk)
+            out[-1] = (k, min(ps, s), max(pe, e))
+        else:
+            out.append((k, s, e))
+    return out, skipped
+
+
 class GradReducer:
     """Bucketed sum all-reduce of ranges of ONE flat gradient buffer, launched as ranges become final.
 
@@ -69,14 +86,24 @@ class GradReducer:
     issued from a dedicated HIP stream that waits on an event recorded by the compute stream; on CPU tensors
     (gloo, used by the world_size-2 tests) the same code runs without streams."""
 
-    def __init__(self, flat_grad: torch.Tensor, buckets, process_group=None, comm_dtype=torch.float32):
-        self.flat, self.pg, self.comm_dtype = flat_grad, process_group, comm_dtype
-        self.buckets = {k: (s, e) for k, s, e in buckets}
+    def __init__(self, flat_grad: torch.Tensor, buckets, process_group=None, comm_dtype=torch.float32, mode: str = "bucketed"):
+        """mode "bucketed": one collective per bucket, issued when the backward signals it (small neighbours merged); "flat": ONE collective over
+        the whole buffer when the LAST bucket is signalled (no overlap with the remaining backward, one launch - SURVEY §2.2 C1)."""
+        self.flat, self.pg, self.comm_dtype, self.mode = flat_grad, process_group, comm_dtype, mode
+        if mode == "flat":
+            keys = [k for k, _, _ in buckets]
+            self.buckets = {keys[-1]: (min(s for _, s, _ in buckets), max(e for _, _, e in buckets))}
+            self.skip = set(keys[:-1])
+        else:
+            merged, self.skip = merged_buckets(list(buckets))
+            self.buckets = {k: (s, e) for k, s, e in merged}
         self.cuda = flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
         self.pending = []
 
     def ready(self, key: str) -> None:
+        if key in self.skip:
+            return  # travels with a later bucket
         s, e = self.buckets[key]
         buf = self.flat[s:e]
         if self.cuda:
@@ -143,7 +170,7 @@ def _pooler_wd_ranges(pool):
 class LHRSEngine:
     def __init__(self, model, optimizer: str = "adanp", lr: float = 2e-4, weight_decay: float = 0.0,
                  max_grad_norm: float = 0.3, betas=None, eps: float = 1e-8, process_group=None, comm_dtype=torch.float32,
-                 gradient_accumulation_steps: int = 1, broadcast_trainable: bool = True):
+                 gradient_accumulation_steps: int = 1, broadcast_trainable: bool = True, reduce_mode: Optional[str] = None):
         self.module = self.model = model
         self.pool = model.rgb_pooler
         self.opt_name = optimizer.lower()
@@ -190,7 +217,8 @@ class LHRSEngine:
         import os
         dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
         with_reducer = self.world > 1 or (dist_on and os.environ.get("LHRS_DP_SINGLE_RANK") == "1")
-        self.reducers = {st.name: GradReducer(st.grad, st.buckets, self.pg, comm_dtype) for st in self.stores} if with_reducer else {}
+        mode = reduce_mode or os.environ.get("LHRS_DP_REDUCE", "bucketed")   # "flat": one all-reduce per trainable store and step
+        self.reducers = {st.name: GradReducer(st.grad, st.buckets, self.pg, comm_dtype, mode) for st in self.stores} if with_reducer else {}
         if self.world > 1:
             self.sync_replicas(broadcast_trainable)
 

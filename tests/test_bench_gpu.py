@@ -71,5 +71,24 @@ def test_bench_gpus2_self_spawns_ranks():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
-    assert d["config"]["grad_allreduce"] == "bfloat16" and d["config"]["dist_backend"] == ("nccl" if two else "gloo")
+    assert d["config"]["grad_allreduce"] == "float32" and d["config"]["dist_backend"] == ("nccl" if two else "gloo")
     assert d["value"] > 0 and "cpu_baseline" not in d
+
+
+@pytest.mark.timeout(1500)
+def test_bench_gpus8_plumbing_on_a_shared_device():
+    """First contact of the 8-rank path before 8-GPU hardware exists: `python bench.py --gpus 8` self-spawns eight ranks that share this
+    box's one GPU over gloo (LHRS_SHARE_GPU=1: plumbing, not a measurement) - rendezvous on 127.0.0.1, per-rank seeds 322 + rank, the
+    rank-0 broadcast of the trainable masters and the replica checksum inside LHRSEngine.__init__, the bucketed fp32 all-reduce on the comm
+    stream, barrier + max-over-ranks timing, ONE rank-0 line with the whole-job rate (BASELINE configs[2], Script/train_stage1.sh:6-17)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(LHRS_SHARE_GPU="1", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--llama-layers", "1",
+                          "--micro-batch", "2"], capture_output=True, text=True, timeout=1400, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp8" and d["scaling"] == "weak"
+    assert d["config"]["dist_backend"] == "gloo" and d["config"]["grad_allreduce"] == "float32" and d["value"] > 0
+    assert "configs[2]" in d["config"]["workload"] and "cpu_baseline" not in d and "micro_batch_8" not in d

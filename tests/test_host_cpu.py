@@ -66,6 +66,13 @@ def test_bucket_ranges_cover_flat_buffer_in_backward_order():
     cover = sorted((s, e) for _, s, e in b)
     assert cover[0][0] == 0 and cover[-1][1] == pool.numel
     assert all(cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1))
+    from lhrs_bot_amd.engine import merged_buckets
+    m, skipped = merged_buckets(b)                             # the tiny `query` range rides with layer 0, issued when `query` is final
+    assert [k for k, _, _ in m] == ["out_proj", "5", "4", "3", "2", "1", "query"] and skipped == {"0"}
+    assert sorted((s, e) for _, s, e in m)[0] == (0, dict((k, e) for k, _, e in b)["0"])
+    lora = [(str(l), l * 262144, (l + 1) * 262144) for l in reversed(range(32))]      # r = 8 on q,k,v,o: 262 k elements per layer
+    ml, sk = merged_buckets(lora)
+    assert len(ml) == 8 and all(e - s == 4 * 262144 for _, s, e in ml) and len(sk) == 24 and ml[-1][0] == "0"
 
 
 WORKER = r'''
@@ -77,12 +84,13 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 pool = AttnPooler(device="cpu", num_layers=2)
 buckets = bucket_ranges(pool)
-for comm_dtype in (torch.float32, torch.bfloat16):
+for comm_dtype, mode in ((torch.float32, "bucketed"), (torch.bfloat16, "bucketed"), (torch.float32, "flat")):
     g = torch.Generator().manual_seed(100 + rank)
     pool.grad.copy_(torch.randn(pool.numel, generator=g))
-    red = GradReducer(pool.grad, buckets, None, comm_dtype)
+    red = GradReducer(pool.grad, buckets, None, comm_dtype, mode)
     for key, _, _ in buckets:            # the order AttnPooler.backward reports ranges
         red.ready(key)
+    assert len(red.pending) == (1 if mode == "flat" else len(buckets) - 1)   # `query` (147 k elements) travels with layer 0
     red.finish()
     others = [torch.randn(pool.numel, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
     want = sum(o.to(comm_dtype).float() for o in others) if comm_dtype != torch.float32 else sum(others)
