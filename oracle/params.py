@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY - deterministic synthetic parameters for the LHRS-Bot hot path.
 
 No weights or tokenizer files exist offline, so parity runs use seeded random parameters in the ENGINE's own
-layout (see DESIGN.md "Parameter layout").  `make_params` is machine-independent for a given torch build
+layout.  `make_params` is machine-independent for a given torch build
 (per-tensor CPU generators), so the golden fixtures only have to store inputs and expected outputs; the
 converters below map the layout onto the state-dict keys of the reference modules and are used by
 tests/golden/make_golden.py to load the very same numbers into the imported reference.

@@ -38,7 +38,7 @@ if sys.argv[1] == "traffic":
                                       "wide streaming read on gfx950, WRITE_SIZE the written bytes - so reads are doubled, writes taken as is"}
     res["traffic_bytes_per_launch"] = int(2 * res["fetch_size_kb_mean"] * 1024 + res["write_size_kb_mean"] * 1024)
     res["note"] = ("memory-side L2 traffic, Infinity-Cache hits included (A + B of a launch fit the 256 MB cache): each XCD's 4 MB L2 streams 12 two-MB operand panels per "
-                   "round of 32 tiles and cannot keep them for the next round - the floor of any tile order at 4 MB per XCD is ~2.5x the algorithmic bytes (DESIGN.md §4)")
+                   "round of 32 tiles and cannot keep them for the next round - the floor of any tile order at 4 MB per XCD is ~2.5x the algorithmic bytes (docs/design_notes_r01_r02.md §4)")
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res)[:600])
 else:
