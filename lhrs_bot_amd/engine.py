@@ -223,38 +223,48 @@ class LHRSEngine:
             self.sync_replicas(broadcast_trainable)
 
     # ------------------------------------------------------------------ replica consistency at start-up
+    # dict keys that hold tensors DERIVED from another entry of the same dict (transposed copies, decode re-tilings, e4m3 copies): skipped by
+    # the replica checksum because the tensor they come from is already in it.  An explicit table - a frozen tensor whose name merely ends
+    # in one of these letters is NOT skipped
+    DERIVED_KEYS = frozenset(b + suf for b in ("qkv_w", "o_w", "gu_w", "down_w") for suf in ("T", "p", "8", "8s", "8p", "T8", "T8s")) | \
+        frozenset(("lm_head8", "lm_head8s", "lm_head8p", "lm_headp"))
+
     def replica_checksums(self) -> torch.Tensor:
-        """fp64 [sum, sum of squares] of every frozen tensor group (ViT, LLaMA) and of every trainable master: what must be equal
-        on all ranks before the first step.  Pure reductions on the device (the LLaMA pass reads 13.5 GB once: ~3 ms)."""
+        """fp64 [sum, sum of squares, position-weighted sum] of every frozen tensor group (ViT, LLaMA) and of every trainable master: what
+        must be equal on all ranks before the first step.  The third term (element i of a tensor weighted by 1 + (i mod 8191) / 8191) makes
+        the check sensitive to permutations.  Pure reductions on the device (the LLaMA pass reads 13.5 GB once)."""
         dev = self.pool.device
+        derived = self.DERIVED_KEYS
 
         def walk(o):
             if torch.is_tensor(o):
                 yield o
             elif isinstance(o, dict):
                 for k in sorted(o, key=str):
-                    if not (isinstance(k, str) and k.endswith("T")):  # transposed copies are derived from the tensors already visited
+                    if k not in derived:
                         yield from walk(o[k])
             elif isinstance(o, (list, tuple)):
                 for v in o:
                     yield from walk(v)
 
+        ramp = 1.0 + torch.arange(8191, device=dev, dtype=torch.float64) / 8191.0
+
+        def three(c):
+            c = c.reshape(-1).double()
+            n = c.numel()
+            w = ramp.repeat((n + 8190) // 8191)[:n]
+            return torch.stack((c.sum(), (c * c).sum(), (c * w).sum()))
+
         rows = []
         for part in (getattr(getattr(self.model, "rgb", None), "p", None), getattr(getattr(self.model, "text", None), "p", None)):
-            acc = torch.zeros(2, dtype=torch.float64, device=dev)
+            acc = torch.zeros(3, dtype=torch.float64, device=dev)
             for t in walk(part or {}):
                 if t.is_floating_point():
-                    f = t.double() if t.numel() <= (1 << 24) else None
-                    if f is None:  # large tensors: chunked so the fp64 temporary stays small
-                        for c in t.reshape(-1).split(1 << 24):
-                            c = c.double()
-                            acc += torch.stack((c.sum(), (c * c).sum()))
-                    else:
-                        acc += torch.stack((f.sum(), (f * f).sum()))
+                    for c in t.reshape(-1).split(8191 * 2048):   # chunked so the fp64 temporaries stay small; chunk size keeps the ramp aligned
+                        acc += three(c)
             rows.append(acc)
         for st in self.stores:
-            f = st.master.double()
-            rows.append(torch.stack((f.sum(), (f * f).sum())))
+            rows.append(three(st.master))
         return torch.stack(rows)
 
     def sync_replicas(self, broadcast_trainable: bool = True) -> None:
@@ -269,6 +279,9 @@ class LHRSEngine:
                 hk.cast_f32_to_bf16(st.master, st.shadow) if st.master.is_cuda else st.shadow.copy_(st.master)
                 st.refresh()
         cs = self.replica_checksums()
+        if not bool(torch.isfinite(cs).all()):
+            raise RuntimeError("non-finite values in this rank's frozen weights or trainable masters (replica checksum is NaN / inf): "
+                               "the weights are broken before any rank comparison")
         lo, hi = cs.clone(), cs.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.pg)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.pg)

@@ -22,7 +22,9 @@ SPLIT_PART = (256, 256, 256)   # common_arch.py:105
 
 import os as _os
 
-_DW_TN = _os.environ.get("LHRS_DW_TRANSPOSED", "0") != "1"
+def _dw_tn_enabled() -> bool:
+    """LHRS_DW_TRANSPOSED=1 forces the round-1 path (transposed copies + NT split-K GEMM); read at call time so tests can flip it."""
+    return _os.environ.get("LHRS_DW_TRANSPOSED", "0") != "1"
 
 
 class AttnPooler:
@@ -206,7 +208,11 @@ class AttnPooler:
         """grad[name] (rows slice) = dy^T @ x, straight from the token-major operands (lhrs_gemm_tn_f32: transposing LDS reads, token range
         split into f32 slabs, ordered sum); LHRS_DW_TRANSPOSED=1 takes the round-1 path (transposed copies + NT split-K GEMM)."""
         g = self.g[name] if rows is None else self.g[name][rows[0]: rows[1]]
-        if _DW_TN and g.shape[0] % 128 == 0 and g.shape[1] % 128 == 0 and dy.stride(1) == 1 and x.stride(1) == 1:
+        # lhrs_gemm_tn_f32 wants 16-B rows on both operands and on the output slice; anything else (a sliced / offset operand) takes the
+        # transposed split-K path instead of failing inside the backward
+        tn_ok = (g.shape[0] % 128 == 0 and g.shape[1] % 128 == 0 and dy.stride(1) == 1 and x.stride(1) == 1 and dy.stride(0) % 8 == 0 and
+                 x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0 and g.stride(1) == 1)
+        if _dw_tn_enabled() and tn_ok:
             hk.gemm_tn_f32(dy, x, g)
             return
         Mp = hk.pad64(dy.shape[0])

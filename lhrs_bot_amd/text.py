@@ -154,7 +154,9 @@ class LoraStore:
         return (self.drop_seed + self.drop_epoch * 0x85EBCA77 + (l * 8 + gid) * 0x9E3779B1) & 0xFFFFFFFF
 
     def refresh(self):
-        """bf16 shadow + transposed operands after a load / optimizer step (all 8 transposes of every layer in one launch)."""
+        """bf16 shadow + transposed operands after a load / optimizer step (all 8 transposes of every layer in one launch).  Bumps `version`:
+        whatever was derived from the adapters (generate()'s merged decode weights) is stale from here on."""
+        self.version = getattr(self, "version", 0) + 1
         hk.cast_f32_to_bf16(self.master, self.shadow)
         if getattr(self, "_bt", None) is None:
             pairs = []
@@ -260,7 +262,20 @@ class TextModal:
                 W = L[wname[gname]]
                 hk.gemm_nt(lo.derived[(li, gname, "Bfull")], lo.derived[(li, gname, "AT")], out=W, residual=W, alpha=lo.s)
                 L[wname[gname] + "T"] = hk.transpose(W)
-        self.lora = None
+            self._drop_derived(L)
+        requant = self.base8
+        self.lora, self._merged_cache, self.base8 = None, None, False
+        if requant:
+            self.quantize_base(8)   # the 8-bit base is a function of the (now merged) weights
+
+    DERIVED_SUFFIXES = ("p", "8", "8s", "8p")   # decode re-tilings and e4m3 copies of a weight `<name>` / `<name>T`, rebuilt lazily from it
+
+    def _drop_derived(self, L) -> None:
+        """Forget every tensor that was computed FROM a decoder weight of layer dict `L` (decode re-tilings, e4m3 copies): after the weight
+        changes in place (merge_lora, a checkpoint load) they are stale; their builders re-create them on next use."""
+        for base in ("qkv_w", "o_w", "gu_w", "down_w", "qkv_wT", "o_wT", "gu_wT", "down_wT"):
+            for suf in self.DERIVED_SUFFIXES:
+                L.pop(base + suf, None)
 
     def init_random(self, seed: int = 0) -> None:
         """Random-init LLaMA-2-7B shapes, N(0, 0.02) (HF initializer_range) - no weights exist offline."""
@@ -717,11 +732,13 @@ class TextModal:
         return s
 
     def _lora_merged_layers(self):
-        """Per-layer weight dicts with the CURRENT adapters folded in (W + (alpha/r) B A as one GEMM per fused group, like `merge_lora`)
-        WITHOUT touching the frozen base: generate() with un-merged adapters (stages >= 1 with a TextLoRA/ loaded or being trained)
-        must answer with the adapted model, as peft's wrapped forward does.  Only the tensors the inference path reads are produced
-        (+13.5 GB for the duration of the call at all-linear targets); decode-only repacks are rebuilt from them on demand."""
+        """Decoder layers with W + s B A in place of every adapted weight (copies; the base stays untouched) for generate() with un-merged
+        adapters.  Cached together with the decode re-tilings / e4m3 copies that `_decode_session` hangs onto the dicts, keyed on the adapter
+        store's `version` (bumped by every optimizer step and load): an evaluation loop between two optimizer steps merges ONCE."""
         lo = self.lora
+        cache = getattr(self, "_merged_cache", None)
+        if cache is not None and cache[0] == (id(lo), lo.version):
+            return cache[1]
         wname = {"qkv": "qkv_w", "o": "o_w", "gu": "gu_w", "down": "down_w"}
         out = []
         for li, L in enumerate(self.p["layers"]):
@@ -730,6 +747,7 @@ class TextModal:
                 W = L[wname[gname]]
                 M[wname[gname]] = hk.gemm_nt(lo.derived[(li, gname, "Bfull")], lo.derived[(li, gname, "AT")], residual=W, alpha=lo.s)
             out.append(M)
+        self._merged_cache = ((id(lo), lo.version), out)
         return out
 
     @torch.no_grad()
