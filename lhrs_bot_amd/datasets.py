@@ -11,7 +11,8 @@ crosses PCIe; a worker never touches the GPU.
 
 Directory contract (unchanged): `<root>/<NAME>_Image/` holds the pictures of corpus NAME and `<root>/<NAME>.json` its annotations;
 the annotation schema is chosen by NAME exactly as the reference does (table `_CAPTION_SCHEMAS` / `_instruct_item`).
-The webdataset loader (RS5M tar shards) needs `webdataset`, which the image lacks: not built (NotImplementedError with the reason).
+RS5M tar shards (the reference reads them through `webdataset`, absent here) are read by `RS5MDataset` on `tarfile` with the same
+pipeline stages and defaults.
 """
 from __future__ import annotations
 
@@ -333,6 +334,190 @@ class InfiniteSampler(torch.utils.data.Sampler):
         pass
 
 
+# ------------------------------------------------------------------------------------------------ RS5M tar shards (stage 1's real corpus)
+# The reference streams RS5M through the `webdataset` package (cap_dataset.py:649-775 `RS5MDataset`, build_loader.py:110-160).  That package is
+# not in this image; the format it reads is plain POSIX tar, so the pipeline is restated on `tarfile` with the same stages and the same
+# defaults: brace-expanded shard list -> per-epoch shard shuffle (seed 322 + epoch) -> split by rank, then by DataLoader worker -> tar
+# members grouped into samples by the key in front of the first dot (no-throw grouping, cap_dataset.py:587-613) -> sample shuffle buffer ->
+# decode (image bytes -> pixels, caption bytes -> one question/answer turn, tokenised) -> batches of exactly `batch_size` (partial=False).
+_SHARD_SHUFFLE_SIZE, _SHARD_SHUFFLE_INITIAL = 2000, 500          # cap_dataset.py:30-33
+_SAMPLE_SHUFFLE_SIZE, _SAMPLE_SHUFFLE_INITIAL = 5000, 1000
+RS5M_NUM_SAMPLES = 5070186                                         # build_loader.py:131
+
+
+def expand_braces(pattern: str) -> List[str]:
+    """`{a,b}` alternatives and `{0000..0031}` zero-padded integer ranges, nested left to right (what braceexpand / wds.shardlists.expand_urls
+    do for the reference's `{pub11,rs3}-train-{0000..0031}.tar`)."""
+    m = re.search(r"\{([^{}]*)\}", pattern)
+    if not m:
+        return [pattern]
+    body, out = m.group(1), []
+    rng = re.fullmatch(r"(-?\d+)\.\.(-?\d+)", body)
+    if rng:
+        a, b = rng.group(1), rng.group(2)
+        width = max(len(a), len(b)) if (a.startswith("0") and len(a) > 1) or (b.startswith("0") and len(b) > 1) else 0
+        step = 1 if int(b) >= int(a) else -1
+        alts = [str(v).zfill(width) for v in range(int(a), int(b) + step, step)]
+    else:
+        alts = body.split(",")
+    for alt in alts:
+        out += expand_braces(pattern[: m.start()] + alt + pattern[m.end():])
+    return out
+
+
+def _shuffle_buffer(src: Iterator, bufsize: int, initial: int, rng: random.Random) -> Iterator:
+    """webdataset's `_shuffle`: keep up to `bufsize` items, start yielding once `initial` are buffered, each yield swaps a random slot out."""
+    initial = min(initial, bufsize)
+    buf: List = []
+    for item in src:
+        buf.append(item)
+        if len(buf) < bufsize:
+            try:
+                buf.append(next(src))
+            except StopIteration:
+                pass
+        if len(buf) >= initial:
+            k = rng.randint(0, len(buf) - 1)
+            buf[k], buf[-1] = buf[-1], buf[k]
+            yield buf.pop()
+    while buf:
+        k = rng.randint(0, len(buf) - 1)
+        buf[k], buf[-1] = buf[-1], buf[k]
+        yield buf.pop()
+
+
+def tar_samples(path: str, suffixes=("img_content", "img_name", "caption")) -> Iterator[Dict]:
+    """Members of one tar shard grouped into samples: `<key>.<suffix>` -> {"__key__": key, suffix: bytes}; a sample ends when the key changes
+    or a suffix repeats (group_by_keys_nothrow, cap_dataset.py:587-613); samples need a key and at least one field; unreadable shards /
+    members are logged and skipped (log_and_continue)."""
+    import tarfile
+    try:
+        tf = tarfile.open(path, "r|*")
+    except (OSError, tarfile.TarError) as e:
+        logger.warning("Handling shard error (%r). Ignoring.", e)
+        return
+    cur: Optional[Dict] = None
+    try:
+        for member in tf:
+            if not member.isreg():
+                continue
+            base = member.name.rsplit("/", 1)[-1]
+            if "." not in base or base.startswith("."):
+                continue
+            prefix_dir = member.name[: len(member.name) - len(base)]
+            key, suffix = base.split(".", 1)
+            key, suffix = prefix_dir + key, suffix.lower()
+            if cur is None or key != cur["__key__"] or suffix in cur:
+                if cur is not None and len(cur) > 2:
+                    yield cur
+                cur = {"__key__": key, "__url__": path}
+            if suffixes is None or suffix in suffixes:
+                fh = tf.extractfile(member)
+                cur[suffix] = fh.read() if fh is not None else b""
+    except (OSError, tarfile.TarError, EOFError) as e:
+        logger.warning("Handling shard error (%r). Ignoring.", e)
+    finally:
+        tf.close()
+    if cur is not None and len(cur) > 2:
+        yield cur
+
+
+class RS5MDataset(torch.utils.data.IterableDataset):
+    """RS5M image / caption tar shards `<root>/{pub11,rs3}-train-{0000..0031}.tar` as an iterable of stage-1 samples {"rgb", "text"} (or of
+    collated batches when `batch_size` is given, as the reference's `wds.batched(batch_size, partial=False)` yields them).  A sample is
+    the members `<key>.img_content` (encoded picture), `<key>.img_name`, `<key>.caption` (UTF-8 text)."""
+
+    URL = "{pub11,rs3}-train-{0000..0031}.tar"
+
+    def __init__(self, root=".data/RS5M", transform=None, tokenizer=None, batch_size: Optional[int] = None, rank: Optional[int] = None,
+                 world_size: Optional[int] = None, seed: int = 322, shards: Optional[List[str]] = None, **kwargs):
+        self.tune_im_start = kwargs.pop("tune_im_start", False)
+        self.prompt_type = kwargs.pop("prompt_type", "llava_llama_2")
+        self.transform, self.tokenizer, self.batch_size, self.seed = transform, tokenizer, batch_size, seed
+        self.url = str(Path(root) / self.URL)
+        self.shards = list(shards) if shards is not None else expand_braces(self.url)
+        dist = torch.distributed
+        on = dist.is_available() and dist.is_initialized()
+        self.rank = rank if rank is not None else (dist.get_rank() if on else 0)
+        self.world = world_size if world_size is not None else (dist.get_world_size() if on else 1)
+        self.epoch = -1
+        self.collate = DataCollatorForSupervisedDataset(tokenizer=tokenizer) if batch_size else None
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = int(epoch) - 1   # __iter__ advances it: the reference's SharedEpoch / detshuffle2 contract
+
+    def _decode(self, s: Dict) -> Optional[Dict]:
+        import io
+        from PIL import Image
+        try:
+            img = Image.open(io.BytesIO(s["img_content"])).convert("RGB")
+            caption = s["caption"].decode("utf-8")
+        except Exception as e:  # noqa: BLE001 - a broken member is skipped like the reference's handler does
+            logger.warning("Handling sample error (%r). Ignoring.", e)
+            return None
+        if self.transform is None:
+            rgb = img
+        elif isinstance(self.transform, DeviceImageTransform):
+            import numpy as np
+            rgb = torch.from_numpy(np.array(img, copy=True))
+        else:
+            rgb = self.transform(img)
+        conversation_lib.default_conversation = conversation_lib.conv_templates[self.prompt_type]
+        turn = [{"Question": random.choice(CaptionDatasetVQA.QUESTION_TEMPLACES), "Answer": pre_caption(caption)}]
+        return _tokenised(dict(rgb=rgb, text=turn), self.tokenizer, self.tune_im_start)
+
+    def my_shards(self) -> List[str]:
+        """This epoch's shards of THIS rank and THIS DataLoader worker: shuffled identically everywhere (seed + epoch), then every
+        world-th shard from `rank` (wds.split_by_node), of those every num_workers-th from the worker id (wds.split_by_worker)."""
+        rng = random.Random(self.seed + self.epoch)
+        order = list(_shuffle_buffer(iter(self.shards), _SHARD_SHUFFLE_SIZE, _SHARD_SHUFFLE_INITIAL, rng))
+        mine = order[self.rank::self.world]
+        info = torch.utils.data.get_worker_info()
+        return mine if info is None else mine[info.id::info.num_workers]
+
+    def __iter__(self):
+        self.epoch += 1
+        info = torch.utils.data.get_worker_info()
+        rng = random.Random((info.seed if info is not None else self.seed * 7919 + self.rank) + self.epoch)
+        raw = itertools.chain.from_iterable(tar_samples(p) for p in self.my_shards())
+        decoded = (d for d in (self._decode(s) for s in _shuffle_buffer(raw, _SAMPLE_SHUFFLE_SIZE, _SAMPLE_SHUFFLE_INITIAL, rng)
+                               if "img_content" in s and "caption" in s) if d is not None)
+        if not self.batch_size:
+            yield from decoded
+            return
+        batch: List[Dict] = []
+        for d in decoded:
+            batch.append(d)
+            if len(batch) == self.batch_size:
+                yield self.collate(batch)
+                batch = []                       # partial=False: a trailing short batch is dropped
+
+
+def build_rs5m_loader(config, transform, **kwargs):
+    """build_loader.py:110-160 for `"RS5M" in config.data_path`: batches are formed inside the dataset (per worker), the loader only
+    multiplexes workers; `num_batches` / `num_samples` / `length` follow the reference's rounding over the nominal 5 070 186 samples."""
+    import math
+    from torch.utils.data import DataLoader
+    world = int(config.get("world_size", 1) or 1)
+    workers = int(config.get("workers", 0))
+    bs = int(config["batch_size"])
+    ds = RS5MDataset(root=str(config["data_path"]), transform=transform, batch_size=bs, **kwargs)
+    have = sum(Path(p).exists() for p in ds.shards)
+    if have == 0:
+        raise FileNotFoundError(f"no RS5M shard found under {config['data_path']} (expected {ds.url})")
+    ds.shards = [p for p in ds.shards if Path(p).exists()]
+    assert len(ds.shards) >= max(1, workers) * world, "number of shards must be >= total workers"
+    loader = DataLoader(ds, batch_size=None, shuffle=False, num_workers=workers, persistent_workers=workers > 0)
+    global_batch = bs * world
+    num_batches = math.ceil(RS5M_NUM_SAMPLES / global_batch)
+    nw = max(1, workers)
+    num_batches = math.ceil(num_batches / nw) * nw
+    loader.num_batches, loader.num_samples = num_batches, num_batches * global_batch
+    loader.length = math.ceil(loader.num_samples / global_batch)
+    return loader
+
+
+
 def build_vlp_transform(config, is_train: bool = True):
     """build_transform.py:43-45: ViT archs use the CLIP image processor - here the device one.  (The convolutional archs' timm /
     torchvision augmentations belong to the dropped Swin / ResNet branches.)"""
@@ -363,10 +548,9 @@ def build_loader_hepler(config, dataset, collate_fn=None, is_train: bool = True)
 def build_vlp_loader(config, is_train: bool = True, **kwargs):
     transform = build_vlp_transform(config, is_train=is_train)
     root = str(config["data_path"])
-    if "RS5M" in root:
-        raise NotImplementedError("RS5M tar shards need `webdataset`, which this image does not have; point --data-path at a "
-                                  "directory of <NAME>_Image/ + <NAME>.json corpora")
     stage = int(config.get("stage", 1))
+    if is_train and stage == 1 and "RS5M" in root:
+        return build_rs5m_loader(config, transform, **kwargs)
     if is_train and stage == 1:
         dataset = CaptionDatasetVQA(root=root, transform=transform, **kwargs)
     elif is_train:

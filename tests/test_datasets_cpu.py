@@ -84,7 +84,7 @@ def test_build_loader_stage1_batches_uint8_pixels_and_samplers(tmp_path):
     smp = DS.InfiniteSampler(ds, shuffle=True, seed=5)
     first = [i for _, i in zip(range(12), iter(smp))]
     assert sorted(first[:6]) == list(range(6)) and sorted(first[6:]) == list(range(6))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(FileNotFoundError, match="no RS5M shard"):       # "RS5M" in the path selects the tar-shard loader (build_loader.py:66-68)
         DS.build_loader(ConfigDict(dict(data_path="/x/RS5M", stage=1, batch_size=2, rgb_vision={"arch": "vit_large"})), mode="pretrain", tokenizer=tok)
 
 
@@ -126,3 +126,68 @@ def test_weighted_stage3_loader_and_sampler_wrapper(tmp_path):
     for b in batches:
         has_img = b["input_ids"].eq(-200).any(dim=1)
         assert torch.equal(has_img, b["valid_image"])
+
+
+# ------------------------------------------------------------------------------------------------ RS5M tar shards
+def _make_rs5m_shards(root, n_shards=4, per_shard=5):
+    """`<root>/{pub11,rs3}-train-000i.tar` with the member naming of RS5M (`<key>.img_content`, `<key>.img_name`, `<key>.caption`)."""
+    import io
+    import tarfile
+    from PIL import Image
+    os.makedirs(root, exist_ok=True)
+    truth = {}
+    for src in ("pub11", "rs3"):
+        for s in range(n_shards // 2):
+            path = os.path.join(root, f"{src}-train-{s:04d}.tar")
+            with tarfile.open(path, "w") as tf:
+                for i in range(per_shard):
+                    key = f"{src}_{s}_{i:03d}"
+                    buf = io.BytesIO()
+                    Image.new("RGB", (8 + i, 6 + s), color=(10 * i, 20 * s, 7)).save(buf, format="PNG")
+                    cap = f"An Aerial (view) of AREA {src} {s} {i}!"
+                    members = [(key + ".img_content", buf.getvalue()), (key + ".img_name", (key + ".png").encode()), (key + ".caption", cap.encode())]
+                    if i == 2:   # a stray member without the grouping key pattern and a sample without caption: both are skipped, not errors
+                        members.append((f"{key}_nocap.img_content", buf.getvalue()))
+                    for name, data in members:
+                        ti = tarfile.TarInfo(name)
+                        ti.size = len(data)
+                        tf.addfile(ti, io.BytesIO(data))
+                    truth[key] = (8 + i, 6 + s, DS.pre_caption(cap))
+    return truth
+
+
+def test_rs5m_tar_shards_grouping_split_and_batches(tmp_path):
+    """RS5MDataset (cap_dataset.py:649-775 restated on `tarfile`): brace expansion of the shard pattern, key grouping, every sample of
+    every shard exactly once per epoch across (rank, worker) splits, captions normalised and tokenised as a one-turn conversation about
+    the image, batches of exactly `batch_size` through the supervised collator (partial batches dropped)."""
+    root = str(tmp_path / "RS5M")
+    truth = _make_rs5m_shards(root)
+    assert DS.expand_braces("x/{pub11,rs3}-train-{0000..0031}.tar")[33] == "x/rs3-train-0001.tar"
+    one = list(DS.tar_samples(os.path.join(root, "pub11-train-0000.tar")))
+    assert [s["__key__"] for s in one][:3] == ["pub11_0_000", "pub11_0_001", "pub11_0_002"] and set(one[0]) == {"__key__", "__url__", "img_content", "img_name", "caption"}
+    tok = DC.ToyTok()
+    shards = [os.path.join(root, f"{s}-train-{i:04d}.tar") for s in ("pub11", "rs3") for i in range(2)]
+    seen = []
+    for rank in range(2):
+        ds = DS.RS5MDataset(root=root, transform=None, tokenizer=tok, prompt_type="plain", rank=rank, world_size=2, shards=shards)
+        random.seed(5)
+        rows = list(ds)
+        assert len(ds.my_shards()) == 2
+        for r in rows:
+            w, h = r["rgb"].size
+            ids = r["text"]["input_ids"].tolist()
+            assert ids[0] == tok.bos_token_id and ids[1] == -200 and r["text"]["labels"].tolist()[:2] == [-100, -100]
+            seen.append((w, h))
+    assert sorted(seen) == sorted((w, h) for w, h, _ in truth.values())          # 20 samples, each once, the caption-less member dropped
+    ds = DS.RS5MDataset(root=root, transform=lambda im: torch.zeros(3, 4, 4), tokenizer=tok, prompt_type="plain", batch_size=3, rank=0, world_size=1, shards=shards)
+    batches = list(ds)
+    assert len(batches) == 20 // 3 and all(b["rgb"].shape == (3, 3, 4, 4) and b["input_ids"].shape[0] == 3 for b in batches)
+    e0 = [b["input_ids"].tolist() for b in batches]
+    e1 = [b["input_ids"].tolist() for b in ds]                                        # next epoch: another shard / sample order
+    assert sorted(map(str, sum(e0, []))) != [] and e0 != e1
+    from lhrs_bot_amd.trainer import ConfigDict
+    cfg = ConfigDict(dict(data_path=root, batch_size=2, workers=0, world_size=1, stage=1))
+    loader = DS.build_rs5m_loader(cfg, lambda im: torch.zeros(3, 4, 4), tokenizer=tok, prompt_type="plain")
+    assert loader.num_batches == -(-DS.RS5M_NUM_SAMPLES // 2) and len(loader.dataset.shards) == 4
+    b = next(iter(loader))
+    assert set(b) >= {"rgb", "input_ids", "labels", "attention_mask"} and b["input_ids"].shape[0] == 2
