@@ -82,7 +82,7 @@ def cpu_baseline(S: int, layers: int = 32):
         loss.backward()
         dt = time.perf_counter() - t0
         zero()
-        return dt, float(loss)
+        return dt, float(loss.detach())
 
     one_step(1, 34, layers=1)                       # warm-up (thread pool, allocator): not timed
     T_head = S - 143
