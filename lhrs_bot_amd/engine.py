@@ -247,24 +247,23 @@ class LHRSEngine:
                 for v in o:
                     yield from walk(v)
 
-        ramp = 1.0 + torch.arange(8191, device=dev, dtype=torch.float64) / 8191.0
+        CH = 8191 * 2048                                     # chunk: a multiple of the ramp period, so every chunk sees the same weights
+        ramp = (1.0 + torch.arange(8191, device=dev, dtype=torch.float64) / 8191.0).repeat(2048)
 
         def three(c):
             c = c.reshape(-1).double()
-            n = c.numel()
-            w = ramp.repeat((n + 8190) // 8191)[:n]
-            return torch.stack((c.sum(), (c * c).sum(), (c * w).sum()))
+            return torch.stack((c.sum(), (c * c).sum(), (c * ramp[: c.numel()]).sum()))
 
         rows = []
         for part in (getattr(getattr(self.model, "rgb", None), "p", None), getattr(getattr(self.model, "text", None), "p", None)):
             acc = torch.zeros(3, dtype=torch.float64, device=dev)
             for t in walk(part or {}):
                 if t.is_floating_point():
-                    for c in t.reshape(-1).split(8191 * 2048):   # chunked so the fp64 temporaries stay small; chunk size keeps the ramp aligned
+                    for c in t.reshape(-1).split(CH):            # chunked so the fp64 temporaries stay small
                         acc += three(c)
             rows.append(acc)
         for st in self.stores:
-            rows.append(three(st.master))
+            rows.append(sum(three(c) for c in st.master.reshape(-1).split(CH)))
         return torch.stack(rows)
 
     def sync_replicas(self, broadcast_trainable: bool = True) -> None:
