@@ -816,6 +816,12 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
+// I8 = true: the same kernel on LLM.int8 operands (int8.hip; the reference's `bits: 8` base, text_modal.py:91-131 -> bitsandbytes MatMul8bitLt):
+// a lane's 32 k-bytes feed TWO v_mfma_i32_32x32x32_i8 (bytes [0,16) and [16,32): both operands are read with the same addressing, so which k
+// a byte slot holds does not matter) into int32 accumulators - exact -, converted to f32 once the 8-bit stages are done; the per-row factors
+// sa[m] = absmax / 127 and sb[n] = absmax / 127 then turn them into real units, and the optional bf16 stages behind them carry the 16-bit
+// outlier-column product (and the LoRA update) on the same accumulators.
+template <bool I8>
 __global__ __launch_bounds__(512, 2) void gemm_fp8_256_kernel(GemmArgs g) {
   constexpr int BM = 256, BN = 256, BKB = 128;  // bytes (= k) per stage row
   constexpr int A_BYTES = BM * BKB, STAGE = A_BYTES + BN * BKB;
@@ -883,8 +889,18 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256_kernel(GemmArgs g) {
     const i32x4 hi_ = *reinterpret_cast<lds4_t>((size_t)((addr1) + (off)));                                          \
     dst = i32x8{lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]};                                     \
   } while (0)
+  typedef __attribute__((ext_vector_type(16))) int i32x16_t;
 #define MF8(A_, B_, mi, ni)                                                                                          \
-  acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B_[ni], A_[mi], acc[mi][ni], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F); \
+  if constexpr (I8) {                                                                                                \
+    i32x16_t c_ = __builtin_bit_cast(i32x16_t, acc[mi][ni]);                                                         \
+    c_ = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_shufflevector(B_[ni], B_[ni], 0, 1, 2, 3),                  \
+                                               __builtin_shufflevector(A_[mi], A_[mi], 0, 1, 2, 3), c_, 0, 0, 0);   \
+    c_ = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_shufflevector(B_[ni], B_[ni], 4, 5, 6, 7),                  \
+                                               __builtin_shufflevector(A_[mi], A_[mi], 4, 5, 6, 7), c_, 0, 0, 0);   \
+    acc[mi][ni] = __builtin_bit_cast(f32x16, c_);                                                                    \
+  } else {                                                                                                           \
+    acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B_[ni], A_[mi], acc[mi][ni], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F); \
+  }                                                                                                                  \
   __builtin_amdgcn_sched_barrier(0);
 #define SB8 __builtin_amdgcn_sched_barrier(0);
   // one block: 8 MFMAs (64 k); fillers: the 6 fragments (12 reads) of the next block and up to 8 DMA pieces of stage kd
@@ -936,6 +952,16 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256_kernel(GemmArgs g) {
 #undef MF8
 #undef RD8
 
+  if constexpr (I8) {  // int32 sums -> f32 (exact below 2^24; |sum| <= 127 * 127 * K stays far inside f32's range, the rounding is 2^-24 relative)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const i32x16_t c_ = __builtin_bit_cast(i32x16_t, acc[mi][ni]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = (float)c_[r];
+      }
+  }
   bool scaled = false;
   if (nk_all > nk) {
     // ---- fused LoRA pair: bring the e4m3 sums to real units, then keep accumulating bf16 products (C layout is dtype-independent)
@@ -1600,14 +1626,14 @@ __global__ __launch_bounds__(256) void gemm_fp8_small_kernel(GemmArgs g) {
 // (lhrs_quant_fp8_rows).  K % 128 == 0, N % 8 == 0; lda / ldb in BYTES (>= K, multiples of 16).
 static int gemm_fp8_launch(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, const void* A2, int lda2,
                            const void* B2, int ldb2, int K2, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
-                           float alpha, void* stream) {
+                           float alpha, void* stream, bool i8 = false) {
   LHRS_REQUIRE(M > 0 && N > 0 && K >= 256 && K % 128 == 0, "gemm_fp8: M=%d N=%d K=%d (K %% 128 == 0, K >= 256)", M, N, K);
   LHRS_REQUIRE(lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K && sa && sb, "gemm_fp8: lda=%ld ldb=%ld", lda, ldb);
   LHRS_REQUIRE(N % 8 == 0 && ldc % 8 == 0 && ldc >= N && (residual == nullptr || ldr % 8 == 0), "gemm_fp8: N=%d ldc=%d ldr=%d", N, ldc, ldr);
   LHRS_REQUIRE(K2 == 0 || (A2 && B2 && K2 % 64 == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && lda2 >= K2 && ldb2 >= K2),
                "gemm_fp8: bad bf16 pair (K2=%d lda2=%d ldb2=%d)", K2, lda2, ldb2);
   // tail-row rule (see gemm_launch): the tile rows that spill over the last full round of the 256 CUs go to the small-tile kernel
-  if (t_split_ok && g_gemm_tail_split) {
+  if (!i8 && t_split_ok && g_gemm_tail_split) {   // (the small-tile sibling exists for e4m3 only)
     const int tm = cdiv(M, 256), tn = cdiv(N, 256);
     const long T = (long)tm * tn, rounds = (T + 255) / 256, full = T / 256;
     const int tm_main = (int)(full * 256 / tn);
@@ -1638,9 +1664,20 @@ static int gemm_fp8_launch(const void* A8, long lda, const float* sa, const void
   g.A2 = (const bf16_t*)A2; g.B2 = (const bf16_t*)B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
   g.tilesM = cdiv(M, 256); g.tilesN = cdiv(N, 256);
   if (g_prof.on) { g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * (K + K2); }
-  hipLaunchKernelGGL(gemm_fp8_256_kernel, dim3(g.tilesM * g.tilesN), dim3(512), 0, (hipStream_t)stream, g);
+  if (i8) hipLaunchKernelGGL(gemm_fp8_256_kernel<true>, dim3(g.tilesM * g.tilesN), dim3(512), 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL(gemm_fp8_256_kernel<false>, dim3(g.tilesM * g.tilesN), dim3(512), 0, (hipStream_t)stream, g);
   LHRS_CHECK_LAUNCH("gemm_fp8_nt");
   return 0;
+}
+
+// LLM.int8 product (int8.hip): C[M, N] (bf16) = alpha * (sa[m] * sb[n] * (A8 . B8^T in int32) + A2[M, K2] . B2[N, K2]^T) (+ residual).
+// A8 / B8: int8 rows (lhrs_int8_prepare / lhrs_quant_int8_rows), sa / sb their dequantisation factors absmax / 127; the bf16 pair carries
+// the 16-bit outlier-column product (and, concatenated along K2, a LoRA update).  K % 128 == 0, K2 % 64 == 0 (0 = no pair).
+extern "C" int lhrs_gemm_int8_nt(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, const void* A2,
+                                 int lda2, const void* B2, int ldb2, int K2, void* C, int ldc, int M, int N, int K, const void* residual,
+                                 int ldr, float alpha, void* stream) {
+  return gemm_fp8_launch(A8, lda, sa, B8, ldb, sb, K2 > 0 ? A2 : nullptr, lda2, K2 > 0 ? B2 : nullptr, ldb2, K2, C, ldc, M, N, K, residual, ldr,
+                         alpha, stream, true);
 }
 
 extern "C" int lhrs_gemm_fp8_nt(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, void* C, int ldc,

@@ -1,0 +1,199 @@
+// LLM.int8() operand preparation for the frozen 8-bit base of stages 2 / 3 (`bits: 8` of Config/multi_modal_stage{2,3}.yaml).
+//
+// The reference loads the frozen LLaMA through bitsandbytes (lhrs/models/text_modal.py:91-131: BitsAndBytesConfig(load_in_8bit=True,
+// llm_int8_threshold=6.0, llm_int8_has_fp16_weight=False)); every decoder linear then runs bitsandbytes' MatMul8bitLt (0.41 series):
+//   weights, once:   CB[n, k] = rint(W[n, k] * 127 / absmax_k |W[n, :]|)  (int8),  SCB[n] = absmax                      (vector-wise, per output row)
+//   per call:        outlier COLUMNS O = {k : any_t |x[t, k]| >= 6.0};
+//                    SCA[t] = max_k { |x[t, k]| : |x[t, k]| < 6.0 };  CA[t, k] = rint(x[t, k] * 127 / SCA[t]), columns in O zeroed
+//                    y = (CA . CB^T in int32) * SCA[t] * SCB[n] / 127^2  +  x[:, O] . (CB[:, O] * SCB / 127)^T       (the second term in 16 bit)
+//   backward:        dx = dy . (CB * SCB / 127)   - the DEquantised weight in 16 bit (has_fp16_weights = False)
+// bitsandbytes is not installed here (parity vs the package is unpinned; oracle/int8_oracle.py restates the same rules and is the checker).
+// This file holds the element-wise side: weight quantisation / dequantisation, the outlier-column scan and compaction, the activation
+// quantisation and the two column gathers that feed the 16-bit outlier product.  The int8 product itself is gemm_fp8_256_kernel<true>
+// (gemm.hip: v_mfma_i32_32x32x32_i8, exact int32 accumulation), with the outlier product appended as bf16 stages of the same launch.
+#include "common.h"
+
+namespace {
+
+constexpr int QCH = 12;  // 16-B chunks a thread keeps in registers between the absmax and the conversion (K <= 24576)
+
+__device__ __forceinline__ int q8(float v, float inv) {
+  const int q = __float2int_rn(v * inv);  // round half to even, like torch.round / rintf
+  return max(-127, min(127, q));
+}
+__device__ __forceinline__ int pack4(int a, int b, int c, int d) { return (a & 0xff) | ((b & 0xff) << 8) | ((c & 0xff) << 16) | ((d & 0xff) << 24); }
+
+// one block per row: scale[n] = absmax / 127 (dequantisation factor), CB = rint(W * 127 / absmax).  flags / thr: the activation variant
+// (flags != nullptr): entries with |x| >= thr do not count towards the absmax, flagged columns are stored as 0.
+__global__ __launch_bounds__(256) void quant_int8_rows_kernel(const bf16_t* __restrict__ W, long ldw, int8_t* __restrict__ Q, long ldq,
+                                                              float* __restrict__ scale, int K, const int* __restrict__ flags, float thr) {
+  __shared__ float red[4];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int nch = K / 8;
+  const bf16_t* row = W + (long)n * ldw;
+  uint4 keep[QCH];
+  float m = 0.f;
+  auto upd = [&](const uint4& raw) {
+    float v[8];
+    unpack8(raw, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float a = fabsf(v[e]);
+      if (flags == nullptr || a < thr) m = fmaxf(m, a);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < QCH; ++i) {
+    const int c = tid + i * 256;
+    keep[i] = make_uint4(0, 0, 0, 0);
+    if (c < nch) { keep[i] = *reinterpret_cast<const uint4*>(row + c * 8); upd(keep[i]); }
+  }
+  for (int c = tid + QCH * 256; c < nch; c += 256) upd(*reinterpret_cast<const uint4*>(row + c * 8));
+  m = block_max<4>(m, red);
+  const float inv = m > 0.f ? 127.f / m : 0.f;
+  if (tid == 0) scale[n] = m / 127.f;
+  int8_t* orow = Q + (long)n * ldq;
+  auto cvt = [&](const uint4& raw, int c) {
+    float v[8];
+    unpack8(raw, v);
+    int q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q[e] = (flags != nullptr && flags[c * 8 + e]) ? 0 : q8(v[e], inv);
+    *reinterpret_cast<int2*>(orow + c * 8) = make_int2(pack4(q[0], q[1], q[2], q[3]), pack4(q[4], q[5], q[6], q[7]));
+  };
+#pragma unroll
+  for (int i = 0; i < QCH; ++i) {
+    const int c = tid + i * 256;
+    if (c < nch) cvt(keep[i], c);
+  }
+  for (int c = tid + QCH * 256; c < nch; c += 256) cvt(*reinterpret_cast<const uint4*>(row + c * 8), c);
+}
+
+// W[n, k] = CB[n, k] * scale[n] as bf16 (the 16-bit weight of the backward and of generate())
+__global__ __launch_bounds__(256) void dequant_int8_rows_kernel(const int8_t* __restrict__ Q, long ldq, const float* __restrict__ scale,
+                                                                bf16_t* __restrict__ W, long ldw, int K) {
+  const int n = blockIdx.x;
+  const float s = scale[n];
+  for (int c = threadIdx.x; c < K / 8; c += 256) {
+    const int2 raw = *reinterpret_cast<const int2*>(Q + (long)n * ldq + c * 8);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = (float)(int8_t)((raw.x >> (8 * e)) & 0xff) * s;
+      v[4 + e] = (float)(int8_t)((raw.y >> (8 * e)) & 0xff) * s;
+    }
+    *reinterpret_cast<uint4*>(W + (long)n * ldw + c * 8) = pack8(v);
+  }
+}
+
+// flags[k] = 1 when any |x[t, k]| >= thr.  Block (x: 256 column chunks of 8, y: strips of 64 rows); plain stores of the same value race freely.
+__global__ __launch_bounds__(256) void outlier_cols_kernel(const bf16_t* __restrict__ X, long ldx, int M, int K, float thr, int* __restrict__ flags) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= K / 8) return;
+  const int r0 = blockIdx.y * 64, r1 = min(M, r0 + 64);
+  unsigned hit = 0;
+  for (int r = r0; r < r1; ++r) {
+    float v[8];
+    unpack8(*reinterpret_cast<const uint4*>(X + (long)r * ldx + c * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hit |= (fabsf(v[e]) >= thr ? 1u : 0u) << e;
+  }
+  if (hit) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if ((hit >> e) & 1) flags[c * 8 + e] = 1;
+  }
+}
+
+// idx[0 .. n) = the flagged columns in ascending order (n capped at `cap`), idx[n .. cap) = -1; meta[0] = n, meta[1] += 1 when more than `cap`
+// columns were flagged (the columns beyond the cap stay ZEROED in the int8 operand and are missing from the 16-bit product: the host
+// checks meta[1] where it logs).  One block of 1024 threads; K <= 1024 * 32.
+__global__ __launch_bounds__(1024) void compact_cols_kernel(const int* __restrict__ flags, int K, int* __restrict__ idx, int cap, int* __restrict__ meta) {
+  __shared__ int cnt[1024];
+  const int tid = threadIdx.x;
+  const int per = (K + 1023) / 1024;
+  const int k0 = tid * per, k1 = min(K, k0 + per);
+  int c = 0;
+  for (int k = k0; k < k1; ++k) c += flags[k] != 0;
+  cnt[tid] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan
+    const int v = tid >= off ? cnt[tid - off] : 0;
+    __syncthreads();
+    cnt[tid] += v;
+    __syncthreads();
+  }
+  int pos = cnt[tid] - c;
+  const int total = cnt[1023];
+  for (int k = k0; k < k1; ++k)
+    if (flags[k]) {
+      if (pos < cap) idx[pos] = k;
+      ++pos;
+    }
+  for (int j = total + tid; j < cap; j += 1024) idx[j] = -1;
+  if (tid == 0) {
+    meta[0] = min(total, cap);
+    if (total > cap) meta[1] += 1;
+  }
+}
+
+// A2[t, j] = x[t, idx[j]] (0 where idx[j] < 0): the 16-bit operand of the outlier product, [M, cap] bf16
+__global__ __launch_bounds__(256) void gather_cols_x_kernel(const bf16_t* __restrict__ X, long ldx, const int* __restrict__ idx, int cap,
+                                                            bf16_t* __restrict__ out, long ldo, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long t = i / cap;
+  const int j = (int)(i - t * cap);
+  const int k = idx[j];
+  out[t * ldo + j] = k >= 0 ? X[t * ldx + k] : (bf16_t)0;
+}
+// B2[n, j] = CB[n, idx[j]] * scale[n] as bf16 (0 where idx[j] < 0): the dequantised weight columns, [N, cap] bf16
+__global__ __launch_bounds__(256) void gather_cols_w_kernel(const int8_t* __restrict__ Q, long ldq, const float* __restrict__ scale,
+                                                            const int* __restrict__ idx, int cap, bf16_t* __restrict__ out, long ldo, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long n = i / cap;
+  const int j = (int)(i - n * cap);
+  const int k = idx[j];
+  out[n * ldo + j] = k >= 0 ? f2bf((float)Q[n * ldq + k] * scale[n]) : (bf16_t)0;
+}
+
+}  // namespace
+
+// bf16 rows -> int8 rows + dequantisation factor absmax / 127 per row (weights; K % 8 == 0)
+extern "C" int lhrs_quant_int8_rows(const void* W, long ldw, void* Q, long ldq, float* scale, int N, int K, void* stream) {
+  LHRS_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldq % 8 == 0, "quant_int8_rows: N=%d K=%d ldw=%ld ldq=%ld", N, K, ldw, ldq);
+  hipLaunchKernelGGL(quant_int8_rows_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W, ldw, (int8_t*)Q, ldq, scale, K,
+                     (const int*)nullptr, 0.f);
+  LHRS_CHECK_LAUNCH("quant_int8_rows");
+  return 0;
+}
+extern "C" int lhrs_dequant_int8_rows(const void* Q, long ldq, const float* scale, void* W, long ldw, int N, int K, void* stream) {
+  LHRS_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldq % 8 == 0, "dequant_int8_rows: N=%d K=%d", N, K);
+  hipLaunchKernelGGL(dequant_int8_rows_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const int8_t*)Q, ldq, scale, (bf16_t*)W, ldw, K);
+  LHRS_CHECK_LAUNCH("dequant_int8_rows");
+  return 0;
+}
+
+// The activation side of one LLM.int8 product, four launches on `stream`:
+//   flags (int [K], zeroed by the caller's previous use - cleared here), idx (int [cap]) and meta (int [2]: n, overflow count) are workspaces;
+//   XQ int8 [M, ldq] + sx [M] (absmax of the non-outlier entries / 127); A2 bf16 [M, lda2 >= cap] = x[:, outlier columns];
+//   B2 bf16 [N, ldb2 >= cap] = dequantised weight columns.  cap % 64 == 0 (the product appends cap bf16 k-columns).
+extern "C" int lhrs_int8_prepare(const void* X, long ldx, int M, int K, float thr, const void* WQ, long ldwq, const float* wscale, int N,
+                                 void* XQ, long ldq, float* sx, int* flags, int* idx, int* meta, int cap, void* A2, long lda2, void* B2,
+                                 long ldb2, void* stream) {
+  LHRS_REQUIRE(M > 0 && K > 0 && N > 0 && K % 8 == 0 && K <= 32768 && ldx % 8 == 0 && ldq % 8 == 0 && cap > 0 && cap % 64 == 0 && lda2 >= cap &&
+                   ldb2 >= cap && thr > 0.f,
+               "int8_prepare: M=%d K=%d N=%d cap=%d", M, K, N, cap);
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(flags, 0, (size_t)K * sizeof(int), s) != hipSuccess) LHRS_FAIL("int8_prepare: memset failed");
+  hipLaunchKernelGGL(outlier_cols_kernel, dim3(cdiv(K / 8, 256), cdiv(M, 64)), dim3(256), 0, s, (const bf16_t*)X, ldx, M, K, thr, flags);
+  hipLaunchKernelGGL(compact_cols_kernel, dim3(1), dim3(1024), 0, s, (const int*)flags, K, idx, cap, meta);
+  hipLaunchKernelGGL(quant_int8_rows_kernel, dim3(M), dim3(256), 0, s, (const bf16_t*)X, ldx, (int8_t*)XQ, ldq, sx, K, (const int*)flags, thr);
+  const long ta = (long)M * cap, tb = (long)N * cap;
+  hipLaunchKernelGGL(gather_cols_x_kernel, dim3(cdiv(ta, 256)), dim3(256), 0, s, (const bf16_t*)X, ldx, (const int*)idx, cap, (bf16_t*)A2, lda2, ta);
+  hipLaunchKernelGGL(gather_cols_w_kernel, dim3(cdiv(tb, 256)), dim3(256), 0, s, (const int8_t*)WQ, ldwq, wscale, (const int*)idx, cap, (bf16_t*)B2,
+                     ldb2, tb);
+  LHRS_CHECK_LAUNCH("int8_prepare");
+  return 0;
+}

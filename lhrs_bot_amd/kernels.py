@@ -770,3 +770,62 @@ def image_preprocess(img_u8: torch.Tensor, out: torch.Tensor = None, short_edge:
 def clip_preprocess(img_u8: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
     """uint8 [H, W, 3] device tensor -> float32 [3, 224, 224] pixel_values, bit-exact with CLIPImageProcessor."""
     return image_preprocess(img_u8, out)
+
+
+# ------------------------------------------------------------------------------------------------ LLM.int8 base (csrc/int8.hip)
+def quant_int8_rows(W):
+    """bf16 [N, K] -> (int8 [N, K], fp32 [N] dequantisation factor absmax / 127): bitsandbytes' vector-wise weight quantisation."""
+    N, K = W.shape
+    Q = torch.empty((N, K), device=W.device, dtype=torch.int8)
+    sc = torch.empty(N, device=W.device, dtype=torch.float32)
+    _lib.check(_L().lhrs_quant_int8_rows(W.data_ptr(), W.stride(0), Q.data_ptr(), Q.stride(0), sc.data_ptr(), N, K, _stream()), "quant_int8_rows")
+    return Q, sc
+
+
+def dequant_int8_rows(Q, sc, out=None):
+    N, K = Q.shape
+    out = torch.empty((N, K), device=Q.device, dtype=torch.bfloat16) if out is None else out
+    _lib.check(_L().lhrs_dequant_int8_rows(Q.data_ptr(), Q.stride(0), sc.data_ptr(), out.data_ptr(), out.stride(0), N, K, _stream()), "dequant_int8_rows")
+    return out
+
+
+class Int8Workspace:
+    """Device scratch of the LLM.int8 activation side: outlier flags per input feature, the compacted outlier column list (at most `cap`) and
+    meta = [columns found by the last call, number of calls that found more than `cap`]."""
+
+    def __init__(self, device, kmax: int = 32768, cap: int = 128, threshold: float = 6.0):
+        assert cap % 64 == 0
+        self.cap, self.threshold = cap, float(threshold)
+        self.flags = torch.zeros(kmax, device=device, dtype=torch.int32)
+        self.idx = torch.full((cap,), -1, device=device, dtype=torch.int32)
+        self.meta = torch.zeros(2, device=device, dtype=torch.int32)
+
+    def overflowed(self) -> int:
+        """Host read (synchronises): how many products saw more outlier columns than `cap` since construction."""
+        return int(self.meta[1].item())
+
+
+def int8_linear(x, WQ, wscale, ws: Int8Workspace, *, residual=None, a2=None, b2=None, alpha: float = 1.0, out=None):
+    """bitsandbytes MatMul8bitLt forward: y = (int8(x') . WQ^T) * sx * wscale + x[:, O] . dequant(WQ)[:, O]^T (+ a2 . b2^T) (+ residual), O = the
+    columns of x holding a value >= ws.threshold, x' = x with those columns zeroed.  x bf16 [M, K]; WQ int8 [N, K] + wscale [N] from
+    quant_int8_rows; (a2 [M, KP], b2 [N, KP]) an optional bf16 pair (LoRA update) riding on the same accumulators."""
+    M, K = x.shape
+    N = WQ.shape[0]
+    KP = a2.shape[1] if a2 is not None else 0
+    K2 = KP + ws.cap
+    xq = torch.empty((M, K), device=x.device, dtype=torch.int8)
+    sx = torch.empty(M, device=x.device, dtype=torch.float32)
+    A2 = torch.empty((M, K2), device=x.device, dtype=torch.bfloat16)
+    B2 = torch.empty((N, K2), device=x.device, dtype=torch.bfloat16)
+    if KP:
+        A2[:, :KP].copy_(a2)
+        B2[:, :KP].copy_(b2)
+    L = _L()
+    _lib.check(L.lhrs_int8_prepare(x.data_ptr(), x.stride(0), M, K, ws.threshold, WQ.data_ptr(), WQ.stride(0), wscale.data_ptr(), N,
+                                   xq.data_ptr(), xq.stride(0), sx.data_ptr(), ws.flags.data_ptr(), ws.idx.data_ptr(), ws.meta.data_ptr(), ws.cap,
+                                   A2.data_ptr() + 2 * KP, K2, B2.data_ptr() + 2 * KP, K2, _stream()), "int8_prepare")
+    out = torch.empty((M, N), device=x.device, dtype=torch.bfloat16) if out is None else out
+    _lib.check(L.lhrs_gemm_int8_nt(xq.data_ptr(), xq.stride(0), sx.data_ptr(), WQ.data_ptr(), WQ.stride(0), wscale.data_ptr(), A2.data_ptr(), K2,
+                                   B2.data_ptr(), K2, K2, out.data_ptr(), out.stride(0), M, N, K, _p(residual),
+                                   residual.stride(0) if residual is not None else 0, float(alpha), _stream()), "gemm_int8_nt")
+    return out

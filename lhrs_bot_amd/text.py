@@ -214,7 +214,9 @@ class TextModal:
         self.sin = fr.sin().to(torch.bfloat16).float().to(self.device).contiguous()
         self._ctx = None
         self.lora: Optional[LoraStore] = None
-        self.base8 = False  # frozen decoder linears in e4m3 (quantize_base)
+        self.base8 = False  # frozen decoder linears in e4m3 (quantize_base(8, "e4m3"))
+        self.base_int8 = False  # frozen decoder linears as LLM.int8 (quantize_base(8, "int8"): the reference's bitsandbytes arithmetic)
+        self._i8ws = None
         # training forward: run the last decoder layer's post-attention half on the supervised rows only when they are one contiguous
         # range per sequence (_layer_fwd `tail`); LHRS_TAIL_ROWS_ONLY=0 / attribute False: every row, as HF does
         self.tail_rows_only = os.environ.get("LHRS_TAIL_ROWS_ONLY", "1") != "0"
@@ -263,12 +265,12 @@ class TextModal:
                 hk.gemm_nt(lo.derived[(li, gname, "Bfull")], lo.derived[(li, gname, "AT")], out=W, residual=W, alpha=lo.s)
                 L[wname[gname] + "T"] = hk.transpose(W)
             self._drop_derived(L)
-        requant = self.base8
-        self.lora, self._merged_cache, self.base8 = None, None, False
+        requant = "e4m3" if self.base8 else ("int8" if self.base_int8 else None)
+        self.lora, self._merged_cache, self.base8, self.base_int8 = None, None, False, False
         if requant:
-            self.quantize_base(8)   # the 8-bit base is a function of the (now merged) weights
+            self.quantize_base(8, requant)   # the 8-bit base is a function of the (now merged) weights
 
-    DERIVED_SUFFIXES = ("p", "8", "8s", "8p")   # decode re-tilings and e4m3 copies of a weight `<name>` / `<name>T`, rebuilt lazily from it
+    DERIVED_SUFFIXES = ("p", "8", "8s", "8p", "i8", "i8s")   # decode re-tilings and e4m3 copies of a weight `<name>` / `<name>T`, rebuilt lazily from it
 
     def _drop_derived(self, L) -> None:
         """Forget every tensor that was computed FROM a decoder weight of layer dict `L` (decode re-tilings, e4m3 copies): after the weight
@@ -315,7 +317,11 @@ class TextModal:
         """(e4m3 weight, per-row scales) of L[name] when the base weights are 8-bit (quantize_base), else None."""
         return (L[name + "8"], L[name + "8s"]) if self.base8 else None
 
-    def _lin(self, li, gname, x, W, residual=None, save=None, q8=None, xq=None, rope=None):
+    def _i8(self, L, name):
+        """(int8 rows, dequantisation factors) of a decoder weight under the LLM.int8 base, else None"""
+        return (L[name + "i8"], L[name + "i8s"]) if self.base_int8 else None
+
+    def _lin(self, li, gname, x, W, residual=None, save=None, q8=None, xq=None, rope=None, i8=None):
         """y = x W^T (+ s (x A^T) B^T when the group carries adapters) (+ residual).  q8 = (W8, scales): the frozen base product runs
         on the e4m3 MFMA path (x quantised per row on the fly), the adapter update stays bf16 and rides on the same accumulators (lhrs_gemm_fp8_nt_lora).
         rope = (pos_mod, pos0): the qkv projection - RoPE of the q / k heads in the bf16 GEMM's epilogue, a separate launch after the e4m3 one."""
@@ -331,6 +337,12 @@ class TextModal:
             T = hk.gemm_nt_skinny(xa, lo.view(lo.shadow, li, gname, "A"), alpha=lo.s)          # [M, KP] = s * dropout(x) A^T
             if save is not None:
                 save["T_" + gname] = T
+        if i8 is not None:  # LLM.int8 base (text_modal.py:91-131 -> bitsandbytes MatMul8bitLt): int8 product + 16-bit outlier columns, adapters on top
+            y = hk.int8_linear(x, i8[0], i8[1], self._i8ws, residual=residual, a2=T if has_lora else None,
+                               b2=lo.derived[(li, gname, "Bfull")] if has_lora else None)
+            if rope is not None:
+                hk.rope_(y, y.shape[0], 2 * self.heads, self.hd, self.cos, self.sin, pos_mod=rope[0], pos0=rope[1])
+            return y
         if q8 is not None:
             x8, sx = xq if xq is not None else hk.quant_fp8_rows(x)  # xq: the producer already emitted the e4m3 operand
             if has_lora:
@@ -347,9 +359,12 @@ class TextModal:
             return hk.gemm_nt(x, W, residual=residual)
         return hk.gemm_nt_lora(x, W, T, lo.derived[(li, gname, "Bfull")], residual=residual)
 
-    def _gu_fwd(self, li, h, W, save, q8=None, xq=None):
+    def _gu_fwd(self, li, h, W, save, q8=None, xq=None, i8=None):
         """gate|up projection with the SwiGLU in the GEMM epilogue (one launch): -> (gu [M, 2ff], act [M, ff])."""
         lo = self.lora
+        if i8 is not None:
+            gu = self._lin(li, "gu", h, W, save=save, i8=i8)
+            return gu, hk.swiglu_fwd(gu, self.ff), None
         if self.base8:  # SwiGLU emits the e4m3 operand of the down projection; bf16 act only if an adapter on `down` needs it
             gu = self._lin(li, "gu", h, W, save=save, q8=q8, xq=xq)
             act, act8, sact = hk.swiglu_fwd_q(gu, self.ff, want_bf16=lo is not None and "down" in lo.groups)
@@ -446,7 +461,7 @@ class TextModal:
             h, hq = hk.rmsnorm_fwd_q(x, L["ln1_w"], self.eps, want_bf16=lo is not None and "qkv" in lo.groups)
         else:
             h = hk.rmsnorm_fwd(x, L["ln1_w"], self.eps)
-        qkv = self._lin(li, "qkv", h, L["qkv_w"], save=rec, q8=self._q8(L, "qkv_w"), xq=hq, rope=(S, 0))
+        qkv = self._lin(li, "qkv", h, L["qkv_w"], save=rec, q8=self._q8(L, "qkv_w"), xq=hq, rope=(S, 0), i8=self._i8(L, "qkv_w"))
         o = torch.empty((M, d), device=self.device, dtype=torch.bfloat16)
         lse = torch.empty((B, H, LT), device=self.device, dtype=torch.float32)
         o_full, x_res = o, x
@@ -456,13 +471,13 @@ class TextModal:
             rows, tdesc, max_q = tail
             hk.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, tdesc, B, H, hd, max_q, S, LT, True, 1.0 / math.sqrt(hd))
             o, x_res = hk.gather_rows(o_full, rows), hk.gather_rows(x, rows)   # from here on: n rows
-        x_mid = self._lin(li, "o", o, L["o_w"], residual=x_res, save=rec, q8=self._q8(L, "o_w"))
+        x_mid = self._lin(li, "o", o, L["o_w"], residual=x_res, save=rec, q8=self._q8(L, "o_w"), i8=self._i8(L, "o_w"))
         if self.base8:
             h, hq = hk.rmsnorm_fwd_q(x_mid, L["ln2_w"], self.eps, want_bf16=lo is not None and "gu" in lo.groups)
         else:
             h = hk.rmsnorm_fwd(x_mid, L["ln2_w"], self.eps, out=h if tail is None else None)
-        gu, act, actq = self._gu_fwd(li, h, L["gu_w"], rec, q8=self._q8(L, "gu_w"), xq=hq)
-        x_out = self._lin(li, "down", act, L["down_w"], residual=x_mid, save=rec, q8=self._q8(L, "down_w"), xq=actq)
+        gu, act, actq = self._gu_fwd(li, h, L["gu_w"], rec, q8=self._q8(L, "gu_w"), xq=hq, i8=self._i8(L, "gu_w"))
+        x_out = self._lin(li, "down", act, L["down_w"], residual=x_mid, save=rec, q8=self._q8(L, "down_w"), xq=actq, i8=self._i8(L, "down_w"))
         if save is not None:
             rec.update(x_in=x, qkv=qkv, o=o, o_full=o_full, lse=lse, x_mid=x_mid, gu=gu)
             save.append(rec)
@@ -625,26 +640,44 @@ class TextModal:
                 L[k + "p"] = hk.repack_bf16_mfma(L[k])
         self.p["lm_headp"] = hk.repack_bf16_mfma(self.p["lm_head"])
 
-    def quantize_base(self, bits: int = 8):
-        """`bits: 8` of Config/multi_modal_stage{2,3}.yaml (text_modal.py:91-131: the reference loads the frozen LLaMA through
-        bitsandbytes LLM.int8 for stages 2/3).  MI355X-native equivalent: every decoder linear (lm_head stays bf16, as bitsandbytes
-        skips it) gets OCP e4m3 copies with one fp32 scale per output row - of W for the forward product and of W^T for the dX product -
-        and TRAINING runs both on the 2x-rate block-scaled MFMA with activations quantised per row on the fly.  LoRA adapters, norms,
-        attention and the loss stay bf16 / fp32.  bitsandbytes is not importable here: the scheme is ours, parity vs LLM.int8 unpinned."""
+    def quantize_base(self, bits: int = 8, scheme: str = "e4m3"):
+        """`bits: 8` of Config/multi_modal_stage{2,3}.yaml (text_modal.py:91-131: the reference loads the frozen LLaMA through bitsandbytes
+        LLM.int8 for stages 2/3; lm_head stays 16-bit there and here).  Two schemes:
+
+        * "int8" - the reference's arithmetic (what `UniBind.prepare_for_training` picks for the YAML key): every decoder linear is stored as
+          int8 rows + absmax factors (vector-wise), the forward is bitsandbytes' MatMul8bitLt - int8 x int8 -> int32 on the MFMA with
+          the activation's outlier columns (any |x| >= 6.0) taken out into a 16-bit product (`hk.int8_linear`) -, the backward multiplies
+          with the DEquantised weight in 16 bit.  The bf16 weights of this object BECOME the dequantised ones (generate, merges and the dX
+          GEMMs read them).  Parity: oracle/int8_oracle.py (bitsandbytes itself is not installed: unpinned against the package).
+        * "e4m3" - MI355X-native fast path: OCP e4m3 copies with one fp32 scale per output row - of W for the forward product and of W^T for
+          the dX product - on the 2x-rate block-scaled MFMA, activations / gradients quantised per row on the fly, no outlier split.
+        LoRA adapters, norms, attention and the loss stay bf16 / fp32 in both."""
         if bits == 4:  # text_modal.py:91-107 `load_in_4bit` (nf4 storage, 16-bit compute): gfx950 has no 4-bit bf16-compute MFMA path worth
             import logging  # a kernel family here; the 8-bit base is the closest resident format and is what runs
-            logging.getLogger("train").warning("bits=4 (bitsandbytes nf4) is run as the 8-bit e4m3 base: 4-bit storage is not built")
+            logging.getLogger("train").warning("bits=4 (bitsandbytes nf4) is run as the 8-bit base: 4-bit storage is not built")
             bits = 8
         if bits not in (8, 16):
-            raise NotImplementedError(f"bits={bits}: 16 (bf16), 8 (e4m3 base weights) or 4 (run as 8)")
+            raise NotImplementedError(f"bits={bits}: 16 (bf16), 8 (8-bit base weights) or 4 (run as 8)")
+        if scheme not in ("e4m3", "int8"):
+            raise ValueError(f"quantize_base scheme {scheme!r}: 'int8' (LLM.int8, the reference's) or 'e4m3'")
         if bits == 16:
-            self.base8 = False
+            self.base8 = self.base_int8 = False
+            return self
+        if scheme == "int8":
+            for L in self.p["layers"]:
+                self._drop_derived(L)
+                for k in ("qkv_w", "o_w", "gu_w", "down_w"):
+                    L[k + "i8"], L[k + "i8s"] = hk.quant_int8_rows(L[k])
+                    hk.dequant_int8_rows(L[k + "i8"], L[k + "i8s"], out=L[k])     # from here on the 16-bit weight IS the int8 one
+                    L[k + "T"] = hk.transpose(L[k])
+            self._i8ws = hk.Int8Workspace(self.device, kmax=max(self.d, self.ff), cap=int(os.environ.get("LHRS_INT8_OUTLIER_CAP", "128")))
+            self.base8, self.base_int8 = False, True
             return self
         self.quantize_fp8()
         for L in self.p["layers"]:
             for k in ("qkv_wT", "o_wT", "gu_wT", "down_wT"):
                 L[k + "8"], L[k + "8s"] = hk.quant_fp8_rows(L[k])
-        self.base8 = True
+        self.base8, self.base_int8 = True, False
         return self
 
     def _decode_session(self, B, max_ctx, caches, max_new, weights="bf16", kmask=None):
@@ -770,12 +803,12 @@ class TextModal:
                   eos_token_id=eos_token_id, return_logits=return_logits, use_graph=use_graph, weights=weights)
         if self.lora is None:
             return self._generate(input_ids, **kw)
-        base_layers, base8 = self.p["layers"], self.base8
-        self.p["layers"], self.base8 = self._lora_merged_layers(), False
+        base_layers, base8, base_i8 = self.p["layers"], self.base8, self.base_int8
+        self.p["layers"], self.base8, self.base_int8 = self._lora_merged_layers(), False, False   # merged 16-bit copies: no 8-bit operands of them exist
         try:
             return self._generate(input_ids, **kw)
         finally:
-            self.p["layers"], self.base8 = base_layers, base8
+            self.p["layers"], self.base8, self.base_int8 = base_layers, base8, base_i8
 
     def _generate(self, input_ids, image_embedding=None, attention_mask=None, do_sample=False, temperature=1.0, top_p=None,
                   top_k=None, max_new_tokens=512, use_cache=True, stopping_criteria=None, streamer=None, eos_token_id=None,

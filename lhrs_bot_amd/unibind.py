@@ -67,7 +67,7 @@ class UniBind:
         if self.bits in (4, 8):
             log.info("config bits=%d: frozen decoder linears kept as %s; double_quant=%s / quant_type=%s are bitsandbytes 4-bit options "
                      "(text_modal.py:97-101) and do not apply to the 8-bit base", self.bits,
-                     "e4m3 rows + fp32 row scales (lhrs_gemm_fp8_nt)" if self.bits == 8 else "e4m3 rows (no 4-bit MFMA path: 8-bit is used)",
+                     "LLM.int8 rows + absmax factors, int8 MFMA + 16-bit outlier columns (LHRS_BASE8=e4m3: e4m3 rows on the fp8 MFMA)" if self.bits == 8 else "the 8-bit base (no 4-bit MFMA path)",
                      _get(config, "double_quant", None), _get(config, "quant_type", None))
 
     # ------------------------------------------------------------------ reference surface
@@ -93,8 +93,11 @@ class UniBind:
         self.train()
         if model_path is not None:
             self.custom_load_state_dict(model_path)
-        if self.bits in (4, 8) and not self.text.base8 and self.text.p.get("layers"):
-            self.text.quantize_base(self.bits)  # the YAML's `bits: 8`: e4m3 copies of the (now loaded) frozen decoder linears
+        if self.bits in (4, 8) and not (self.text.base8 or self.text.base_int8) and self.text.p.get("layers"):
+            # the YAML's `bits: 8`: LLM.int8 storage and arithmetic of the (now loaded) frozen decoder linears, as the reference runs stages 2/3;
+            # LHRS_BASE8=e4m3 selects the faster MI355X-native 8-bit base instead (a deviation: no outlier decomposition)
+            import os
+            self.text.quantize_base(self.bits, os.environ.get("LHRS_BASE8", "int8"))  # the YAML's `bits: 8`: e4m3 copies of the (now loaded) frozen decoder linears
 
     def train(self):
         self.training = True

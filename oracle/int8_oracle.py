@@ -9,7 +9,8 @@ forward, y = x W^T with W [out, in] frozen:
   * W is stored once as int8 with one absmax scale per OUTPUT ROW:   CB = round(127 * W / SCB[:, None]),  SCB = max_k |W[n, k]|
   * per call, the feature columns k of x [tokens, in] in which ANY |x[t, k]| >= threshold (6.0) are OUTLIERS:
         - outlier part in 16 bit:     y_o = x[:, O] . (CB[:, O] * SCB[:, None] / 127)^T        (the weight columns are DEquantised int8)
-        - the rest in int8:           x' = x with outlier columns zeroed;  CA = round(127 * x' / SCA[:, None]), SCA = max_k |x'[t, k]|
+        - the rest in int8:           SCA[t] = max_k { |x[t, k]| : |x[t, k]| < threshold }  (bitsandbytes' row statistics skip outlier ENTRIES, not
+                                      whole outlier columns);  CA = round(x * (127 / SCA[:, None])) with the outlier COLUMNS zeroed
                                       y_i = (CA . CB^T  in int32) * SCA[:, None] * SCB[None, :] / (127 * 127)
         - y = y_i + y_o   (fp16 in the reference; here the caller's dtype)
 backward (frozen int8 weight, `has_fp16_weights=False`):  dx = dy . (CB * SCB[:, None] / 127)  - the DEQUANTISED weight, in 16 bit.
@@ -29,7 +30,7 @@ THRESHOLD = 6.0
 def quantize_rows_int8(w: torch.Tensor):
     """-> (CB int8 [out, in], SCB fp32 [out]): vector-wise absmax quantisation of the weight rows (round half to even, like torch.round)."""
     scb = w.abs().amax(dim=1).clamp_min(1e-30)
-    cb = torch.round(127.0 * w / scb[:, None]).clamp_(-127, 127).to(torch.int8)
+    cb = torch.round(w * (127.0 / scb)[:, None]).clamp_(-127, 127).to(torch.int8)      # x * (127 / absmax): bitsandbytes multiplies by the reciprocal
     return cb, scb
 
 
@@ -47,9 +48,8 @@ class _MatMul8bitLt(torch.autograd.Function):
         y = x2.new_zeros((x2.shape[0], cb.shape[0]))
         if bool(outlier.any()):
             y = y + x2[:, outlier] @ wd[:, outlier].t()                   # 16-bit path of the reference (fp32 here: the oracle's dtype)
-        xi = x2.masked_fill(outlier[None, :], 0.0)
-        sca = xi.abs().amax(dim=1).clamp_min(1e-30)
-        ca = torch.round(127.0 * xi / sca[:, None]).clamp_(-127, 127)
+        sca = x2.abs().masked_fill(x2.abs() >= threshold, 0.0).amax(dim=1).clamp_min(1e-30)
+        ca = torch.round(x2 * (127.0 / sca)[:, None]).clamp_(-127, 127).masked_fill(outlier[None, :], 0.0)
         acc = ca.double() @ cb.double().t()                               # exact int32 accumulation (|sum| < 2^31 for in <= 2^17)
         y = y + (acc * (sca[:, None].double() * scb[None, :].double() / (127.0 * 127.0))).float()
         ctx.save_for_backward(cb, scb)

@@ -109,12 +109,12 @@ def test_stage2_and_stage3_drivers_from_yaml_keys(tmp_path):
 
     t2 = drv.main(cfg(2, tmp_path / "s2"))
     m2 = t2.model.module
-    assert m2.text.lora is not None and m2.text.lora.r == 8 and m2.text.lora.dropout == 0.05 and m2.text.base8
+    assert m2.text.lora is not None and m2.text.lora.r == 8 and m2.text.lora.dropout == 0.05 and m2.text.base_int8
     assert {s.name for s in t2.model.stores} == {"rgb_pooler", "lora"} and t2.model.global_steps == 3
     assert os.path.isdir(tmp_path / "s2" / "checkpoints" / "TextLoRA")
     t3 = drv.main(cfg(3, tmp_path / "s3", epochs=4, model_path=str(tmp_path / "s2" / "checkpoints" / "FINAL.pt")))
     m3 = t3.model.module
-    assert m3.text.lora is not None and m3.text.lora.r == 8 and m3.text.base8        # adapters came from TextLoRA/, base re-quantised
+    assert m3.text.lora is not None and m3.text.lora.r == 8 and m3.text.base_int8    # adapters came from TextLoRA/, base re-quantised (LLM.int8: the YAML default)
     assert {s.name for s in t3.model.stores} == {"lora"} and t3.model.global_steps == 4
     assert len(t3.history) == 4 and all(torch.isfinite(torch.tensor(h["loss"])) for h in t3.history)
 
@@ -141,11 +141,11 @@ def test_stage2_and_stage3_drivers_from_the_shipped_yaml_trees(tmp_path):
 
     t2 = run("stage2", 2, tmp_path / "s2")
     m2 = t2.model.module
-    assert m2.text.lora is not None and m2.text.lora.r == 128 and m2.text.lora.dropout == 0.05 and m2.text.base8
+    assert m2.text.lora is not None and m2.text.lora.r == 128 and m2.text.lora.dropout == 0.05 and m2.text.base_int8
     assert t2.model.opt_name == "adamw" and t2.model.precision_request == "fp16" and t2.model.max_grad_norm == 1.0
     assert {s.name for s in t2.model.stores} == {"rgb_pooler", "lora"} and t2.model.global_steps == 3
     assert all(torch.isfinite(torch.tensor(h["loss"])) for h in t2.history)
     t3 = run("stage3", 3, tmp_path / "s3", "--model-path", str(tmp_path / "s2" / "checkpoints" / "FINAL.pt"), "--opts", "epochs", "4")
     m3 = t3.model.module
-    assert m3.text.lora is not None and m3.text.lora.r == 128 and m3.text.base8          # adapters from TextLoRA/, `lora.enable: False` in the YAML
+    assert m3.text.lora is not None and m3.text.lora.r == 128 and m3.text.base_int8     # adapters from TextLoRA/, `lora.enable: False` in the YAML
     assert {s.name for s in t3.model.stores} == {"lora"} and t3.model.global_steps == 4 and len(t3.history) == 4
