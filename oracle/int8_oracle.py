@@ -27,10 +27,19 @@ import torch.nn.functional as F
 THRESHOLD = 6.0
 
 
+def _codes(x: torch.Tensor, absmax: torch.Tensor) -> torch.Tensor:
+    """rint(x * (127 / absmax)) per row in IEEE fp32 (numpy: correctly rounded division and product, ties to even) - torch's vectorised CPU
+    division is not correctly rounded (127 / 0.0810546875 comes out one ulp low), which flips exact .5 ties that bf16 data produces often."""
+    import numpy as np
+    inv = np.float32(127.0) / absmax.detach().numpy().astype(np.float32)
+    q = np.rint(x.detach().numpy().astype(np.float32) * inv[:, None])
+    return torch.from_numpy(np.clip(q, -127, 127).astype(np.float32))
+
+
 def quantize_rows_int8(w: torch.Tensor):
     """-> (CB int8 [out, in], SCB fp32 [out]): vector-wise absmax quantisation of the weight rows (round half to even, like torch.round)."""
     scb = w.abs().amax(dim=1).clamp_min(1e-30)
-    cb = torch.round(w * (127.0 / scb)[:, None]).clamp_(-127, 127).to(torch.int8)      # x * (127 / absmax): bitsandbytes multiplies by the reciprocal
+    cb = _codes(w, scb).to(torch.int8)                                                  # x * (127 / absmax): bitsandbytes multiplies by the reciprocal
     return cb, scb
 
 
@@ -49,7 +58,7 @@ class _MatMul8bitLt(torch.autograd.Function):
         if bool(outlier.any()):
             y = y + x2[:, outlier] @ wd[:, outlier].t()                   # 16-bit path of the reference (fp32 here: the oracle's dtype)
         sca = x2.abs().masked_fill(x2.abs() >= threshold, 0.0).amax(dim=1).clamp_min(1e-30)
-        ca = torch.round(x2 * (127.0 / sca)[:, None]).clamp_(-127, 127).masked_fill(outlier[None, :], 0.0)
+        ca = _codes(x2, sca).masked_fill(outlier[None, :], 0.0)
         acc = ca.double() @ cb.double().t()                               # exact int32 accumulation (|sum| < 2^31 for in <= 2^17)
         y = y + (acc * (sca[:, None].double() * scb[None, :].double() / (127.0 * 127.0))).float()
         ctx.save_for_backward(cb, scb)
