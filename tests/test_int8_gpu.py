@@ -73,6 +73,9 @@ def test_llm_int8_base_end_to_end_vs_int8_oracle(with_lora):
     (`int8_llama_params`): loss, d loss / d image, and with adapters every dA / dB; the backward multiplies with the dequantised weights."""
     nl = 2
     P = {"vit": OP.make_vit_params(seed=2), "pooler": OP.make_pooler_params(seed=1), "llama": OP.make_llama_params(seed=3, layers=nl)}
+    for L in P["llama"]["layers"]:          # the int8 codes are a function of the 16-bit checkpoint weights: both sides quantise the SAME bf16 values
+        for k in ("qkv_w", "o_w", "gu_w", "down_w"):
+            L[k] = L[k].to(torch.bfloat16).float()
     model = UniBind(("rgb", "text"), None, device=DEV, llama_layers=nl).load_params(P)
     targets = ("q", "k", "v", "o", "gate", "up", "down")
     lora_p = OP.make_lora_params(seed=4, layers=nl, r=16, alpha=32, targets=targets) if with_lora else None
