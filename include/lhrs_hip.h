@@ -123,16 +123,17 @@ int lhrs_gemm_set_bm144(int mode);
 /* ---- LLM.int8() base (the reference's `bits: 8`: lhrs/models/text_modal.py:91-131 -> bitsandbytes MatMul8bitLt, 0.41 series) --------------
  * weights once: lhrs_quant_int8_rows -> int8 rows + factor absmax / 127 per row; lhrs_dequant_int8_rows -> the 16-bit weight CB * factor that
  * the backward (dx = dy . dequant(W)) and generate() use.  Per product: lhrs_int8_prepare scans x for outlier columns (any |x| >= thr = 6.0),
- * compacts them (at most `cap`, cap % 64 == 0; meta[0] = count, meta[1] counts calls that exceeded the cap), quantises x per row with those
- * columns zeroed and gathers x[:, O] and dequant(W)[:, O] into the bf16 pair; lhrs_gemm_int8_nt then computes
- * sa[m] * sb[n] * (XQ . WQ^T in int32) + A2 . B2^T (+ residual) in one launch.  Workspaces (flags int[K], idx int[cap], meta int[2]) are the caller's. */
+ * compacts them (meta[0] = count n, meta[1] = n rounded up to 64; no cap: idx / A2 / B2 are sized for K columns), quantises x per row with
+ * those columns zeroed and gathers x[:, O] and dequant(W)[:, O] into the bf16 pair; lhrs_gemm_int8_nt then computes
+ * sa[m] * sb[n] * (XQ . WQ^T in int32) + A2 . B2^T (+ residual) in one launch, reading the outlier column count from k2_dev (= meta + 1) on the
+ * device.  Workspaces (flags int[K], idx int[K rounded up to 64], meta int[2]) are the caller's. */
 int lhrs_quant_int8_rows(const void* W, long ldw, void* Q, long ldq, float* scale, int N, int K, void* stream);
 int lhrs_dequant_int8_rows(const void* Q, long ldq, const float* scale, void* W, long ldw, int N, int K, void* stream);
 int lhrs_int8_prepare(const void* X, long ldx, int M, int K, float thr, const void* WQ, long ldwq, const float* wscale, int N, void* XQ,
-                      long ldq, float* sx, int* flags, int* idx, int* meta, int cap, void* A2, long lda2, void* B2, long ldb2, void* stream);
+                      long ldq, float* sx, int* flags, int* idx, int* meta, void* A2, long lda2, void* B2, long ldb2, void* stream);
 int lhrs_gemm_int8_nt(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, const void* A2, int lda2,
-                      const void* B2, int ldb2, int K2, void* C, int ldc, int M, int N, int K, const void* residual, int ldr, float alpha,
-                      void* stream);
+                      const void* B2, int ldb2, int K2, const int* k2_dev, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
+                      float alpha, void* stream);
 /* kernel A/B tests only: fewest 64x128 tiles for which the small-tile GEMM takes 64x128 tiles instead of 64x64 (default 256) */
 int lhrs_gemm_set_small_thresh(int n);
 /* kernel A/B tests only: fewest 256x256 tiles for which lhrs_gemm_bf16_nt picks the big-tile kernel (default 128) */

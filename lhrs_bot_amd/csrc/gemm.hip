@@ -67,6 +67,9 @@ struct GemmArgs {
   int rope_mod, rope_pos0, rope_cols;
   // split-K of the small-tile kernel (skinny-N products): block (x, y) reduces K-slice y of length ksplit into f32 slab y of C
   int ksplit;
+  // 8-bit kernels: bf16 columns of the second pair whose count is only known on the device (LLM.int8 outlier columns; a multiple of 64),
+  // appended behind the K2 host-known ones (nullptr = none)
+  const int* k2_dev;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -841,6 +844,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256_kernel(GemmArgs g) {
   const char* base2 = reinterpret_cast<const char*>(isA ? g.A2 : g.B2);
   const long ld2 = (isA ? g.lda2 : g.ldb2) * 2L;  // bytes
   const int nk1 = g.K / BKB;
+  const int K2 = g.K2 + (g.k2_dev ? __builtin_amdgcn_readfirstlane(g.k2_dev[0]) : 0);   // host-known + device-known bf16 columns
   unsigned off1[8], off2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -848,10 +852,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256_kernel(GemmArgs g) {
     const int lchunk = (lane & 7) ^ ((((j & 1) << 2) + (lane >> 4)) & 7);
     const int row = min(row0 + ridx * 8 + (lane >> 3), rmax);
     off1[j] = (unsigned)((long)row * ld1 + lchunk * 16);
-    off2[j] = g.K2 > 0 ? (unsigned)((long)row * ld2 + lchunk * 16) : 0u;
+    off2[j] = K2 > 0 ? (unsigned)((long)row * ld2 + lchunk * 16) : 0u;
   }
   const int dst0 = (isA ? 0 : A_BYTES) + (wave & 3) * 8192;
-  const int nk_all = nk1 + g.K2 / 64;    // e4m3 stages + bf16 stages of the fused pair
+  const int nk_all = nk1 + K2 / 64;    // e4m3 stages + bf16 stages of the fused pair
   auto issue1 = [&](int kt, int j) {
     if (kt >= nk_all) return;            // (wave-uniform) nothing left to fetch
     const char* p = kt < nk1 ? base1 + (long)kt * BKB + off1[j] : base2 + (long)(kt - nk1) * BKB + off2[j];
@@ -1626,11 +1630,11 @@ __global__ __launch_bounds__(256) void gemm_fp8_small_kernel(GemmArgs g) {
 // (lhrs_quant_fp8_rows).  K % 128 == 0, N % 8 == 0; lda / ldb in BYTES (>= K, multiples of 16).
 static int gemm_fp8_launch(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, const void* A2, int lda2,
                            const void* B2, int ldb2, int K2, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
-                           float alpha, void* stream, bool i8 = false) {
+                           float alpha, void* stream, bool i8 = false, const int* k2_dev = nullptr) {
   LHRS_REQUIRE(M > 0 && N > 0 && K >= 256 && K % 128 == 0, "gemm_fp8: M=%d N=%d K=%d (K %% 128 == 0, K >= 256)", M, N, K);
   LHRS_REQUIRE(lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K && sa && sb, "gemm_fp8: lda=%ld ldb=%ld", lda, ldb);
   LHRS_REQUIRE(N % 8 == 0 && ldc % 8 == 0 && ldc >= N && (residual == nullptr || ldr % 8 == 0), "gemm_fp8: N=%d ldc=%d ldr=%d", N, ldc, ldr);
-  LHRS_REQUIRE(K2 == 0 || (A2 && B2 && K2 % 64 == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && lda2 >= K2 && ldb2 >= K2),
+  LHRS_REQUIRE((K2 == 0 && !k2_dev) || (A2 && B2 && K2 % 64 == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && lda2 >= K2 && ldb2 >= K2),
                "gemm_fp8: bad bf16 pair (K2=%d lda2=%d ldb2=%d)", K2, lda2, ldb2);
   // tail-row rule (see gemm_launch): the tile rows that spill over the last full round of the 256 CUs go to the small-tile kernel
   if (!i8 && t_split_ok && g_gemm_tail_split) {   // (the small-tile sibling exists for e4m3 only)
@@ -1661,7 +1665,7 @@ static int gemm_fp8_launch(const void* A8, long lda, const float* sa, const void
   GemmArgs g; memset(&g, 0, sizeof(g));
   g.A = (const bf16_t*)A8; g.B = (const bf16_t*)B8; g.C = C; g.res = (const bf16_t*)residual;
   g.M = M; g.N = N; g.K = K; g.lda = (int)lda; g.ldb = (int)ldb; g.ldc = ldc; g.ldr = ldr; g.alpha = alpha; g.sa = sa; g.sb = sb;
-  g.A2 = (const bf16_t*)A2; g.B2 = (const bf16_t*)B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
+  g.A2 = (const bf16_t*)A2; g.B2 = (const bf16_t*)B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2; g.k2_dev = k2_dev;
   g.tilesM = cdiv(M, 256); g.tilesN = cdiv(N, 256);
   if (g_prof.on) { g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * (K + K2); }
   if (i8) hipLaunchKernelGGL(gemm_fp8_256_kernel<true>, dim3(g.tilesM * g.tilesN), dim3(512), 0, (hipStream_t)stream, g);
@@ -1670,15 +1674,16 @@ static int gemm_fp8_launch(const void* A8, long lda, const float* sa, const void
   return 0;
 }
 
-// LLM.int8 product (int8.hip): C[M, N] (bf16) = alpha * (sa[m] * sb[n] * (A8 . B8^T in int32) + A2[M, K2] . B2[N, K2]^T) (+ residual).
-// A8 / B8: int8 rows (lhrs_int8_prepare / lhrs_quant_int8_rows), sa / sb their dequantisation factors absmax / 127; the bf16 pair carries
-// the 16-bit outlier-column product (and, concatenated along K2, a LoRA update).  K % 128 == 0, K2 % 64 == 0 (0 = no pair).
+// LLM.int8 product (int8.hip): C[M, N] (bf16) = alpha * (sa[m] * sb[n] * (A8 . B8^T in int32) + A2[M, :K2t] . B2[N, :K2t]^T) (+ residual).
+// A8 / B8: int8 rows (lhrs_int8_prepare / lhrs_quant_int8_rows), sa / sb their dequantisation factors absmax / 127.  The bf16 pair holds
+// K2 host-known columns (a LoRA update; 0 = none) followed by k2_dev[0] device-known ones (the 16-bit outlier-column product, a multiple of
+// 64 written by lhrs_int8_prepare into meta[1]); K2t is their sum, lda2 / ldb2 must cover the worst case.  K % 128 == 0, K2 % 64 == 0.
 extern "C" int lhrs_gemm_int8_nt(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, const void* A2,
-                                 int lda2, const void* B2, int ldb2, int K2, void* C, int ldc, int M, int N, int K, const void* residual,
-                                 int ldr, float alpha, void* stream) {
-  return gemm_fp8_launch(A8, lda, sa, B8, ldb, sb, K2 > 0 ? A2 : nullptr, lda2, K2 > 0 ? B2 : nullptr, ldb2, K2, C, ldc, M, N, K, residual, ldr,
-                         alpha, stream, true);
+                                 int lda2, const void* B2, int ldb2, int K2, const int* k2_dev, void* C, int ldc, int M, int N, int K,
+                                 const void* residual, int ldr, float alpha, void* stream) {
+  return gemm_fp8_launch(A8, lda, sa, B8, ldb, sb, A2, lda2, B2, ldb2, K2, C, ldc, M, N, K, residual, ldr, alpha, stream, true, k2_dev);
 }
+
 
 extern "C" int lhrs_gemm_fp8_nt(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, void* C, int ldc,
                                 int M, int N, int K, const void* residual, int ldr, float alpha, void* stream) {

@@ -105,10 +105,10 @@ __global__ __launch_bounds__(256) void outlier_cols_kernel(const bf16_t* __restr
   }
 }
 
-// idx[0 .. n) = the flagged columns in ascending order (n capped at `cap`), idx[n .. cap) = -1; meta[0] = n, meta[1] += 1 when more than `cap`
-// columns were flagged (the columns beyond the cap stay ZEROED in the int8 operand and are missing from the 16-bit product: the host
-// checks meta[1] where it logs).  One block of 1024 threads; K <= 1024 * 32.
-__global__ __launch_bounds__(1024) void compact_cols_kernel(const int* __restrict__ flags, int K, int* __restrict__ idx, int cap, int* __restrict__ meta) {
+// idx[0 .. n) = the flagged columns in ascending order, idx[n .. n_pad) = -1 with n_pad = n rounded up to 64 (the product appends whole
+// 64-column bf16 stages); meta[0] = n, meta[1] = n_pad.  idx holds K entries: there is no cap - LLM.int8 takes however many columns carry an
+// outlier into the 16-bit product (the inputs of down_proj routinely have hundreds).  One block of 1024 threads; K <= 1024 * 32.
+__global__ __launch_bounds__(1024) void compact_cols_kernel(const int* __restrict__ flags, int K, int* __restrict__ idx, int* __restrict__ meta) {
   __shared__ int cnt[1024];
   const int tid = threadIdx.x;
   const int per = (K + 1023) / 1024;
@@ -124,38 +124,38 @@ __global__ __launch_bounds__(1024) void compact_cols_kernel(const int* __restric
     __syncthreads();
   }
   int pos = cnt[tid] - c;
-  const int total = cnt[1023];
+  const int total = cnt[1023], npad = (total + 63) / 64 * 64;
   for (int k = k0; k < k1; ++k)
-    if (flags[k]) {
-      if (pos < cap) idx[pos] = k;
-      ++pos;
-    }
-  for (int j = total + tid; j < cap; j += 1024) idx[j] = -1;
-  if (tid == 0) {
-    meta[0] = min(total, cap);
-    if (total > cap) meta[1] += 1;
-  }
+    if (flags[k]) idx[pos++] = k;
+  for (int j = total + tid; j < npad; j += 1024) idx[j] = -1;   // npad <= K rounded up to 64 <= the idx buffer
+  if (tid == 0) { meta[0] = total; meta[1] = npad; }
 }
 
-// A2[t, j] = x[t, idx[j]] (0 where idx[j] < 0): the 16-bit operand of the outlier product, [M, cap] bf16
-__global__ __launch_bounds__(256) void gather_cols_x_kernel(const bf16_t* __restrict__ X, long ldx, const int* __restrict__ idx, int cap,
-                                                            bf16_t* __restrict__ out, long ldo, long total) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const long t = i / cap;
-  const int j = (int)(i - t * cap);
-  const int k = idx[j];
-  out[t * ldo + j] = k >= 0 ? X[t * ldx + k] : (bf16_t)0;
+// A2[t, j] = x[t, idx[j]] (0 where idx[j] < 0), j < n_pad = meta[1]: the 16-bit operand of the outlier product (grid-stride: the column
+// count is only known on the device)
+__global__ __launch_bounds__(256) void gather_cols_x_kernel(const bf16_t* __restrict__ X, long ldx, const int* __restrict__ idx,
+                                                            const int* __restrict__ meta, bf16_t* __restrict__ out, long ldo, long rows) {
+  const int npad = meta[1];
+  const long total = rows * npad;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long t = i / npad;
+    const int j = (int)(i - t * npad);
+    const int k = idx[j];
+    out[t * ldo + j] = k >= 0 ? X[t * ldx + k] : (bf16_t)0;
+  }
 }
-// B2[n, j] = CB[n, idx[j]] * scale[n] as bf16 (0 where idx[j] < 0): the dequantised weight columns, [N, cap] bf16
+// B2[n, j] = CB[n, idx[j]] * scale[n] as bf16 (0 where idx[j] < 0): the dequantised weight columns
 __global__ __launch_bounds__(256) void gather_cols_w_kernel(const int8_t* __restrict__ Q, long ldq, const float* __restrict__ scale,
-                                                            const int* __restrict__ idx, int cap, bf16_t* __restrict__ out, long ldo, long total) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const long n = i / cap;
-  const int j = (int)(i - n * cap);
-  const int k = idx[j];
-  out[n * ldo + j] = k >= 0 ? f2bf((float)Q[n * ldq + k] * scale[n]) : (bf16_t)0;
+                                                            const int* __restrict__ idx, const int* __restrict__ meta, bf16_t* __restrict__ out,
+                                                            long ldo, long rows) {
+  const int npad = meta[1];
+  const long total = rows * npad;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long n = i / npad;
+    const int j = (int)(i - n * npad);
+    const int k = idx[j];
+    out[n * ldo + j] = k >= 0 ? f2bf((float)Q[n * ldq + k] * scale[n]) : (bf16_t)0;
+  }
 }
 
 }  // namespace
@@ -175,25 +175,24 @@ extern "C" int lhrs_dequant_int8_rows(const void* Q, long ldq, const float* scal
   return 0;
 }
 
-// The activation side of one LLM.int8 product, four launches on `stream`:
-//   flags (int [K], zeroed by the caller's previous use - cleared here), idx (int [cap]) and meta (int [2]: n, overflow count) are workspaces;
-//   XQ int8 [M, ldq] + sx [M] (absmax of the non-outlier entries / 127); A2 bf16 [M, lda2 >= cap] = x[:, outlier columns];
-//   B2 bf16 [N, ldb2 >= cap] = dequantised weight columns.  cap % 64 == 0 (the product appends cap bf16 k-columns).
+// The activation side of one LLM.int8 product, on `stream`:
+//   flags (int [K]), idx (int [K rounded up to 64]) and meta (int [2]: n, n_pad) are workspaces;
+//   XQ int8 [M, ldq] + sx [M] (absmax of the non-outlier entries / 127); A2 bf16 [M, lda2] = x[:, outlier columns] and B2 bf16 [N, ldb2] =
+//   dequantised weight columns, n_pad = meta[1] columns of each written (both buffers hold up to K rounded up to 64 columns).
 extern "C" int lhrs_int8_prepare(const void* X, long ldx, int M, int K, float thr, const void* WQ, long ldwq, const float* wscale, int N,
-                                 void* XQ, long ldq, float* sx, int* flags, int* idx, int* meta, int cap, void* A2, long lda2, void* B2,
-                                 long ldb2, void* stream) {
-  LHRS_REQUIRE(M > 0 && K > 0 && N > 0 && K % 8 == 0 && K <= 32768 && ldx % 8 == 0 && ldq % 8 == 0 && cap > 0 && cap % 64 == 0 && lda2 >= cap &&
-                   ldb2 >= cap && thr > 0.f,
-               "int8_prepare: M=%d K=%d N=%d cap=%d", M, K, N, cap);
+                                 void* XQ, long ldq, float* sx, int* flags, int* idx, int* meta, void* A2, long lda2, void* B2, long ldb2,
+                                 void* stream) {
+  const int kpad = (K + 63) / 64 * 64;
+  LHRS_REQUIRE(M > 0 && K > 0 && N > 0 && K % 8 == 0 && K <= 32768 && ldx % 8 == 0 && ldq % 8 == 0 && lda2 >= kpad && ldb2 >= kpad && thr > 0.f,
+               "int8_prepare: M=%d K=%d N=%d lda2=%ld ldb2=%ld", M, K, N, lda2, ldb2);
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(flags, 0, (size_t)K * sizeof(int), s) != hipSuccess) LHRS_FAIL("int8_prepare: memset failed");
   hipLaunchKernelGGL(outlier_cols_kernel, dim3(cdiv(K / 8, 256), cdiv(M, 64)), dim3(256), 0, s, (const bf16_t*)X, ldx, M, K, thr, flags);
-  hipLaunchKernelGGL(compact_cols_kernel, dim3(1), dim3(1024), 0, s, (const int*)flags, K, idx, cap, meta);
+  hipLaunchKernelGGL(compact_cols_kernel, dim3(1), dim3(1024), 0, s, (const int*)flags, K, idx, meta);
   hipLaunchKernelGGL(quant_int8_rows_kernel, dim3(M), dim3(256), 0, s, (const bf16_t*)X, ldx, (int8_t*)XQ, ldq, sx, K, (const int*)flags, thr);
-  const long ta = (long)M * cap, tb = (long)N * cap;
-  hipLaunchKernelGGL(gather_cols_x_kernel, dim3(cdiv(ta, 256)), dim3(256), 0, s, (const bf16_t*)X, ldx, (const int*)idx, cap, (bf16_t*)A2, lda2, ta);
-  hipLaunchKernelGGL(gather_cols_w_kernel, dim3(cdiv(tb, 256)), dim3(256), 0, s, (const int8_t*)WQ, ldwq, wscale, (const int*)idx, cap, (bf16_t*)B2,
-                     ldb2, tb);
+  hipLaunchKernelGGL(gather_cols_x_kernel, dim3(2048), dim3(256), 0, s, (const bf16_t*)X, ldx, (const int*)idx, (const int*)meta, (bf16_t*)A2, lda2, (long)M);
+  hipLaunchKernelGGL(gather_cols_w_kernel, dim3(2048), dim3(256), 0, s, (const int8_t*)WQ, ldwq, wscale, (const int*)idx, (const int*)meta, (bf16_t*)B2,
+                     ldb2, (long)N);
   LHRS_CHECK_LAUNCH("int8_prepare");
   return 0;
 }

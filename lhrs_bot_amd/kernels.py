@@ -790,42 +790,50 @@ def dequant_int8_rows(Q, sc, out=None):
 
 
 class Int8Workspace:
-    """Device scratch of the LLM.int8 activation side: outlier flags per input feature, the compacted outlier column list (at most `cap`) and
-    meta = [columns found by the last call, number of calls that found more than `cap`]."""
+    """Device scratch of the LLM.int8 activation side: outlier flags per input feature, the compacted outlier column list, meta = [columns
+    found by the last call, that count rounded up to 64] and the persistent [N, KP + K] buffers of the dequantised outlier weight columns."""
 
-    def __init__(self, device, kmax: int = 32768, cap: int = 128, threshold: float = 6.0):
-        assert cap % 64 == 0
-        self.cap, self.threshold = cap, float(threshold)
-        self.flags = torch.zeros(kmax, device=device, dtype=torch.int32)
-        self.idx = torch.full((cap,), -1, device=device, dtype=torch.int32)
+    def __init__(self, device, kmax: int = 32768, threshold: float = 6.0):
+        self.threshold, self.kmax = float(threshold), (kmax + 63) // 64 * 64
+        self.flags = torch.zeros(self.kmax, device=device, dtype=torch.int32)
+        self.idx = torch.full((self.kmax,), -1, device=device, dtype=torch.int32)
         self.meta = torch.zeros(2, device=device, dtype=torch.int32)
+        self._b2 = {}
 
-    def overflowed(self) -> int:
-        """Host read (synchronises): how many products saw more outlier columns than `cap` since construction."""
-        return int(self.meta[1].item())
+    def b2(self, N: int, cols: int):
+        key = (N, cols)
+        if key not in self._b2:
+            self._b2[key] = torch.empty((N, cols), device=self.flags.device, dtype=torch.bfloat16)
+        return self._b2[key]
+
+    def last_outlier_columns(self):
+        """Host read (synchronises): the outlier feature columns of the most recent product, ascending."""
+        n = int(self.meta[0].item())
+        return self.idx[:n].tolist()
 
 
 def int8_linear(x, WQ, wscale, ws: Int8Workspace, *, residual=None, a2=None, b2=None, alpha: float = 1.0, out=None):
     """bitsandbytes MatMul8bitLt forward: y = (int8(x') . WQ^T) * sx * wscale + x[:, O] . dequant(WQ)[:, O]^T (+ a2 . b2^T) (+ residual), O = the
-    columns of x holding a value >= ws.threshold, x' = x with those columns zeroed.  x bf16 [M, K]; WQ int8 [N, K] + wscale [N] from
-    quant_int8_rows; (a2 [M, KP], b2 [N, KP]) an optional bf16 pair (LoRA update) riding on the same accumulators."""
+    columns of x holding a value >= ws.threshold (however many there are), x' = x with those columns zeroed.  x bf16 [M, K]; WQ int8 [N, K] +
+    wscale [N] from quant_int8_rows; (a2 [M, KP], b2 [N, KP]) an optional bf16 pair (LoRA update) riding on the same accumulators."""
     M, K = x.shape
     N = WQ.shape[0]
     KP = a2.shape[1] if a2 is not None else 0
-    K2 = KP + ws.cap
+    kpad = (K + 63) // 64 * 64
+    assert kpad <= ws.kmax, (K, ws.kmax)
     xq = torch.empty((M, K), device=x.device, dtype=torch.int8)
     sx = torch.empty(M, device=x.device, dtype=torch.float32)
-    A2 = torch.empty((M, K2), device=x.device, dtype=torch.bfloat16)
-    B2 = torch.empty((N, K2), device=x.device, dtype=torch.bfloat16)
+    A2 = torch.empty((M, KP + kpad), device=x.device, dtype=torch.bfloat16)
+    B2 = ws.b2(N, KP + kpad)
     if KP:
         A2[:, :KP].copy_(a2)
         B2[:, :KP].copy_(b2)
     L = _L()
     _lib.check(L.lhrs_int8_prepare(x.data_ptr(), x.stride(0), M, K, ws.threshold, WQ.data_ptr(), WQ.stride(0), wscale.data_ptr(), N,
-                                   xq.data_ptr(), xq.stride(0), sx.data_ptr(), ws.flags.data_ptr(), ws.idx.data_ptr(), ws.meta.data_ptr(), ws.cap,
-                                   A2.data_ptr() + 2 * KP, K2, B2.data_ptr() + 2 * KP, K2, _stream()), "int8_prepare")
+                                   xq.data_ptr(), xq.stride(0), sx.data_ptr(), ws.flags.data_ptr(), ws.idx.data_ptr(), ws.meta.data_ptr(),
+                                   A2.data_ptr() + 2 * KP, A2.stride(0), B2.data_ptr() + 2 * KP, B2.stride(0), _stream()), "int8_prepare")
     out = torch.empty((M, N), device=x.device, dtype=torch.bfloat16) if out is None else out
-    _lib.check(L.lhrs_gemm_int8_nt(xq.data_ptr(), xq.stride(0), sx.data_ptr(), WQ.data_ptr(), WQ.stride(0), wscale.data_ptr(), A2.data_ptr(), K2,
-                                   B2.data_ptr(), K2, K2, out.data_ptr(), out.stride(0), M, N, K, _p(residual),
-                                   residual.stride(0) if residual is not None else 0, float(alpha), _stream()), "gemm_int8_nt")
+    _lib.check(L.lhrs_gemm_int8_nt(xq.data_ptr(), xq.stride(0), sx.data_ptr(), WQ.data_ptr(), WQ.stride(0), wscale.data_ptr(), A2.data_ptr(),
+                                   A2.stride(0), B2.data_ptr(), B2.stride(0), KP, ws.meta.data_ptr() + 4, out.data_ptr(), out.stride(0), M, N, K,
+                                   _p(residual), residual.stride(0) if residual is not None else 0, float(alpha), _stream()), "gemm_int8_nt")
     return out

@@ -670,7 +670,7 @@ class TextModal:
                     L[k + "i8"], L[k + "i8s"] = hk.quant_int8_rows(L[k])
                     hk.dequant_int8_rows(L[k + "i8"], L[k + "i8s"], out=L[k])     # from here on the 16-bit weight IS the int8 one
                     L[k + "T"] = hk.transpose(L[k])
-            self._i8ws = hk.Int8Workspace(self.device, kmax=max(self.d, self.ff), cap=int(os.environ.get("LHRS_INT8_OUTLIER_CAP", "128")))
+            self._i8ws = hk.Int8Workspace(self.device, kmax=max(self.d, self.ff))
             self.base8, self.base_int8 = False, True
             return self
         self.quantize_fp8()
