@@ -15,7 +15,7 @@ import dataset_cases as DC  # noqa: E402
 
 def _config(tmp_path, **kw):
     from lhrs.CustomTrainer.utils import ConfigDict
-    c = ConfigDict(dict(stage=1, batch_size=2, workers=2, data_path=str(tmp_path / "corpus"), prompt_template="plain", output=str(tmp_path / "out"),
+    c = ConfigDict(dict(stage=1, batch_size=2, workers=1, data_path=str(tmp_path / "corpus"), prompt_template="plain", output=str(tmp_path / "out"),
                         accelerator="gpu", enable_amp=True, wandb=False, gpus=0, local_rank=0, rank=0, world_size=1, is_distribute=False,
                         inf_sampler=False, optimizer="adanp", lr=2e-4, wd=0.0, max_grad_norm=0.3, epochs=2, llama_layers=1, seed=322,
                         bf16=True, fp16=False, accumulation_steps=1, tune_rgb_bk=False, tune_rgb_pooler=True, tune_im_start=False,
