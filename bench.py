@@ -209,7 +209,7 @@ def timed_run(engine, batch, steps, warmup, world, lib, on_timed_start=None):
     for _ in range(warmup):
         loss = step()
     torch.cuda.synchronize()
-    _lib.check(lib.lhrs_gemm_profile_enable(16000), "gemm_profile_enable")
+    _lib.check(lib.lhrs_gemm_profile_enable(int(os.environ.get("LHRS_GEMM_PROFILE_SAMPLES", "16000"))), "gemm_profile_enable")   # 0: A/B of the event overhead
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
