@@ -209,6 +209,7 @@ def timed_run(engine, batch, steps, warmup, world, lib, on_timed_start=None):
     for _ in range(warmup):
         loss = step()
     torch.cuda.synchronize()
+    lib.lhrs_gemm_profile_stride(PROFILE_STRIDE)
     _lib.check(lib.lhrs_gemm_profile_enable(int(os.environ.get("LHRS_GEMM_PROFILE_SAMPLES", "16000"))), "gemm_profile_enable")   # 0: A/B of the event overhead
     if world > 1:
         torch.distributed.barrier()
@@ -235,6 +236,10 @@ def timed_run(engine, batch, steps, warmup, world, lib, on_timed_start=None):
     return dict(dt=dt, loss=loss, prof=list(prof), kinds=list(kinds), median_ms=median)
 
 
+# every 7th launch of each GEMM variant is bracketed by HIP events: timing every launch costs 1.0 % (micro-batch 30) / 2.2 % (micro-batch 8) of
+# the step in event-record idle time; 7 is coprime to the launch sequence's periods (2 forward, 3 backward plain launches per layer)
+PROFILE_STRIDE = int(os.environ.get("LHRS_GEMM_PROFILE_STRIDE", "7"))
+
 GEMM_KERNEL_DESC = ("gemm_nt_256s_kernel<ACT, 0, K2P> (256x256 tile, 16 waves) / gemm_nt_144s_kernel<ACT, 0> (144x256 tile, 12 waves; chosen per launch "
                     "when its rounds finish first): BK=64 double-buffered LDS stages via global_load_lds DMA, v_mfma_f32_16x16x32_bf16, persistent over "
                     "tiles; the launches with a fused SwiGLU / RoPE epilogue are timed separately under `variants`")
@@ -257,7 +262,7 @@ def roofline_block(prof, kinds, steps, B, S, scale_layers, sclk=None, watts=None
             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
             "traffic_note": "not measured in this run (PMC passes are separate rocprofv3 runs: profiles/*gemm_traffic.json)",
             "variants": variants, "all_variants_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else None,
-            "launches_timed": int(n_samp), "avg_launch_us": round(1e3 * ms / max(n_samp, 1), 2),
+            "launches_timed": int(n_samp), "timed_every_nth_launch": PROFILE_STRIDE, "avg_launch_us": round(1e3 * ms / max(n_samp, 1), 2),
             "sclk_mhz_during_timed_region": round(sclk) if sclk else None, "package_power_w": round(watts) if watts else None,
             "frac_of_peak_at_measured_clock": round(ach / (PEAK_BF16_TFLOPS * sclk / 2400.0), 4) if sclk else None,
             "gemm_flops_share_of_step": round(prof[4] / steps / (B * f_alg(S)), 3) if scale_layers == 1.0 else None}

@@ -142,6 +142,8 @@ int lhrs_gemm_set_min_tiles(int n);
  * enable(n) arms n event pairs (0 = off); read() -> {launches of the dominant <ACT,0> kernel, their ms, their flops, all GEMM launches,
  * all GEMM flops}; read_kinds() -> [4][3] = {launches, ms, flops} per epilogue variant (0 plain, 1 SwiGLU fwd, 2 SwiGLU bwd, 3 RoPE) */
 int lhrs_gemm_profile_enable(int max_samples);
+/* bracket only every n-th launch of each epilogue variant (default 1): the event records themselves cost stream time (1-2 % of a step) */
+int lhrs_gemm_profile_stride(int n);
 int lhrs_gemm_profile_read(double* out5_host);
 int lhrs_gemm_profile_read_kinds(double* out12_host);
 

@@ -1103,8 +1103,17 @@ struct GemmProf {
   int* kind = nullptr;        // cap: epilogue variant of the sampled launch (0 plain <ACT,0>, 1 SwiGLU fwd, 2 SwiGLU bwd, 3 RoPE)
   double total_flops_all = 0; // every GEMM launch while enabled (sampled or not)
   long launches_all = 0;
+  int stride = 1;             // every stride-th launch of each epilogue variant is bracketed (lhrs_gemm_profile_stride)
+  long seen[4] = {0, 0, 0, 0};
+  bool take(int kind) { return (seen[kind]++ % stride) == 0; }
 } g_prof;
 }  // namespace
+
+// Sampling stride of the live timing: the two event records around a launch cost the stream ~3 us of idle time each (measured: timing
+// EVERY dominant launch slows the step by 1.0 % at micro-batch 30 and 2.2 % at micro-batch 8), so bench.py brackets every 7th launch of
+// each variant - 7 is coprime to the period of the launch sequence (2 plain launches per layer forward, 3 backward), so the sample keeps
+// the shape mix.  Default 1 (every launch).
+extern "C" int lhrs_gemm_profile_stride(int n) { g_prof.stride = n > 0 ? n : 1; return 0; }
 
 extern "C" int lhrs_gemm_profile_enable(int max_samples) {
   if (g_prof.ev) {
@@ -1114,6 +1123,7 @@ extern "C" int lhrs_gemm_profile_enable(int max_samples) {
   }
   g_prof.on = max_samples > 0; g_prof.cap = max_samples > 0 ? max_samples : 0; g_prof.used = 0;
   g_prof.total_flops_all = 0; g_prof.launches_all = 0;
+  for (int k = 0; k < 4; ++k) g_prof.seen[k] = 0;
   if (g_prof.on) {
     g_prof.ev = new hipEvent_t[2 * g_prof.cap];
     g_prof.flops = new double[g_prof.cap];
@@ -1316,7 +1326,7 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   if (g_prof.on) {
     g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * (K + K2);
     const bool dominant = use256 && g_gemm_allow_256 == 2 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128;
-    if (dominant && g_prof.used < g_prof.cap) {  // time exactly the launches rocprof lists as gemm_nt_256s_kernel<ACT, 0, K2P>
+    if (dominant && g_prof.used < g_prof.cap && g_prof.take(0)) {  // time the launches rocprof lists as gemm_nt_256s / 144s_kernel<ACT, 0 ...>
       slot = g_prof.used++;
       g_prof.flops[slot] = 2.0 * M * N * (K + K2);
       g_prof.kind[slot] = 0;
@@ -1386,7 +1396,7 @@ extern "C" int lhrs_gemm_swiglu_fusable(int M, int ff, int K_fwd, int K_bwd, int
 static int prof_count(int M, int N, int K, int kind, hipStream_t s) {
   if (!g_prof.on) return -1;
   g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * K;
-  if (g_prof.used >= g_prof.cap) return -1;
+  if (g_prof.used >= g_prof.cap || !g_prof.take(kind)) return -1;
   const int slot = g_prof.used++;
   g_prof.flops[slot] = 2.0 * M * N * K; g_prof.kind[slot] = kind;
   (void)hipEventRecord(g_prof.ev[2 * slot], s);
