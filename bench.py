@@ -376,7 +376,7 @@ def main():
                             comm_dtype=getattr(torch, a.comm_dtype))
     batch = make_batch(B, T, dev, seed=322 + rank)  # reference seed convention (main_pretrain_stage1.py:281-287)
 
-    smi = _SmiSampler() if rank == 0 else None
+    smi = _SmiSampler() if rank == 0 and os.environ.get("LHRS_BENCH_NO_SMI") != "1" else None   # LHRS_BENCH_NO_SMI=1: A/B of the sampler's own cost
     run = timed_run(engine, batch, a.steps, a.warmup, world, lib, on_timed_start=smi.start if smi is not None else None)
     sclk, watts = smi.stop() if smi is not None else (None, None)
     dt, loss, prof, kinds = run["dt"], run["loss"], run["prof"], run["kinds"]
