@@ -156,10 +156,12 @@ def _make_rs5m_shards(root, n_shards=4, per_shard=5):
     return truth
 
 
-def test_rs5m_tar_shards_grouping_split_and_batches(tmp_path):
+def test_rs5m_tar_shards_grouping_split_and_batches(tmp_path, monkeypatch):
     """RS5MDataset (cap_dataset.py:649-775 restated on `tarfile`): brace expansion of the shard pattern, key grouping, every sample of
     every shard exactly once per epoch across (rank, worker) splits, captions normalised and tokenised as a one-turn conversation about
     the image, batches of exactly `batch_size` through the supervised collator (partial batches dropped)."""
+    from lhrs_bot_amd import conversation as conversation_lib
+    monkeypatch.setattr(conversation_lib, "default_conversation", conversation_lib.default_conversation)   # the datasets re-bind this module global
     root = str(tmp_path / "RS5M")
     truth = _make_rs5m_shards(root)
     assert DS.expand_braces("x/{pub11,rs3}-train-{0000..0031}.tar")[33] == "x/rs3-train-0001.tar"
