@@ -265,9 +265,6 @@ int lhrs_rope_kv_append(void* qkv, long ld, void* kcache, void* vcache, const fl
 int lhrs_decode_advance(int* state, int* desc, int* pos, int B, int max_ctx, int step_inc, void* stream);
 int lhrs_kv_append(const void* qkv, long ld, void* kcache, void* vcache, const int* pos, int B, int d, int max_ctx, void* stream);
 int lhrs_decode_emit(const long* next_ids, int* tok32, long* out_ids, int* state, int B, int max_new, void* stream);
-/* touch one dword per 64 B of [ptr, ptr + bytes) with `blocks` workgroups of 256 threads: pulls a weight into the 256 MB Infinity Cache ahead of
- * the GEMV that streams it (launched on a second stream of the captured token graph; the data is discarded) */
-int lhrs_prefetch(const void* ptr, long bytes, int blocks, void* stream);
 int lhrs_graph_begin(void* stream);
 int lhrs_graph_end(void* stream, void** exec_out);
 int lhrs_graph_launch(void* exec, void* stream);

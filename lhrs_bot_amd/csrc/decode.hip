@@ -870,34 +870,6 @@ extern "C" int lhrs_kv_append(const void* qkv, long ld, void* kcache, void* vcac
   return 0;
 }
 
-// ---- weight prefetch into the memory-side Infinity Cache (256 MB) ---------------------------------------------------------------------------
-// A batch-1 token is 129 dependent weight-streaming launches; each pays one HBM round trip before its first bytes and one after its last
-// request (~2.7 us of a 7-30 us launch) during which HBM idles, and a GEMV whose weights already sit in the Infinity Cache streams 13-17 %
-// faster (tools/gemv_bench.py: 33.5 MB at 6.7 vs 7.7 us, 100 MB at 17.2 vs 20.6 us).  lhrs_prefetch touches one dword per 64 B of a weight
-// (plain loads: they allocate in the memory-side cache; the data is discarded) and is launched on a SECOND stream of the captured token graph,
-// one launch ahead of the GEMV that will read that weight - HBM keeps streaming through the fill / drain gaps and the attention launches.
-__device__ unsigned g_prefetch_sink;
-__global__ __launch_bounds__(256) void prefetch_kernel(const unsigned* __restrict__ p, long n64) {   // n64 = number of 64-byte segments
-  unsigned acc = 0;
-  const long stride = (long)gridDim.x * 256;
-  long i = (long)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 7 * stride < n64; i += 8 * stride) {
-    unsigned v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = p[(i + u * stride) * 16];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc ^= v[u];
-  }
-  for (; i < n64; i += stride) acc ^= p[i * 16];
-  if (acc == 0x9E3779B1u) g_prefetch_sink = acc;   // keeps the loads alive; practically never taken
-}
-extern "C" int lhrs_prefetch(const void* ptr, long bytes, int blocks, void* stream) {
-  LHRS_REQUIRE(ptr != nullptr && bytes >= 64 && blocks > 0, "prefetch: bytes=%ld blocks=%d", bytes, blocks);
-  hipLaunchKernelGGL(prefetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned*)ptr, bytes / 64);
-  LHRS_CHECK_LAUNCH("prefetch");
-  return 0;
-}
-
 // ---- thin hipGraph wrappers: capture the launches enqueued on `stream` between begin/end, replay with launch ----
 extern "C" int lhrs_graph_begin(void* stream) {
   hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);

@@ -686,12 +686,6 @@ def decode_emit(next_ids, tok32, out_ids, state, B, max_new):
                "decode_emit")
 
 
-def prefetch(t, max_bytes: int = 1 << 40, blocks: int = 256):
-    """Pull (the first max_bytes of) a tensor into the Infinity Cache on the CURRENT stream (lhrs_prefetch)."""
-    n = min(t.numel() * t.element_size(), max_bytes) // 64 * 64
-    _lib.check(_L().lhrs_prefetch(t.data_ptr(), n, blocks, _stream()), "prefetch")
-
-
 class HipGraph:
     """hipGraph capture / replay of the launches enqueued on the current (non-default) HIP stream."""
 

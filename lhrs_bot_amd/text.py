@@ -743,61 +743,22 @@ class TextModal:
                 x_in, pro = s.actb, hk.PRO_NONE
             hk.gemv_fused(w, x_in, out, K, wscale=sc, prologue=pro, norm_w=norm_w, eps=self.eps, residual=residual, out_f32=out_f32)
 
-        # Weight prefetch on a second stream of the token graph (LHRS_DECODE_PREFETCH=0 switches it off; batch 1-2 only - larger batches share
-        # one weight stream over more arithmetic and are not launch-gap bound): while GEMV j streams, the weight of GEMV j + 1 is pulled into
-        # the 256 MB Infinity Cache, so HBM does not idle through the fill / drain of the 129 dependent launches and GEMV j + 1 starts on
-        # cache hits.  At most PF_MAX bytes per weight so that the weight being read and the one being fetched fit the cache together.
-        pf_on = os.environ.get("LHRS_DECODE_PREFETCH", "1") != "0" and B <= 2
-        PF_MAX = int(os.environ.get("LHRS_DECODE_PREFETCH_MB", "110")) << 20
-        if pf_on:
-            s.pf_stream = torch.cuda.Stream(device=dev)
-            s.pf_events = []
-
-        def stream_tensor(w):  # the tensor a GEMV actually reads (packed copies carry it in .data)
-            return w.data if hasattr(w, "data") and not torch.is_tensor(w) else w
-
         def enqueue():
             hk.decode_advance(s.state, s.desc, s.pos, B, max_ctx, 1)
             hk.gather_rows(self.p["embed"], s.tok32, out=s.x)
             x, x2 = s.x, s.x2
-            lmw, lmsc = (self.p["lm_head8p"], self.p["lm_head8s"]) if fp8 else (self.p["lm_headp"] if packed16 else self.p["lm_head"], None)
-            ops = []   # (weight, scale) of every streaming launch of the token, in order
-            for L in self.p["layers"]:
-                ops += [W(L, "qkv_w"), W(L, "o_w"), W(L, "gu_w"), W(L, "down_w")]
-            ops.append((lmw, lmsc))
-            main = torch.cuda.current_stream()
-            k = [0]
-
-            def ahead():  # called right BEFORE streaming launch k goes out on the main stream: fetch the weight of launch k + 1 beside it
-                j = k[0]
-                k[0] += 1
-                if not pf_on or j + 1 >= len(ops):
-                    return
-                ev = torch.cuda.Event()
-                ev.record(main)                       # = launch j - 1 has finished
-                s.pf_events.append(ev)
-                with torch.cuda.stream(s.pf_stream):
-                    s.pf_stream.wait_event(ev)
-                    hk.prefetch(stream_tensor(ops[j + 1][0]), PF_MAX)
-
             for L, (kc, vc) in zip(self.p["layers"], caches):
-                ahead()
                 lin(*W(L, "qkv_w"), x, s.qkv, d, hk.PRO_RMSNORM, L["ln1_w"])
                 if hd == 128:  # RoPE + KV append + attention over the cache in one launch
                     hk.decode_attn(s.qkv, kc, vc, self.cos, self.sin, s.pos, s.o, B, H, hd, max_ctx, scale, key_mask=kmask)
                 else:
                     hk.rope_kv_append(s.qkv, kc, vc, self.cos, self.sin, s.pos, B, H, hd, max_ctx)
                     hk.attn_fwd(s.qkv[:, :d], kc, vc, s.o, None, s.desc, B, H, hd, 1, 1 << 30, 64, True, scale, key_mask=kmask)
-                ahead()
                 lin(*W(L, "o_w"), s.o, x2, d, residual=x)
-                ahead()
                 lin(*W(L, "gu_w"), x2, s.gu, d, hk.PRO_RMSNORM, L["ln2_w"])
-                ahead()
                 lin(*W(L, "down_w"), s.gu, x, ff, hk.PRO_SWIGLU, residual=x2)
-            ahead()
-            lin(lmw, lmsc, x, s.logits, d, hk.PRO_RMSNORM, self.p["norm_w"], out_f32=True)
-            if pf_on:  # join: the captured graph (and an eager step) ends with the prefetch stream folded back into the main one
-                main.wait_stream(s.pf_stream)
+            w, sc = (self.p["lm_head8p"], self.p["lm_head8s"]) if fp8 else (self.p["lm_headp"] if packed16 else self.p["lm_head"], None)
+            lin(w, sc, x, s.logits, d, hk.PRO_RMSNORM, self.p["norm_w"], out_f32=True)
 
         s.enqueue = enqueue
         s.graph = None
