@@ -303,6 +303,7 @@ def main():
                          "frozen (BASELINE configs[3]); 2: LoRA r=128 on every linear + projector, AdamW (Config/multi_modal_stage2.yaml)")
     ap.add_argument("--comm-dtype", default="float32", choices=["float32", "bfloat16"],
                     help="dtype of the gradient all-reduce (N > 1): bfloat16 = 160 MB per step at stage 1, what DeepSpeed bf16 ZeRO-2 moves (SURVEY §8e)")
+    ap.add_argument("--base8", default="int8", choices=["int8", "e4m3"], help="--bits 8: scheme of the 8-bit frozen base (text.py::quantize_base)")
     ap.add_argument("--bits", type=int, default=16, choices=[16, 8],
                     help="stages 2/3 only: 8 = frozen decoder linears in e4m3 (the reference's `bits: 8` base weights)")
     a = ap.parse_args()
@@ -370,7 +371,7 @@ def main():
         else:
             model.enable_lora(r=128, alpha=256, dropout=0.05)  # Config/multi_modal_stage2.yaml:81-86 (train mode: dropout active)
         if a.bits == 8:
-            model.text.quantize_base(8)
+            model.text.quantize_base(8, a.base8)   # "int8": the reference's LLM.int8 arithmetic (what the YAML key selects); "e4m3": the faster MI355X-native base
         model.prepare_for_training(freeze_text=False, tune_rgb_pooler=a.stage == 2)
         engine = LHRSEngine(model, optimizer="adamw", lr=1e-4 if a.stage == 3 else 2e-4, weight_decay=0.0, max_grad_norm=1.0,
                             comm_dtype=getattr(torch, a.comm_dtype))
@@ -400,7 +401,7 @@ def main():
             "metric": ("stage-1 pretrain samples/sec (224^2 image + 128-tok caption)" if a.stage == 1 else
                        f"stage-{a.stage} LoRA train samples/sec (224^2 image + 128-tok sequence)"), "value": round(sps, 3), "unit": "samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "ms_per_step_median": round(run["median_ms"], 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.bits == 16 or a.stage == 1 else "e4m3 base weights + bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.bits == 16 or a.stage == 1 else ("int8 base weights (LLM.int8) + bf16" if a.base8 == "int8" else "e4m3 base weights + bf16"), "data": "synthetic",
             "config": {"workload": (("BASELINE configs[1]: stage-1 projector-only" if world == 1 else "BASELINE configs[2]: stage-1 projector-only, DDP") if a.stage == 1
                                     else ("BASELINE configs[3]: stage-3 SFT, LoRA r=8 on q,k,v,o" if a.stage == 3 else "stage-2 (Config/multi_modal_stage2.yaml): LoRA r=128 on all linears + projector"))
                                    + f", CLIP ViT-L/14@224 + AttnPooler + LLaMA2-7B ({a.llama_layers} layers), S={S}, random-init weights",
