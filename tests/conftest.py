@@ -28,3 +28,14 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _restore_default_conversation():
+    """`lhrs.Dataset.conversation.default_conversation` is a MODULE GLOBAL that the datasets re-bind to their prompt template (the reference does
+    the same: cap_dataset.py:343, 397, 664); a test that builds a "plain" stage-1 dataset must not change what a later test's evaluation prompt
+    looks like."""
+    from lhrs_bot_amd import conversation as conversation_lib
+    saved = conversation_lib.default_conversation
+    yield
+    conversation_lib.default_conversation = saved
