@@ -134,6 +134,16 @@ int lhrs_int8_prepare(const void* X, long ldx, int M, int K, float thr, const vo
 int lhrs_gemm_int8_nt(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, const void* A2, int lda2,
                       const void* B2, int ldb2, int K2, const int* k2_dev, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
                       float alpha, void* stream);
+/* ---- 4-bit base storage (the reference's `bits: 4`, `quant_type: nf4 | fp4`, `double_quant`: lhrs/models/text_modal.py:91-107 ->
+ * bitsandbytes quantize_4bit / dequantize_4bit, 0.41 series).  Blocks of 64 consecutive elements: absmax + 16-level codes, two per byte (first
+ * element in the high nibble); lhrs_dequant4_blocks expands table[code] * absmax back into the bf16 weight that every product reads (bitsandbytes
+ * computes y = x . dequant(W)^T in 16 bit, forward and backward).  double_quant: the caller subtracts the mean of absmax and stores the rest through
+ * lhrs_quant8_dynamic (blocks of 256 values, the package's sorted 256-entry "dynamic" table passed as code256, nearest entry) /
+ * lhrs_dequant8_dynamic (code256[q] * absmax2 + offset). */
+int lhrs_quant4_blocks(const void* W, long n, int fp4, void* packed, float* absmax, void* stream);
+int lhrs_dequant4_blocks(const void* packed, const float* absmax, long n, int fp4, void* W, void* stream);
+int lhrs_quant8_dynamic(const float* x, long n, const float* code256, void* q, float* absmax2, void* stream);
+int lhrs_dequant8_dynamic(const void* q, const float* absmax2, long n, const float* code256, float offset, float* out, void* stream);
 /* kernel A/B tests only: fewest 64x128 tiles for which the small-tile GEMM takes 64x128 tiles instead of 64x64 (default 256) */
 int lhrs_gemm_set_small_thresh(int n);
 /* kernel A/B tests only: fewest 256x256 tiles for which lhrs_gemm_bf16_nt picks the big-tile kernel (default 128) */

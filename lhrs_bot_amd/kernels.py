@@ -789,6 +789,81 @@ def dequant_int8_rows(Q, sc, out=None):
     return out
 
 
+# --------------------------------------------------------------------------------------------- 4-bit base storage (bits: 4)
+def dynamic_map_8bit() -> torch.Tensor:
+    """The sorted 256-entry table of bitsandbytes' signed "dynamic" 8-bit data type (functional.create_dynamic_map(signed=True,
+    max_exponent_bits=7, total_bits=8)) that `double_quant` stores the absmax statistics in: for i = 0..6 the 2^i midpoints of
+    linspace(0.1, 1, 2^i + 1) scaled by 10^(i - 6), both signs, plus 0 and 1.  fp32 CPU tensor."""
+    data = []
+    for i in range(7):
+        b = torch.linspace(0.1, 1, 2 ** i + 1)
+        means = (b[:-1] + b[1:]) / 2.0
+        data += ((10 ** (-6 + i)) * means).tolist()
+        data += (-(10 ** (-6 + i)) * means).tolist()
+    data += [0.0, 1.0]
+    assert len(data) == 256
+    return torch.tensor(sorted(data), dtype=torch.float32)
+
+
+_DYN_MAP = {}
+
+
+def _dyn_map(device) -> torch.Tensor:
+    key = str(device)
+    if key not in _DYN_MAP:
+        _DYN_MAP[key] = dynamic_map_8bit().to(device)
+    return _DYN_MAP[key]
+
+
+def quant4_blocks(W, quant_type: str = "nf4", double_quant: bool = True):
+    """bitsandbytes quantize_4bit of ONE weight (a contiguous bf16 [N, K] tensor or row range, N*K % 64 == 0) -> state dict:
+    packed uint8 [N*K/2], and either absmax fp32 [N*K/64] or (double_quant) its 8-bit form: qabsmax uint8, absmax2 fp32, offset."""
+    if quant_type not in ("nf4", "fp4"):
+        raise ValueError(f"quant_type {quant_type!r}: 'nf4' or 'fp4' (bitsandbytes bnb_4bit_quant_type)")
+    _req(W, torch.bfloat16, "quant4_blocks weight")
+    if not W.is_contiguous():
+        raise ValueError("quant4_blocks: the weight (row range) must be contiguous")
+    n = W.numel()
+    packed = torch.empty(n // 2, device=W.device, dtype=torch.uint8)
+    absmax = torch.empty(n // 64, device=W.device, dtype=torch.float32)
+    _lib.check(_L().lhrs_quant4_blocks(W.data_ptr(), n, int(quant_type == "fp4"), packed.data_ptr(), absmax.data_ptr(), _stream()), "quant4_blocks")
+    st = dict(packed=packed, quant_type=quant_type, shape=tuple(W.shape))
+    if not double_quant:
+        st["absmax"] = absmax
+        return st
+    nb = absmax.numel()
+    offset = float(absmax.double().mean().float())   # the package: absmax.mean() in fp32; the fp64 sum makes the value independent of the reduction order
+    rest = absmax - offset
+    q = torch.empty(nb, device=W.device, dtype=torch.uint8)
+    absmax2 = torch.empty((nb + 255) // 256, device=W.device, dtype=torch.float32)
+    _lib.check(_L().lhrs_quant8_dynamic(rest.data_ptr(), nb, _dyn_map(W.device).data_ptr(), q.data_ptr(), absmax2.data_ptr(), _stream()), "quant8_dynamic")
+    st.update(qabsmax=q, absmax2=absmax2, offset=offset)
+    return st
+
+
+def absmax_of(st) -> torch.Tensor:
+    """The fp32 block absmax a 4-bit state dequantises with (double_quant: code[q] * absmax2 + offset)."""
+    if "absmax" in st:
+        return st["absmax"]
+    q = st["qabsmax"]
+    out = torch.empty(q.numel(), device=q.device, dtype=torch.float32)
+    _lib.check(_L().lhrs_dequant8_dynamic(q.data_ptr(), st["absmax2"].data_ptr(), q.numel(), _dyn_map(q.device).data_ptr(), float(st["offset"]),
+                                          out.data_ptr(), _stream()), "dequant8_dynamic")
+    return out
+
+
+def dequant4_blocks(st, out=None):
+    """bitsandbytes dequantize_4bit: table[code] * absmax -> bf16, into `out` (contiguous, same element count) or a new tensor of the stored shape."""
+    packed = st["packed"]
+    n = packed.numel() * 2
+    out = torch.empty(st["shape"], device=packed.device, dtype=torch.bfloat16) if out is None else out
+    if out.numel() != n or not out.is_contiguous() or out.dtype != torch.bfloat16:
+        raise ValueError("dequant4_blocks: `out` must be a contiguous bf16 tensor with the element count of the state")
+    a = absmax_of(st)
+    _lib.check(_L().lhrs_dequant4_blocks(packed.data_ptr(), a.data_ptr(), n, int(st["quant_type"] == "fp4"), out.data_ptr(), _stream()), "dequant4_blocks")
+    return out
+
+
 class Int8Workspace:
     """Device scratch of the LLM.int8 activation side: outlier flags per input feature, the compacted outlier column list, meta = [columns
     found by the last call, that count rounded up to 64] and the persistent [N, KP + K] buffers of the dequantised outlier weight columns."""

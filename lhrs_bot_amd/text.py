@@ -216,6 +216,7 @@ class TextModal:
         self.lora: Optional[LoraStore] = None
         self.base8 = False  # frozen decoder linears in e4m3 (quantize_base(8, "e4m3"))
         self.base_int8 = False  # frozen decoder linears as LLM.int8 (quantize_base(8, "int8"): the reference's bitsandbytes arithmetic)
+        self.base4 = None  # (quant_type, double_quant) once the decoder linears are bitsandbytes 4-bit storage (quantize_base(4, ...))
         self._i8ws = None
         # training forward: run the last decoder layer's post-attention half on the supervised rows only when they are one contiguous
         # range per sequence (_layer_fwd `tail`); LHRS_TAIL_ROWS_ONLY=0 / attribute False: every row, as HF does
@@ -266,11 +267,15 @@ class TextModal:
                 L[wname[gname] + "T"] = hk.transpose(W)
             self._drop_derived(L)
         requant = "e4m3" if self.base8 else ("int8" if self.base_int8 else None)
+        base4 = getattr(self, "base4", None)
         self.lora, self._merged_cache, self.base8, self.base_int8 = None, None, False, False
         if requant:
             self.quantize_base(8, requant)   # the 8-bit base is a function of the (now merged) weights
+        elif base4:
+            self.quantize_base(4, quant_type=base4[0], double_quant=base4[1])   # peft re-quantises a merged Linear4bit the same way
 
-    DERIVED_SUFFIXES = ("p", "8", "8s", "8p", "i8", "i8s")   # decode re-tilings and e4m3 copies of a weight `<name>` / `<name>T`, rebuilt lazily from it
+    _W4_PARTS = {"qkv_w": 3, "o_w": 1, "gu_w": 2, "down_w": 1}   # reference Linears per fused weight (row-concatenated): 4-bit statistics are per Linear
+    DERIVED_SUFFIXES = ("p", "8", "8s", "8p", "i8", "i8s", "q4")   # decode re-tilings and e4m3 copies of a weight `<name>` / `<name>T`, rebuilt lazily from it
 
     def _drop_derived(self, L) -> None:
         """Forget every tensor that was computed FROM a decoder weight of layer dict `L` (decode re-tilings, e4m3 copies): after the weight
@@ -640,7 +645,7 @@ class TextModal:
                 L[k + "p"] = hk.repack_bf16_mfma(L[k])
         self.p["lm_headp"] = hk.repack_bf16_mfma(self.p["lm_head"])
 
-    def quantize_base(self, bits: int = 8, scheme: str = "e4m3"):
+    def quantize_base(self, bits: int = 8, scheme: str = "e4m3", quant_type: str = "nf4", double_quant: bool = True):
         """`bits: 8` of Config/multi_modal_stage{2,3}.yaml (text_modal.py:91-131: the reference loads the frozen LLaMA through bitsandbytes
         LLM.int8 for stages 2/3; lm_head stays 16-bit there and here).  Two schemes:
 
@@ -651,15 +656,34 @@ class TextModal:
           GEMMs read them).  Parity: oracle/int8_oracle.py (bitsandbytes itself is not installed: unpinned against the package).
         * "e4m3" - MI355X-native fast path: OCP e4m3 copies with one fp32 scale per output row - of W for the forward product and of W^T for
           the dX product - on the 2x-rate block-scaled MFMA, activations / gradients quantised per row on the fly, no outlier split.
-        LoRA adapters, norms, attention and the loss stay bf16 / fp32 in both."""
-        if bits == 4:  # text_modal.py:91-107 `load_in_4bit` (nf4 storage, 16-bit compute): gfx950 has no 4-bit bf16-compute MFMA path worth
-            import logging  # a kernel family here; the 8-bit base is the closest resident format and is what runs
-            logging.getLogger("train").warning("bits=4 (bitsandbytes nf4) is run as the 8-bit base: 4-bit storage is not built")
-            bits = 8
+        LoRA adapters, norms, attention and the loss stay bf16 / fp32 in both.
+
+        `bits: 4` (text_modal.py:91-107 `load_in_4bit`, `quant_type` nf4 | fp4, `double_quant`): bitsandbytes' Linear4bit stores 4-bit codes
+        per block of 64 and computes every product on the DEquantised weight in the compute dtype, forward and backward.  Here each
+        reference Linear (q, k, v, o, gate, up, down - the statistics of `double_quant` are per Linear) is quantised by `hk.quant4_blocks`,
+        the codes and statistics stay beside the weight (`<name>q4`), and the bf16 weight BECOMES `hk.dequant4_blocks` of them: the ordinary
+        bf16 kernels then run the arithmetic bitsandbytes runs.  Parity: oracle/nf4_oracle.py (unpinned against the package)."""
+        if bits == 4:
+            for L in self.p["layers"]:
+                self._drop_derived(L)
+                for k, parts in self._W4_PARTS.items():
+                    W = L[k]
+                    rows = W.shape[0] // parts
+                    states = []
+                    for i in range(parts):
+                        sub = W[i * rows:(i + 1) * rows]
+                        st = hk.quant4_blocks(sub, quant_type, double_quant)
+                        hk.dequant4_blocks(st, out=sub)              # from here on the 16-bit weight IS the 4-bit one
+                        states.append(st)
+                    L[k + "q4"] = states
+                    L[k + "T"] = hk.transpose(W)
+            self.base8, self.base_int8, self.base4 = False, False, (quant_type, bool(double_quant))
+            return self
         if bits not in (8, 16):
-            raise NotImplementedError(f"bits={bits}: 16 (bf16), 8 (8-bit base weights) or 4 (run as 8)")
+            raise NotImplementedError(f"bits={bits}: 16 (bf16), 8 (LLM.int8 / e4m3 base weights) or 4 (nf4 / fp4 storage)")
         if scheme not in ("e4m3", "int8"):
             raise ValueError(f"quantize_base scheme {scheme!r}: 'int8' (LLM.int8, the reference's) or 'e4m3'")
+        self.base4 = None
         if bits == 16:
             self.base8 = self.base_int8 = False
             return self

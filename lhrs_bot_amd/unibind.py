@@ -65,10 +65,13 @@ class UniBind:
         if dt is not None and str(dt) not in ("bfloat16", "bf16"):
             log.info("config dtype=%s: frozen towers are stored and multiplied in bf16 (fp32 accumulation); the key selects no other path", dt)
         if self.bits in (4, 8):
-            log.info("config bits=%d: frozen decoder linears kept as %s; double_quant=%s / quant_type=%s are bitsandbytes 4-bit options "
-                     "(text_modal.py:97-101) and do not apply to the 8-bit base", self.bits,
-                     "LLM.int8 rows + absmax factors, int8 MFMA + 16-bit outlier columns (LHRS_BASE8=e4m3: e4m3 rows on the fp8 MFMA)" if self.bits == 8 else "the 8-bit base (no 4-bit MFMA path)",
-                     _get(config, "double_quant", None), _get(config, "quant_type", None))
+            if self.bits == 8:
+                log.info("config bits=8: frozen decoder linears kept as LLM.int8 rows + absmax factors, int8 MFMA + 16-bit outlier columns "
+                         "(LHRS_BASE8=e4m3: e4m3 rows on the fp8 MFMA); double_quant=%s / quant_type=%s are bitsandbytes 4-bit options "
+                         "(text_modal.py:97-101) and do not apply to the 8-bit base", _get(config, "double_quant", None), _get(config, "quant_type", None))
+            else:
+                log.info("config bits=4: frozen decoder linears stored as %s codes per block of 64 (double_quant=%s), every product on the "
+                         "dequantised bf16 weight - bitsandbytes' Linear4bit arithmetic", _get(config, "quant_type", "nf4"), _get(config, "double_quant", True))
 
     # ------------------------------------------------------------------ reference surface
     def prepare_for_training(self, freeze_vision=True, freeze_text=True, tune_rgb_pooler=True, model_path=None,
@@ -93,11 +96,13 @@ class UniBind:
         self.train()
         if model_path is not None:
             self.custom_load_state_dict(model_path)
-        if self.bits in (4, 8) and not (self.text.base8 or self.text.base_int8) and self.text.p.get("layers"):
+        if self.bits in (4, 8) and not (self.text.base8 or self.text.base_int8 or getattr(self.text, "base4", None)) and self.text.p.get("layers"):
             # the YAML's `bits: 8`: LLM.int8 storage and arithmetic of the (now loaded) frozen decoder linears, as the reference runs stages 2/3;
-            # LHRS_BASE8=e4m3 selects the faster MI355X-native 8-bit base instead (a deviation: no outlier decomposition)
+            # LHRS_BASE8=e4m3 selects the faster MI355X-native 8-bit base instead (a deviation: no outlier decomposition).
+            # `bits: 4`: bitsandbytes 4-bit storage with the YAML's quant_type / double_quant (text_modal.py:97-101)
             import os
-            self.text.quantize_base(self.bits, os.environ.get("LHRS_BASE8", "int8"))  # the YAML's `bits: 8`: e4m3 copies of the (now loaded) frozen decoder linears
+            self.text.quantize_base(self.bits, os.environ.get("LHRS_BASE8", "int8"), quant_type=str(_get(self.config, "quant_type", "nf4")),
+                                    double_quant=bool(_get(self.config, "double_quant", True)))
 
     def train(self):
         self.training = True

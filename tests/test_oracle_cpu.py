@@ -279,3 +279,64 @@ def test_lora_restatement_pinned_to_the_reference_llama_with_merged_weights(name
             assert abs(B.grad.norm().item() - float(z[f"dB_norm.{l}.{pr}"])) < 2e-4 * float(z[f"dB_norm.{l}.{pr}"]), (l, pr)
             assert rel(A.grad if full else A.grad[::16, ::16], z[f"dA.{l}.{pr}"]) < 5e-4, (l, pr)
             assert rel(B.grad if full else B.grad[::16, ::16], z[f"dB.{l}.{pr}"]) < 5e-4, (l, pr)
+
+
+# ---- 4-bit storage (bits: 4): oracle/nf4_oracle.py against the published constructions ------------------------------------------------------
+def test_nf4_table_is_the_published_normal_float_construction():
+    """QLoRA Appendix E / bitsandbytes functional.create_normal_map(offset=0.9677083): 8 positive quantiles norm.ppf(linspace(offset, 0.5, 9)[:-1]),
+    7 negative ones -norm.ppf(linspace(offset, 0.5, 8)[:-1]), an exact 0, normalised by the largest.  The hard-coded NF4 levels of the oracle
+    (and of quant4.hip) must be that table, the decision thresholds its midpoints; FP4: sign + {0, 1/192, 1/6, 1/4, 1/3, 1/2, 2/3, 1}."""
+    from scipy.stats import norm
+    from oracle import nf4_oracle as N4
+    off = 0.9677083
+    pos = norm.ppf(torch.linspace(off, 0.5, 9)[:-1].numpy()).tolist()
+    neg = (-norm.ppf(torch.linspace(off, 0.5, 8)[:-1].numpy())).tolist()
+    table = np.sort(np.asarray(pos + [0.0] + neg, dtype=np.float64))
+    table /= table.max()
+    assert table.shape == (16,) and np.abs(table - N4.NF4_LEVEL).max() < 2e-6
+    assert N4.NF4_LEVEL[7] == 0.0 and N4.NF4_LEVEL[0] == -1.0 and N4.NF4_LEVEL[15] == 1.0
+    assert np.abs((N4.NF4_LEVEL[:-1].astype(np.float64) + N4.NF4_LEVEL[1:]) / 2 - N4.NF4_THR).max() < 1e-7
+    mags = np.sort(N4.FP4_MAG)
+    assert np.allclose(mags, [0, 1 / 192, 1 / 6, 1 / 4, 1 / 3, 1 / 2, 2 / 3, 1], atol=1e-7)
+    assert np.allclose((mags[:-1] + mags[1:]) / 2, N4.FP4_THR, atol=1e-6) and np.array_equal(N4.FP4_MAG[N4.FP4_CODE], mags)
+    dyn = N4.dynamic_map()
+    assert dyn.shape == (256,) and np.all(np.diff(dyn) > 0) and dyn[-1] == 1.0 and 0.0 in dyn
+    assert dyn[127] == 0.0 and np.allclose(dyn[0:127][::-1], -dyn[128:255], rtol=1e-6)   # 127 mirrored pairs around 0, plus 0 and the lone 1.0
+
+
+@pytest.mark.parametrize("quant_type", ["nf4", "fp4"])
+@pytest.mark.parametrize("double_quant", [False, True])
+def test_nf4_oracle_blocks_round_trip_properties(quant_type, double_quant):
+    """Size-independent properties of quantize_4bit / dequantize_4bit: the packing order, +-absmax reproduced exactly, the error bound of the
+    coarsest interval, the nested statistics within the 8-bit table's resolution, all-zero blocks."""
+    from oracle import nf4_oracle as N4
+    rng = np.random.default_rng(5)
+    w = torch.from_numpy((rng.standard_normal((64, 1024)) * 0.02).astype(np.float32)).to(torch.bfloat16).float().numpy()
+    w[2, 128:192] = 0.0
+    st = N4.quantize_4bit(w, quant_type, double_quant)
+    assert st["packed"].dtype == np.uint8 and st["packed"].shape == (w.size // 2,)
+    x = w.reshape(-1, 64)
+    am = np.abs(x).max(1)
+    first = N4._q4((x[:, 0] / np.where(am > 0, am, 1)).astype(np.float32), quant_type)
+    ok = am > 0
+    assert np.array_equal((st["packed"].reshape(-1, 32)[:, 0] >> 4)[ok], first[ok])                 # element 0 of a block: HIGH nibble of byte 0
+    a = N4.absmax_of(st)
+    if double_quant:
+        assert st["qabsmax"].shape == am.shape and st["absmax2"].shape == ((am.size + 255) // 256,)
+        assert np.abs(a - am).max() <= 0.008 * np.abs(am - st["offset"]).max() + 1e-12              # coarsest step of the dynamic table: 1.4 % of absmax2 (half of it)
+    else:
+        assert np.array_equal(a, am)
+    d = N4.dequantize_4bit(st)
+    assert d.shape == w.shape
+    db = d.reshape(-1, 64)
+    i = np.abs(x).argmax(1)
+    r = np.arange(x.shape[0])
+    assert np.allclose(np.abs(db[r, i])[ok], a[ok])                                                         # the block's largest element -> level +-1
+    assert np.array_equal(np.sign(db[r, i])[ok], np.sign(x[r, i])[ok])
+    half_gap = 0.5 * np.diff(np.sort(N4.NF4_LEVEL if quant_type == "nf4" else N4.FP4_LEVEL)).max()
+    assert (np.abs(db - x * (a / np.where(am > 0, am, 1))[:, None])[ok] <= (half_gap + 1e-6) * a[ok, None]).all()
+    if not double_quant:
+        assert np.all(db[~ok] == 0)                                    # all-zero block: 0 * inf = NaN -> code 0 -> -1 * absmax = -0
+    else:
+        code0 = -1.0 if quant_type == "nf4" else 0.0                   # ... and with nested statistics absmax comes back as the 8-bit table's rounding error
+        assert np.all(db[~ok] == code0 * a[~ok, None])

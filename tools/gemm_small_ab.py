@@ -18,14 +18,15 @@ def t(fn, it=30):
     for _ in range(it): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / it
-configs = [("default", 256, 128), ("small>=512", 512, 128), ("small>=1024", 1024, 128), ("min256=32", 256, 32), ("min256=32,small>=1024", 1024, 32)]
+configs = [("default", 256, 128, 1), ("64x64", 1 << 30, 128, 1), ("64x128", 1, 128, 1), ("min256=32 cost", 256, 32, 1), ("min256=32 144-row", 256, 32, 2),
+           ("min256=32 256-row", 256, 32, 0)]
 print(f"B={B}  us per launch: " + " | ".join(c[0] for c in configs))
 for M, N, K, res in shapes:
     a, b = rn(M, K), rn(N, K)
     bias, r = rn(N), (rn(M, N) if res else None)
     row = []
-    for _, st, m256 in configs:
-        lib.lhrs_gemm_set_small_thresh(st); lib.lhrs_gemm_set_min_tiles(m256)
+    for _, st, m256, bm in configs:
+        lib.lhrs_gemm_set_small_thresh(st); lib.lhrs_gemm_set_min_tiles(m256); lib.lhrs_gemm_set_bm144(bm)
         row.append(t(lambda: hk.gemm_nt(a, b, bias=bias, residual=r)))
-    print(f"M={M:5d} N={N:5d} K={K:5d}  " + "  ".join(f"{x:7.1f}" for x in row) + f"   best {min(row):6.1f} us = {2*M*N*K/min(row)/1e6:5.0f} TF")
-lib.lhrs_gemm_set_small_thresh(256); lib.lhrs_gemm_set_min_tiles(128)
+    print(f"M={M:5d} N={N:5d} K={K:5d}  " + "  ".join(f"{x:7.1f}" for x in row) + f"   best [{configs[row.index(min(row))][0]}] {min(row):6.1f} us = {2*M*N*K/min(row)/1e6:5.0f} TF")
+lib.lhrs_gemm_set_small_thresh(256); lib.lhrs_gemm_set_min_tiles(128); lib.lhrs_gemm_set_bm144(1)
