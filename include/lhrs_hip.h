@@ -250,6 +250,12 @@ int lhrs_splice_fwd(const long* ids, const long* labels, const uint8_t* mask, co
                     void* out_embeds, long* out_labels, uint8_t* out_mask, int* img_pos, int B, int T, int NI, int dim,
                     int S, int vocab, void* stream);
 int lhrs_splice_bwd(const void* d_embeds, const int* img_pos, void* d_image, int B, int NI, int dim, int S, void* stream);
+/* general splice - several <image> placeholders per sample (text_modal.py:341-438; the walk over the placeholders and the batch-wide image slot
+ * counter run on the host, TextModal.splice_plan_host): per output row the token index it copies (src_tok >= 0) or the row of the flattened image
+ * slots [n_slots * NI] (src_img >= 0), neither = zero padding; backward: d_image[r] = d_embeds[inv[r]] (inv[r] < 0: zeros).  Pure copies. */
+int lhrs_splice_map_fwd(const long* ids, const int* src_tok, const int* src_img, const void* image, const void* embed, void* out_embeds, int B,
+                        int T, int dim, int S, int vocab, void* stream);
+int lhrs_splice_map_bwd(const void* d_embeds, const int* inv, void* d_image, int n_rows, int dim, void* stream);
 int lhrs_gather_rows(const void* src, long ld_src, const int* idx, void* dst, long ld_dst, int n, int dim, void* stream);
 int lhrs_scatter_rows(const void* src, long ld_src, const int* idx, void* dst, long ld_dst, int n, int dim, void* stream);
 /* greedy decoding pick (HF GenerationMixin argmax, do_sample=False: main_vqa.py:205-214, cli_qa.py:176-186) */

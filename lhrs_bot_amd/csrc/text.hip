@@ -75,6 +75,41 @@ __global__ __launch_bounds__(256) void splice_bwd_kernel(const bf16_t* __restric
   }
 }
 
+// General splice (several <image> placeholders per sample; text_modal.py:341-438): the host walked the placeholders (TextModal.splice_plan_host)
+// and hands over, per output row, the token index it copies (src_tok >= 0), the row of the flattened image slots [n_slots * NI] it copies
+// (src_img >= 0), or neither (right padding -> zeros).  One block per output row.
+__global__ __launch_bounds__(256) void splice_map_fwd_kernel(const long* __restrict__ ids, const int* __restrict__ src_tok,
+                                                             const int* __restrict__ src_img, const bf16_t* __restrict__ image,
+                                                             const bf16_t* __restrict__ embed, bf16_t* __restrict__ out_embeds, int T, int dim,
+                                                             int S, int vocab) {
+  const int j = blockIdx.x, b = blockIdx.y;
+  const int st = src_tok[(long)b * S + j], si = src_img[(long)b * S + j];
+  const bf16_t* src = nullptr;
+  if (si >= 0) src = image + (long)si * dim;
+  else if (st >= 0) {
+    long id = ids[(long)b * T + st];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    src = embed + id * dim;
+  }
+  bf16_t* dst = out_embeds + ((long)b * S + j) * dim;
+  for (int c = threadIdx.x; c < dim / 8; c += 256) {
+    const uint4 v = src ? *reinterpret_cast<const uint4*>(src + c * 8) : make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(dst + c * 8) = v;
+  }
+}
+// d_image[r, :] = d_embeds[inv[r], :] for every row r of the flattened image slots; inv[r] < 0 (a slot no placeholder took): zeros
+__global__ __launch_bounds__(256) void splice_map_bwd_kernel(const bf16_t* __restrict__ d_embeds, const int* __restrict__ inv,
+                                                             bf16_t* __restrict__ d_image, int dim) {
+  const int r = blockIdx.x;
+  const int i = inv[r];
+  const bf16_t* src = i >= 0 ? d_embeds + (long)i * dim : nullptr;
+  bf16_t* dst = d_image + (long)r * dim;
+  for (int c = threadIdx.x; c < dim / 8; c += 256) {
+    const uint4 v = src ? *reinterpret_cast<const uint4*>(src + c * 8) : make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(dst + c * 8) = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ src, long ld_src, const int* __restrict__ idx,
                                                           bf16_t* __restrict__ dst, long ld_dst, int dim) {
   const int r = blockIdx.x;
@@ -208,6 +243,20 @@ extern "C" int lhrs_splice_fwd(const long* ids, const long* labels, const uint8_
   return 0;
 }
 
+extern "C" int lhrs_splice_map_fwd(const long* ids, const int* src_tok, const int* src_img, const void* image, const void* embed,
+                                   void* out_embeds, int B, int T, int dim, int S, int vocab, void* stream) {
+  LHRS_REQUIRE(B > 0 && T > 0 && S > 0 && dim % 8 == 0, "splice_map_fwd: B=%d T=%d S=%d dim=%d", B, T, S, dim);
+  hipLaunchKernelGGL(splice_map_fwd_kernel, dim3(S, B), dim3(256), 0, (hipStream_t)stream, ids, src_tok, src_img, (const bf16_t*)image,
+                     (const bf16_t*)embed, (bf16_t*)out_embeds, T, dim, S, vocab);
+  LHRS_CHECK_LAUNCH("splice_map_fwd");
+  return 0;
+}
+extern "C" int lhrs_splice_map_bwd(const void* d_embeds, const int* inv, void* d_image, int n_rows, int dim, void* stream) {
+  LHRS_REQUIRE(n_rows > 0 && dim % 8 == 0, "splice_map_bwd: n_rows=%d dim=%d", n_rows, dim);
+  hipLaunchKernelGGL(splice_map_bwd_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)d_embeds, inv, (bf16_t*)d_image, dim);
+  LHRS_CHECK_LAUNCH("splice_map_bwd");
+  return 0;
+}
 extern "C" int lhrs_splice_bwd(const void* d_embeds, const int* img_pos, void* d_image, int B, int NI, int dim, int S,
                                void* stream) {
   LHRS_REQUIRE(B > 0 && NI > 0 && dim % 8 == 0, "splice_bwd: B=%d NI=%d dim=%d", B, NI, dim);

@@ -525,6 +525,29 @@ def splice_bwd(d_embeds, img_pos, NI):
     return d_image
 
 
+def splice_map_fwd(ids, src_tok, src_img, image, embed, S):
+    """General splice (several <image> placeholders per sample): ids int64 [B, T], src_tok / src_img int32 [B, S] from TextModal.splice_plan_host,
+    image bf16 [n_slots, NI, dim] -> embeds bf16 [B, S, dim]."""
+    B, T = ids.shape
+    dim = image.shape[-1]
+    _req(ids, torch.int64, "input_ids")
+    _req(src_tok, torch.int32, "src_tok")
+    _req(src_img, torch.int32, "src_img")
+    out = torch.empty((B, S, dim), device=ids.device, dtype=torch.bfloat16)
+    _lib.check(_L().lhrs_splice_map_fwd(ids.contiguous().data_ptr(), src_tok.contiguous().data_ptr(), src_img.contiguous().data_ptr(), image.data_ptr(),
+                                        embed.data_ptr(), out.data_ptr(), B, T, dim, S, embed.shape[0], _stream()), "splice_map_fwd")
+    return out
+
+
+def splice_map_bwd(d_embeds, inv, n_slots, NI):
+    """d_image [n_slots, NI, dim] = rows inv[r] of d_embeds [B, S, dim] (inv int32 [n_slots * NI], < 0 -> zeros)."""
+    dim = d_embeds.shape[-1]
+    _req(inv, torch.int32, "inv")
+    d_image = torch.empty((n_slots, NI, dim), device=d_embeds.device, dtype=torch.bfloat16)
+    _lib.check(_L().lhrs_splice_map_bwd(d_embeds.data_ptr(), inv.data_ptr(), d_image.data_ptr(), n_slots * NI, dim, _stream()), "splice_map_bwd")
+    return d_image
+
+
 def gather_rows(src, idx, out=None):
     n, dim = idx.numel(), src.shape[1]
     out = torch.empty((n, dim), device=src.device, dtype=torch.bfloat16) if out is None else out

@@ -434,7 +434,9 @@ class TextModal:
 
     # ------------------------------------------------------------------ splice
     def prepare_inputs_for_multimodal(self, input_ids, attention_mask, labels, image_embedding):
-        """Device-side restatement of text_modal.py:296-526 (one <image> per sample, tune_im_start off)."""
+        """Device-side restatement of text_modal.py:296-526 (tune_im_start off) -> (embeds, labels, mask, img_pos).  One placeholder per sample:
+        everything on the device (`lhrs_splice_fwd`).  Several placeholders in a sample (or an image tensor with one slot per placeholder): the
+        walk runs on the host (`splice_plan_host`), the device copies rows through its map; the fourth value is then the inverse map."""
         ids = input_ids.to(self.device)
         B, T = ids.shape
         if image_embedding is None:  # text-only turn (text_modal.py:321-339): no <image> token may be present, plain embeddings
@@ -444,8 +446,13 @@ class TextModal:
         NI = image_embedding.shape[1]
         has_img = (ids == IMAGE_TOKEN_INDEX).any(dim=1)
         n_img = (ids == IMAGE_TOKEN_INDEX).sum(dim=1)
-        if int(n_img.max()) > 1:
-            raise NotImplementedError("more than one <image> token per sample is not supported by the device splice")
+        if int(n_img.max()) > 1 or image_embedding.shape[0] != B:   # several placeholders in a sample: host walk + mapped copy (text_modal.py:341-438)
+            ids_h, lab_h, msk_h = self._ints_to_host(input_ids, labels, attention_mask)
+            plan = self.splice_plan_host(ids_h, lab_h, msk_h, NI)
+            self._check_slots(plan, image_embedding)
+            embeds = hk.splice_map_fwd(ids, hk.h2d(plan["src_tok"], self.device), hk.h2d(plan["src_img"], self.device), image_embedding.contiguous(),
+                                       self.p["embed"], plan["S"])
+            return embeds, hk.h2d(plan["labels"], self.device), hk.h2d(plan["mask"], self.device), hk.h2d(plan["inv"], self.device)
         S = T - 1 + NI if bool(has_img.any()) else T
         lab = None if labels is None else labels.to(self.device)
         msk = None if attention_mask is None else attention_mask.to(self.device)
@@ -525,7 +532,7 @@ class TextModal:
         is_img = ids == IMAGE_TOKEN_INDEX
         n_img = is_img.sum(dim=1)
         if int(n_img.max()) > 1:
-            raise NotImplementedError("more than one <image> token per sample is not supported by the device splice")
+            raise ValueError("several <image> placeholders in a sample: use splice_plan_host (the general walk)")
         has = n_img > 0
         S = T - 1 + NI if bool(has.any()) else T
         p = torch.where(has, is_img.to(torch.int64).argmax(dim=1), torch.full((B,), T, dtype=torch.int64))[:, None]
@@ -543,6 +550,77 @@ class TextModal:
         new_mask = torch.where(j < new_len, torch.where(j < shift, torch.ones((B, S), dtype=torch.uint8), m.gather(1, (j - shift).clamp(0, T - 1))),
                                torch.zeros((B, S), dtype=torch.uint8))
         return S, has, new_labels, new_mask
+
+    @staticmethod
+    def splice_plan_host(ids, labels, mask, NI, tune_im_start=False):
+        """The GENERAL walk of prepare_inputs_for_multimodal (text_modal.py:318-438) on CPU tensors: any number of <image> placeholders per
+        sample, each one taking the next image SLOT of a counter that runs over the batch and that a placeholder-free sample advances too
+        (`cur_image_idx`, :339, :402).  -> dict(S, n_slots, labels int64 [B,S], mask uint8 [B,S], src_tok int32 [B,S] (token index or -1),
+        src_img int32 [B,S] (row of the flattened slots [n_slots * NI] or -1), inv int32 [n_slots * NI] (flat output row b * S + j that copies
+        image row r, -1 for a slot nobody took)).  tune_im_start: the integer side of the `tune_pooler and tune_im_start` branch (:353-387) -
+        the token map is the plain one, the label kept behind the image is the placeholder's own and the walk resumes two tokens on."""
+        B, T = ids.shape
+        rows_tok, rows_img, rows_lab = [], [], []
+        slot = 0
+        for b in range(B):
+            cur = ids[b].tolist()
+            lab = labels[b].tolist() if labels is not None else None
+            tok, img, nl = [], [], []
+            base = 0
+            if IMAGE_TOKEN_INDEX not in cur:
+                tok, img, nl = list(range(T)), [-1] * T, (list(lab) if lab is not None else [])
+                slot += 1
+            else:
+                while IMAGE_TOKEN_INDEX in cur:
+                    p = cur.index(IMAGE_TOKEN_INDEX)
+                    tok += [base + i for i in range(p)] + [-1] * NI
+                    img += [-1] * p + [slot * NI + k for k in range(NI)]
+                    step = 1
+                    if tune_im_start:
+                        if p + 1 >= len(cur):
+                            raise ValueError("tune_im_start: every <image> placeholder needs its <im_end> neighbour (cap_dataset.py:875-876)")
+                        tok.append(base + p + 1)
+                        img.append(-1)
+                        step = 2
+                    if lab is not None:
+                        nl += lab[:p] + [IGNORE_INDEX] * NI + (lab[p:p + 1] if tune_im_start else [])
+                        lab = lab[p + step:]
+                    cur = cur[p + step:]
+                    base += p + step
+                    slot += 1
+                tok += [base + i for i in range(len(cur))]
+                img += [-1] * len(cur)
+                if lab is not None:
+                    nl += lab
+            rows_tok.append(tok); rows_img.append(img); rows_lab.append(nl)
+        S = max(len(r) for r in rows_tok)
+        src_tok = torch.full((B, S), -1, dtype=torch.int32)
+        src_img = torch.full((B, S), -1, dtype=torch.int32)
+        new_labels = torch.full((B, S), IGNORE_INDEX, dtype=torch.int64)
+        new_mask = torch.zeros((B, S), dtype=torch.uint8)
+        inv = torch.full((max(slot, 1) * NI,), -1, dtype=torch.int32)
+        m = torch.ones((B, T), dtype=torch.uint8) if mask is None else mask.to(torch.uint8)
+        for b in range(B):
+            n = len(rows_tok[b])
+            src_tok[b, :n] = torch.tensor(rows_tok[b], dtype=torch.int32)
+            src_img[b, :n] = torch.tensor(rows_img[b], dtype=torch.int32)
+            if labels is not None:
+                new_labels[b, :n] = torch.tensor(rows_lab[b], dtype=torch.int64)
+            new_mask[b, : n - T] = 1                      # the reference left-extends the mask by the growth of the row (:511-524)
+            new_mask[b, n - T: n] = m[b]
+            j = torch.nonzero(src_img[b] >= 0).squeeze(1)
+            inv[src_img[b, j].long()] = (b * S + j).to(torch.int32)
+        return dict(S=S, n_slots=slot, labels=new_labels, mask=new_mask, src_tok=src_tok, src_img=src_img, inv=inv)
+
+    def _splice_general(self, ids_h, image_embedding, NI):
+        """True when the batch needs the general walk: a sample with several placeholders, or an image tensor that is not one slot per sample."""
+        n_img = (ids_h == IMAGE_TOKEN_INDEX).sum(dim=1)
+        return int(n_img.max()) > 1 or image_embedding.shape[0] != ids_h.shape[0]
+
+    def _check_slots(self, plan, image_embedding):
+        if plan["n_slots"] > image_embedding.shape[0]:   # the reference: IndexError at image_embedding[cur_image_idx] (text_modal.py:343-345)
+            raise IndexError(f"the batch takes {plan['n_slots']} image slots (one per <image> placeholder, one per placeholder-free sample) but "
+                             f"image_embedding holds {image_embedding.shape[0]}")
 
     def _ints_to_host(self, *ts):
         """CPU views of the small integer inputs.  Host tensors (what a DataLoader delivers) pass through; device tensors cost ONE
@@ -566,7 +644,13 @@ class TextModal:
                 raise ValueError("input_ids contain the <image> placeholder but no image embedding was given")
             image_embedding = torch.zeros((B, 1, self.d), device=self.device, dtype=torch.bfloat16)
         NI = image_embedding.shape[1]
-        S, _, new_labels, new_mask = self.splice_ints_host(ids_h, lab_h, msk_h, NI)
+        plan = None
+        if self._splice_general(ids_h, image_embedding, NI):
+            plan = self.splice_plan_host(ids_h, lab_h, msk_h, NI)
+            self._check_slots(plan, image_embedding)
+            S, new_labels, new_mask = plan["S"], plan["labels"], plan["mask"]
+        else:
+            S, _, new_labels, new_mask = self.splice_ints_host(ids_h, lab_h, msk_h, NI)
         # shifted targets: position j predicts label j+1 (HF LlamaForCausalLM.forward); ignore_index rows are skipped
         tgt = torch.full_like(new_labels, IGNORE_INDEX)
         tgt[:, :-1] = new_labels[:, 1:]
@@ -577,7 +661,13 @@ class TextModal:
         rows32 = hk.h2d(rows.to(torch.int32), self.device)
         targets = hk.h2d(flat[rows].to(torch.int32), self.device)
         ids_d = input_ids if input_ids.is_cuda else hk.h2d(ids_h.contiguous(), self.device)
-        embeds, _, _, img_pos = hk.splice_fwd(ids_d, None, None, image_embedding.contiguous(), self.p["embed"], S)
+        if plan is None:
+            embeds, _, _, img_pos = hk.splice_fwd(ids_d, None, None, image_embedding.contiguous(), self.p["embed"], S)
+            img_inv = None
+        else:
+            embeds = hk.splice_map_fwd(ids_d, hk.h2d(plan["src_tok"], self.device), hk.h2d(plan["src_img"], self.device),
+                                       image_embedding.contiguous(), self.p["embed"], S)
+            img_pos, img_inv = None, (hk.h2d(plan["inv"], self.device), image_embedding.shape[0])
         # supervised positions of each sequence: when they form ONE contiguous range (stage 1: the caption at the end of the sequence; any
         # single-answer sample) the last decoder layer only has to produce those rows
         tail = None
@@ -594,7 +684,7 @@ class TextModal:
         logits = hk.gemm_nt(hv, self.p["lm_head"])
         loss, dlogits = hk.cross_entropy(logits, targets, want_grad=save_ctx, inplace=True)
         if save_ctx:
-            self._ctx.update(rows=rows32, dlogits=dlogits, img_pos=img_pos, NI=NI)
+            self._ctx.update(rows=rows32, dlogits=dlogits, img_pos=img_pos, img_inv=img_inv, NI=NI)
         return loss
 
     __call__ = decode
@@ -1011,6 +1101,13 @@ class TextModal:
             s.clear()
             if on_layer_ready is not None:
                 on_layer_ready(li)
-        d_image = hk.splice_bwd(dx.view(B, S, d), c["img_pos"], c["NI"]) if need_input_grad else None
+        d_image = None
+        if need_input_grad and c.get("img_inv") is not None:      # general splice: rows of the image slots through the inverse map
+            inv, n_slots = c["img_inv"]
+            if inv.numel() < n_slots * c["NI"]:                    # slots past the last one the batch took: zero gradient
+                inv = torch.cat([inv, torch.full((n_slots * c["NI"] - inv.numel(),), -1, device=inv.device, dtype=torch.int32)])
+            d_image = hk.splice_map_bwd(dx.view(B, S, d), inv, n_slots, c["NI"])
+        elif need_input_grad:
+            d_image = hk.splice_bwd(dx.view(B, S, d), c["img_pos"], c["NI"])
         self._ctx = None
         return d_image

@@ -137,6 +137,72 @@ def splice(ids: torch.Tensor, labels: Optional[torch.Tensor], mask: Optional[tor
     return src_t, new_labels, new_mask
 
 
+def splice_multi(ids: torch.Tensor, labels: Optional[torch.Tensor], mask: Optional[torch.Tensor], n_img_tokens: int, tune_im_start: bool = False):
+    """The GENERAL walk of TextModal.prepare_inputs_for_multimodal (lhrs/models/text_modal.py:318-438): any number of `<image>` placeholders per
+    sample, each taking `image_embedding[cur_image_idx]` with the running counter over the batch that a placeholder-free sample also advances (:339).
+    Returns (src, new_labels, new_mask, n_slots); image rows are encoded GLOBALLY: src = -(1 + slot * n_img_tokens + k).
+    tune_im_start (the `tune_pooler and tune_im_start` branch, :353-387): the same token map - tokens[:p-1] (detached), `<im_start>` = token p-1, image,
+    `<im_end>` = token p+1, rest - but the LABEL kept for `<im_end>` is labels[p] (the placeholder's) and the walk resumes at p+2 (:382-386)."""
+    B, T = ids.shape
+    PAD = -10 ** 9
+    rows, lab_rows = [], []
+    slot = 0
+    for b in range(B):
+        cur = ids[b].tolist()
+        lab = labels[b].tolist() if labels is not None else None
+        src: List[int] = []
+        nl: List[int] = []
+        base = 0
+        if IMAGE_TOKEN_INDEX not in cur:
+            rows.append(list(range(T)))
+            lab_rows.append(list(lab) if lab is not None else [])
+            slot += 1
+            continue
+        while IMAGE_TOKEN_INDEX in cur:
+            p = cur.index(IMAGE_TOKEN_INDEX)
+            src += [base + i for i in range(p)] + [-(1 + slot * n_img_tokens + k) for k in range(n_img_tokens)]
+            step = 1
+            if tune_im_start:
+                assert p + 1 < len(cur), "tune_im_start: the placeholder needs its <im_end> neighbour"
+                src += [base + p + 1]
+                step = 2
+            if lab is not None:
+                nl += lab[:p] + [IGNORE_INDEX] * n_img_tokens + (lab[p:p + 1] if tune_im_start else [])
+                lab = lab[p + step:]
+            cur = cur[p + step:]
+            base += p + step
+            slot += 1
+        src += [base + i for i in range(len(cur))]
+        if lab is not None:
+            nl += lab
+        rows.append(src)
+        lab_rows.append(nl)
+    S = max(len(r) for r in rows)
+    src_t = torch.full((B, S), PAD, dtype=torch.int64)
+    new_labels = torch.full((B, S), IGNORE_INDEX, dtype=torch.int64) if labels is not None else None
+    new_mask = torch.zeros((B, S), dtype=torch.bool) if mask is not None else None
+    for b in range(B):
+        n = len(rows[b])
+        src_t[b, :n] = torch.tensor(rows[b], dtype=torch.int64)
+        if labels is not None:
+            new_labels[b, :n] = torch.tensor(lab_rows[b], dtype=torch.int64)
+        if mask is not None:
+            new_mask[b, : n - T] = True
+            new_mask[b, n - T: n] = mask[b]
+    return src_t, new_labels, new_mask, slot
+
+
+def splice_embeds_multi(src: torch.Tensor, ids: torch.Tensor, image: torch.Tensor, embed: torch.Tensor) -> torch.Tensor:
+    """Embeddings for a `splice_multi` plan: image [n_slots, n_img_tokens, d] indexed by the global row code; differentiable in `image`."""
+    B, S = src.shape
+    flat = image.reshape(-1, image.shape[-1])
+    tok = embed[torch.gather(ids.clamp(min=0), 1, src.clamp(min=0))].to(image.dtype)
+    is_img = (src < 0) & (src > -10 ** 8)
+    img_rows = flat[(-src - 1).clamp(0, flat.shape[0] - 1)]
+    out = torch.where(is_img[..., None], img_rows, tok)
+    return torch.where((src <= -10 ** 8)[..., None], torch.zeros_like(out), out)
+
+
 def splice_embeds(src: torch.Tensor, ids: torch.Tensor, image: torch.Tensor, embed: torch.Tensor) -> torch.Tensor:
     B, S = src.shape
     out = torch.zeros(B, S, embed.shape[1], dtype=image.dtype)
@@ -233,16 +299,22 @@ def unibind_forward(P: Dict, batch: Dict, collect: Optional[Dict] = None) -> tor
     """UniBind.forward (lhrs/models/UniBind.py:178-199): rgb -> ViT taps -> AttnPooler -> splice -> LLaMA -> loss."""
     taps = vit_forward(P["vit"], batch["rgb"])
     img = pooler_forward(P["pooler"], taps)
-    src, labels, mask = splice(batch["input_ids"], batch["labels"], batch["attention_mask"], img.shape[1])
-    B, S = src.shape
-    emb = P["llama"]["embed"]
-    tok = batch["input_ids"].clamp(min=0)
-    gathered = emb[torch.gather(tok, 1, src.clamp(min=0))]                      # [B,S,d] token rows
-    img_rows = img[torch.arange(B)[:, None], (-src - 1).clamp(0, img.shape[1] - 1)]
-    is_img = (src < 0) & (src > -10 ** 8)
-    is_pad = src <= -10 ** 8
-    embeds = torch.where(is_img[..., None], img_rows, gathered)
-    embeds = torch.where(is_pad[..., None], torch.zeros_like(embeds), embeds)
+    n_ph = (batch["input_ids"] == IMAGE_TOKEN_INDEX).sum(dim=1)
+    if int(n_ph.max()) > 1 or img.shape[0] != batch["input_ids"].shape[0]:         # several placeholders in a sample: the general walk, global image slots
+        src, labels, mask, n_slots = splice_multi(batch["input_ids"], batch["labels"], batch["attention_mask"], img.shape[1])
+        assert n_slots <= img.shape[0], "the reference indexes image_embedding[cur_image_idx] past its end"
+        embeds = splice_embeds_multi(src, batch["input_ids"], img, P["llama"]["embed"])
+    else:
+        src, labels, mask = splice(batch["input_ids"], batch["labels"], batch["attention_mask"], img.shape[1])
+        B, S = src.shape
+        emb = P["llama"]["embed"]
+        tok = batch["input_ids"].clamp(min=0)
+        gathered = emb[torch.gather(tok, 1, src.clamp(min=0))]                      # [B,S,d] token rows
+        img_rows = img[torch.arange(B)[:, None], (-src - 1).clamp(0, img.shape[1] - 1)]
+        is_img = (src < 0) & (src > -10 ** 8)
+        is_pad = src <= -10 ** 8
+        embeds = torch.where(is_img[..., None], img_rows, gathered)
+        embeds = torch.where(is_pad[..., None], torch.zeros_like(embeds), embeds)
     hidden = llama_hidden(P["llama"], embeds, mask)
     loss = causal_lm_loss(P["llama"], hidden, labels)
     if collect is not None:
@@ -261,12 +333,17 @@ def generate_logits(P: Dict, rgb: torch.Tensor, input_ids: torch.Tensor, forced_
     keys; positions stay arange(S) because CustomLlamaForCausalLM.prepare_inputs_for_generation (text_modal.py:36-60) passes no
     position_ids; generated positions are visible (HF generate appends ones)."""
     img = pooler_forward(P["pooler"], vit_forward(P["vit"], rgb))
-    src, _, mask = splice(input_ids, None, attention_mask, img.shape[1])
-    B, S0 = src.shape
     emb = P["llama"]["embed"]
-    tok = emb[torch.gather(input_ids.clamp(min=0), 1, src.clamp(min=0))]
-    img_rows = img[torch.arange(B)[:, None], (-src - 1).clamp(0, img.shape[1] - 1)]
-    embeds = torch.where((src < 0)[..., None], img_rows, tok)
+    if int((input_ids == IMAGE_TOKEN_INDEX).sum(dim=1).max()) > 1 or img.shape[0] != input_ids.shape[0]:   # several placeholders in a prompt
+        src, _, mask, _ = splice_multi(input_ids, None, attention_mask, img.shape[1])
+        B, S0 = src.shape
+        embeds = splice_embeds_multi(src, input_ids, img, emb)
+    else:
+        src, _, mask = splice(input_ids, None, attention_mask, img.shape[1])
+        B, S0 = src.shape
+        tok = emb[torch.gather(input_ids.clamp(min=0), 1, src.clamp(min=0))]
+        img_rows = img[torch.arange(B)[:, None], (-src - 1).clamp(0, img.shape[1] - 1)]
+        embeds = torch.where((src < 0)[..., None], img_rows, tok)
     if attention_mask is None:
         mask = None
     out = []

@@ -268,3 +268,33 @@ def test_generated_gemm_schedule_is_current():
     for name in ("S_BLOCK0", "S_BLOCK1"):  # 16 MFMAs per k-block, every fragment re-read exactly once per block
         body = out.split(f"#define {name}(aa, ba)")[1].split("#define")[0]
         assert body.count("MF(") == 16 and body.count("RDQ(") == 8
+
+
+def test_host_splice_plan_general_walk_against_the_reference_fixture():
+    """TextModal.splice_plan_host (host side of the multi-image splice: the walk over the placeholders, the batch-wide image slot counter, the
+    tune_im_start label rule) against tests/golden/splice_multi.npz produced by the reference's own prepare_inputs_for_multimodal; the inverse map
+    the backward uses points every image row at the output row that copied it."""
+    from lhrs_bot_amd.text import TextModal
+    z = np.load(os.path.join(G, "splice_multi.npz"))
+    NI = int(z["n_img_tokens"])
+    for name in ("two_each", "two_and_one", "three_none_one", "adjacent_and_last", "four_in_one", "ims_one_each", "ims_ragged"):
+        ids = torch.from_numpy(z[name + "_ids"]); lab = torch.from_numpy(z[name + "_labels"]); m = torch.from_numpy(z[name + "_mask"])
+        plan = TextModal.splice_plan_host(ids, lab, m, NI, tune_im_start=bool(z[name + "_tune_im_start"]))
+        src = torch.from_numpy(z[name + "_src"])
+        assert plan["n_slots"] == int(z[name + "_slots"]) and plan["S"] == src.shape[1], name
+        assert torch.equal(plan["labels"], torch.from_numpy(z[name + "_new_labels"])), name
+        assert torch.equal(plan["mask"].bool(), torch.from_numpy(z[name + "_new_mask"])), name
+        amb = src == -2 * 10 ** 9
+        is_tok = (src >= 0) | amb
+        is_img = (src < 0) & (src > -10 ** 8)
+        assert torch.equal(plan["src_tok"].long()[src >= 0], src[src >= 0]) and bool((plan["src_tok"][is_tok] >= 0).all()), name
+        assert torch.all(torch.gather(ids, 1, plan["src_tok"].long().clamp(min=0))[amb] == 0), name
+        assert torch.equal(plan["src_img"].long()[is_img], (-src - 1)[is_img]) and bool((plan["src_img"][~is_img] == -1).all()), name
+        assert bool((plan["src_tok"][~is_tok] == -1).all()), name
+        inv = plan["inv"].long()
+        flat_img = plan["src_img"].reshape(-1).long()
+        taken = inv >= 0
+        assert torch.equal(flat_img[inv[taken]], torch.nonzero(taken).squeeze(1)), name
+        assert int(taken.sum()) == int(is_img.sum()), name
+    with pytest.raises(ValueError, match="im_end"):
+        TextModal.splice_plan_host(torch.tensor([[1, 5, -200]]), None, None, NI, tune_im_start=True)

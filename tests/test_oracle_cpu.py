@@ -340,3 +340,34 @@ def test_nf4_oracle_blocks_round_trip_properties(quant_type, double_quant):
     else:
         code0 = -1.0 if quant_type == "nf4" else 0.0                   # ... and with nested statistics absmax comes back as the 8-bit table's rounding error
         assert np.all(db[~ok] == code0 * a[~ok, None])
+
+
+MULTI_CASES = ("two_each", "two_and_one", "three_none_one", "adjacent_and_last", "four_in_one", "ims_one_each", "ims_ragged")
+
+
+def test_multi_image_and_im_start_splice_bit_exact_against_reference():
+    """The general walk of prepare_inputs_for_multimodal (several placeholders per sample, the batch-wide slot counter, the tune_im_start branch)
+    against tests/golden/splice_multi.npz, produced by the reference's own method (tests/golden/make_golden_splice_multi.py)."""
+    z = np.load(os.path.join(G, "splice_multi.npz"))
+    NI = int(z["n_img_tokens"])
+    for name in MULTI_CASES:
+        ids = torch.from_numpy(z[name + "_ids"]); labels = torch.from_numpy(z[name + "_labels"]); mask = torch.from_numpy(z[name + "_mask"])
+        src, nl, nm, slots = O.splice_multi(ids, labels, mask, NI, tune_im_start=bool(z[name + "_tune_im_start"]))
+        assert slots == int(z[name + "_slots"]), name
+        want_src = torch.from_numpy(z[name + "_src"])
+        amb = want_src == -2 * 10 ** 9                          # repeated id in the row (padding zeros): must copy id 0
+        assert torch.equal(src[~amb], want_src[~amb]), name
+        assert torch.all(torch.gather(ids, 1, src.clamp(min=0))[amb] == 0), name
+        assert torch.equal(nl, torch.from_numpy(z[name + "_new_labels"])), name
+        assert torch.equal(nm, torch.from_numpy(z[name + "_new_mask"])), name
+    # one placeholder per sample: the general walk is the single-image one with slot = sample index
+    z1 = np.load(os.path.join(G, "splice.npz"))
+    n1 = int(z1["n_img_tokens"])
+    for name in ("uniform", "ragged_pad", "mixed_noimg", "img_last", "single"):
+        ids = torch.from_numpy(z1[name + "_ids"]); labels = torch.from_numpy(z1[name + "_labels"]); mask = torch.from_numpy(z1[name + "_mask"])
+        src, nl, nm = O.splice(ids, labels, mask, n1)
+        srcm, nlm, nmm, slots = O.splice_multi(ids, labels, mask, n1)
+        is_img = (src < 0) & (src > -10 ** 8)
+        b = torch.arange(ids.shape[0])[:, None].expand_as(src)
+        assert slots == ids.shape[0] and torch.equal(nl, nlm) and torch.equal(nm, nmm)
+        assert torch.equal(srcm[~is_img], src[~is_img]) and torch.equal(srcm[is_img], (src - b * n1)[is_img])
