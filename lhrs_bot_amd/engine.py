@@ -226,7 +226,7 @@ class LHRSEngine:
     # dict keys that hold tensors DERIVED from another entry of the same dict (transposed copies, decode re-tilings, e4m3 copies): skipped by
     # the replica checksum because the tensor they come from is already in it.  An explicit table - a frozen tensor whose name merely ends
     # in one of these letters is NOT skipped
-    DERIVED_KEYS = frozenset(b + suf for b in ("qkv_w", "o_w", "gu_w", "down_w") for suf in ("T", "p", "8", "8s", "8p", "T8", "T8s", "i8", "i8s")) | \
+    DERIVED_KEYS = frozenset(b + suf for b in ("qkv_w", "o_w", "gu_w", "down_w") for suf in ("T", "p", "8", "8s", "8p", "T8", "T8s", "i8", "i8s", "q4")) | \
         frozenset(("lm_head8", "lm_head8s", "lm_head8p", "lm_headp"))
 
     def replica_checksums(self) -> torch.Tensor:

@@ -149,3 +149,84 @@ def test_stage2_and_stage3_drivers_from_the_shipped_yaml_trees(tmp_path):
     m3 = t3.model.module
     assert m3.text.lora is not None and m3.text.lora.r == 128 and m3.text.base_int8     # adapters from TextLoRA/, `lora.enable: False` in the YAML
     assert {s.name for s in t3.model.stores} == {"lora"} and t3.model.global_steps == 4 and len(t3.history) == 4
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("opt,wd", [("adanp", 0.02), ("adamw", 0.05)])
+def test_three_optimizer_steps_track_the_oracle_training_loop(opt, wd):
+    """The WHOLE stage-1 step, three times over: forward, backward, global-norm clipping, the optimizer rule with the reference's decay groups
+    (build_optimizer.py:41-73: 1-D tensors and biases do not decay), bf16 refresh - against the oracle's autograd + restated Adan / AdamW in fp64 on the
+    same three batches.  Losses agree step by step (1e-3); the accumulated parameter change of the projector points the same way (cosine) and has
+    the same size; the bf16 gradients' sign noise on near-zero entries is what keeps an Adam-type update from agreeing element by element."""
+    import math
+    from lhrs_bot_amd.engine import LHRSEngine
+    from lhrs_bot_amd.unibind import UniBind
+    from oracle import lhrs_oracle as O
+    from oracle import params as OP
+    from oracle.optim_oracle import adamw_step_ref, adan_step_ref, clip_coef
+
+    nl, lr, max_norm = 2, 2e-4, 0.3          # the stage-1 YAML's lr and the DeepSpeed gradient_clipping of build_ds_config
+    P = {"vit": OP.make_vit_params(seed=2), "pooler": OP.make_pooler_params(seed=1), "llama": OP.make_llama_params(seed=3, layers=nl)}
+    model = UniBind(("rgb", "text"), None, device="cuda", llama_layers=nl).load_params(P)
+    model.prepare_for_training()
+    eng = LHRSEngine(model, optimizer=opt, lr=lr, weight_decay=wd, max_grad_norm=max_norm)
+    names = [n for n, _ in model.rgb_pooler.named_parameters()]
+    start = {n: v.detach().cpu().double().clone() for n, v in model.rgb_pooler.named_parameters()}
+
+    def batch(seed):
+        g = torch.Generator().manual_seed(seed)
+        B, T = 2, 24
+        ids = torch.randint(3, 32000, (B, T), generator=g)
+        ids[:, 0], ids[:, 1] = 1, -200
+        ids[1, 20:] = 0
+        labels = ids.clone()
+        labels[:, :2] = -100
+        labels[ids == 0] = -100
+        return dict(rgb=torch.randn(B, 3, 224, 224, generator=g), input_ids=ids, labels=labels, attention_mask=ids.ne(0))
+
+    batches = [batch(40 + i) for i in range(3)]
+    got_losses = []
+    for b in batches:
+        out = eng(b)
+        eng.backward()
+        eng.step()
+        got_losses.append(out["total_loss"].item())
+    torch.cuda.synchronize()
+
+    ref = OP.pooler_to_ref(P["pooler"])                      # reference state-dict names -> the oracle's leaf tensors
+    leaves = [P["pooler"]["query"], P["pooler"]["out_proj_w"], P["pooler"]["out_proj_b"]] + [v for L in P["pooler"]["layers"] for v in L.values() if torch.is_tensor(v)]
+    for v in leaves:
+        v.requires_grad_(True)
+    decays = {n: not (ref[n].squeeze(0).dim() == 1 or n.endswith(".bias")) for n in names}
+    state = {n: dict(p=ref[n].detach().double().clone(), m=torch.zeros_like(ref[n], dtype=torch.float64), v=torch.zeros_like(ref[n], dtype=torch.float64),
+                     n=torch.zeros_like(ref[n], dtype=torch.float64), pre=None) for n in names}
+    want_losses = []
+    for step, b in enumerate(batches, 1):
+        for v in leaves:
+            v.grad = None
+        loss = O.unibind_forward(P, b)
+        loss.backward()
+        want_losses.append(loss.item())
+        grads = {n: (P["pooler"]["query"].grad[None] if n == "query" else ref[n].grad).double() for n in names}
+        coef = clip_coef(torch.cat([g.reshape(-1) for g in grads.values()]), max_norm)
+        for n in names:
+            rule = adan_step_ref if opt == "adanp" else adamw_step_ref
+            rule(state[n], grads[n] * coef, step, lr=lr, wd=wd if decays[n] else 0.0)
+            with torch.no_grad():
+                (P["pooler"]["query"] if n == "query" else ref[n]).copy_(state[n]["p"].reshape(ref[n].shape if n != "query" else P["pooler"]["query"].shape).float()
+                                                                         if n != "query" else state[n]["p"][0].float())
+    print("losses", got_losses, want_losses)
+    for a, w in zip(got_losses, want_losses):
+        assert abs(a - w) < 1e-3 * w, (got_losses, want_losses)
+    d_got = torch.cat([(v.detach().cpu().double() - start[n]).reshape(-1) for n, v in model.rgb_pooler.named_parameters()])
+    d_want = torch.cat([(state[n]["p"] - start[n].reshape(state[n]["p"].shape)).reshape(-1) for n in names])
+    cos = (d_got @ d_want / (d_got.norm() * d_want.norm())).item()
+    print("cos", cos, "norm ratio", d_got.norm().item() / d_want.norm().item())
+    assert cos > 0.97, cos
+    assert abs(d_got.norm().item() / d_want.norm().item() - 1.0) < 3e-2
+    # the 2-D weights with the largest gradients (the output projection) agree closely element by element
+    i = names.index("out_proj.weight")
+    a = dict(model.rgb_pooler.named_parameters())["out_proj.weight"].detach().cpu().double() - start["out_proj.weight"]
+    w = state["out_proj.weight"]["p"] - start["out_proj.weight"]
+    assert ((a - w).norm() / w.norm()).item() < 0.15, ((a - w).norm() / w.norm()).item()
+    assert math.isfinite(sum(got_losses)) and i >= 0
