@@ -260,7 +260,7 @@ def roofline_block(prof, kinds, steps, B, S, scale_layers, sclk=None, watts=None
     all_fl = sum(kinds[3 * k + 2] for k in range(4))
     return {"bound": "mfma", "kernel": GEMM_KERNEL_DESC, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-            "traffic_note": "not measured in this run (PMC passes are separate rocprofv3 runs: profiles/*gemm_traffic.json)",
+            "traffic_note": "not measured in this run (PMC passes are separate rocprofv3 runs: profiles/r03_gemm_traffic.json: 1.06 GB per launch of the dominant kernel = 3.0x its algorithmic bytes, Infinity-Cache hits included)",
             "variants": variants, "all_variants_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else None,
             "launches_timed": int(n_samp), "timed_every_nth_launch": PROFILE_STRIDE, "avg_launch_us": round(1e3 * ms / max(n_samp, 1), 2),
             "sclk_mhz_during_timed_region": round(sclk) if sclk else None, "package_power_w": round(watts) if watts else None,
