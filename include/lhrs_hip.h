@@ -126,7 +126,7 @@ int lhrs_gemm_set_bm144(int mode);
  * compacts them (meta[0] = count n, meta[1] = n rounded up to 64; no cap: idx / A2 / B2 are sized for K columns), quantises x per row with
  * those columns zeroed and gathers x[:, O] and dequant(W)[:, O] into the bf16 pair; lhrs_gemm_int8_nt then computes
  * sa[m] * sb[n] * (XQ . WQ^T in int32) + A2 . B2^T (+ residual) in one launch, reading the outlier column count from k2_dev (= meta + 1) on the
- * device.  Workspaces (flags int[K], idx int[K rounded up to 64], meta int[2]) are the caller's. */
+ * device.  Workspaces (flags int[K] - the outlier BIT mask lives in its first K / 8 bytes -, idx int[K rounded up to 64], meta int[2]) are the caller's. */
 int lhrs_quant_int8_rows(const void* W, long ldw, void* Q, long ldq, float* scale, int N, int K, void* stream);
 int lhrs_dequant_int8_rows(const void* Q, long ldq, const float* scale, void* W, long ldw, int N, int K, void* stream);
 int lhrs_int8_prepare(const void* X, long ldx, int M, int K, float thr, const void* WQ, long ldwq, const float* wscale, int N, void* XQ,

@@ -102,6 +102,51 @@ template <int SHAPE> void run8(const void* din, float* dout) {
   double flops = 256.0 * 8 * iters * (SHAPE == 32 ? 16 * 2.0 * 32 * 32 * 64 : 32 * 2.0 * 16 * 16 * 128);
   printf("e4m3 %s: %.1f TFLOP/s (%.2f ms)\n", SHAPE == 32 ? "32x32x64 " : "16x16x128", flops / (ms * 1e-3) / 1e12, ms);
 }
+// the two dense int8 shapes, same operations per loop iteration: 32x32x32 (16 accumulator VGPRs) vs 16x16x64 (4)
+typedef __attribute__((ext_vector_type(4))) int i32x4v;
+typedef __attribute__((ext_vector_type(16))) int i32x16v;
+template <int SHAPE>
+__global__ __launch_bounds__(512, 2) void ki8(const i32x4v* in, int* out, int iters) {
+  i32x4v a[4], b[4];
+  for (int i = 0; i < 4; ++i) { a[i] = in[(threadIdx.x + i * 512) % 3072]; b[i] = in[(threadIdx.x + (4 + i) * 512) % 3072]; }
+  int s = 0;
+  if (SHAPE == 32) {
+    i32x16v acc[4][2];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[j], a[i], acc[i][j], 0, 0, 0);
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  } else {
+    i32x4v acc[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) acc[i][j][r] = 0;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b[j], a[i], acc[i][j], 0, 0, 0);
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) s += acc[i][j][r];
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int SHAPE> void runi8(const void* din, float* dout) {
+  const int iters = g_iters;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(ki8<SHAPE>, dim3(256), dim3(512), 0, 0, (const i32x4v*)din, (int*)dout, 1000);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(ki8<SHAPE>, dim3(256), dim3(512), 0, 0, (const i32x4v*)din, (int*)dout, iters);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  double ops = 256.0 * 8 * iters * (SHAPE == 32 ? 32 * 2.0 * 32 * 32 * 32 : 64 * 2.0 * 16 * 16 * 64);
+  printf("int8 %s: %.1f TOP/s (%.2f ms)\n", SHAPE == 32 ? "32x32x32" : "16x16x64", ops / (ms * 1e-3) / 1e12, ms);
+}
 template <int WAVES> void run(const bf16x8* din, float* dout, int blocks) {
   const int iters = g_iters;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -129,6 +174,7 @@ int main(int argc, char** argv) {
       for (int i = 0; i < 1536 * 32; ++i) { unsigned char v = (unsigned char)(rand() & 0xff); if ((v & 0x7f) == 0x7f) v ^= 1; hb[i] = v; }
       void* d8; hipMalloc(&d8, 1536 * 32); hipMemcpy(d8, hb, 1536 * 32, hipMemcpyHostToDevice);
       for (int r = 0; r < 3; ++r) { run8<32>(d8, dout); run8<16>(d8, dout); }
+      for (int r = 0; r < 3; ++r) { runi8<32>(d8, dout); runi8<16>(d8, dout); }   // the same random bytes as int8
     }
     return 0;
   }
