@@ -585,14 +585,14 @@ __global__ void decode_emit_kernel(const long* __restrict__ next_ids, int* __res
 //   (m, l, o[128]) across passes and merge them through LDS - no global atomics or fences (a cross-workgroup split was tried:
 //   device-scope release/acquire between XCD-private L2s cost more than the serial pass loop).
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int DA_WAVES = 16, DA_PASS = DA_WAVES * 32;
+constexpr int DA_WAVES = 8, DA_KPG = 16, DA_PASS = DA_WAVES * 4 * DA_KPG;   // 8 waves x 4 lane groups x 16 keys = 512 keys per pass; 8 waves (not 16 x 8 keys): 256 VGPRs per lane hold the 32 row loads without scratch (16 waves: 46 spilled registers)
 
 __device__ __forceinline__ float group16_sum(float v) {
   v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
   return v;
 }
 
-__global__ __launch_bounds__(1024) void decode_attn_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* kc, bf16_t* vc,
+__global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* kc, bf16_t* vc,
                                                            const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                            const int* __restrict__ pos, const unsigned char* __restrict__ kmask,
                                                            long ld_kmask, bf16_t* __restrict__ out, long ldo, int H, int max_ctx,
@@ -605,12 +605,12 @@ __global__ __launch_bounds__(1024) void decode_attn_kernel(const bf16_t* __restr
   const long cache_row0 = (long)b * max_ctx;
   const bf16_t* kbase = kc + cache_row0 * d_model + h * D + l16 * 8;
   const bf16_t* vbase = vc + cache_row0 * d_model + h * D + l16 * 8;
-  int key0 = wave * 32 + grp;  // this 16-lane group: keys key0, key0+4, ..., key0+28 of the current pass
+  int key0 = wave * (4 * DA_KPG) + grp;  // this 16-lane group: keys key0, key0+4, ... (DA_KPG of them) of the current pass
   // first pass: every global load is issued up front - none depends on another (any cache row < max_ctx is readable; rows past the
   // context are discarded below)
-  uint4 kr[8], vr[8];
+  uint4 kr[DA_KPG], vr[DA_KPG];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < DA_KPG; ++i) {
     const long key = min(key0 + i * 4, max_ctx - 1);
     kr[i] = *reinterpret_cast<const uint4*>(kbase + key * d_model);
     vr[i] = *reinterpret_cast<const uint4*>(vbase + key * d_model);
@@ -644,18 +644,18 @@ __global__ __launch_bounds__(1024) void decode_attn_kernel(const bf16_t* __restr
   for (int e = 0; e < 8; ++e) o[e] = 0.f;
   for (int base = 0; base <= p; base += DA_PASS) {
     if (base > 0) {  // later passes (context > 512): same load pattern, issued together at the top of the pass
-      key0 = base + wave * 32 + grp;
+      key0 = base + wave * (4 * DA_KPG) + grp;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < DA_KPG; ++i) {
         const long key = min(key0 + i * 4, max_ctx - 1);
         kr[i] = *reinterpret_cast<const uint4*>(kbase + key * d_model);
         vr[i] = *reinterpret_cast<const uint4*>(vbase + key * d_model);
       }
     }
-    float sc[8];
+    float sc[DA_KPG];
     float mp = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < DA_KPG; ++i) {
       const int key = key0 + i * 4;
       float kv[8];
       unpack8(kr[i], kv);
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(1024) void decode_attn_kernel(const bf16_t* __restr
     for (int e = 0; e < 8; ++e) o[e] *= alpha;
     m = m_new;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < DA_KPG; ++i) {
       if (sc[i] == -INFINITY) continue;  // masked / absent key: its (possibly uninitialised) cache row must not touch the sum
       const float pr = __expf(sc[i] - m_use);
       float vv[8];
@@ -903,7 +903,7 @@ extern "C" int lhrs_decode_attn(const void* qkv, long ld, void* kcache, void* vc
                                 int max_ctx, float scale, void* stream) {
   LHRS_REQUIRE(D == 128, "decode_attn: head_dim %d (only 128)", D);
   LHRS_REQUIRE(B >= 1 && H >= 1 && max_ctx >= 1 && ld % 8 == 0, "decode_attn: B=%d H=%d max_ctx=%d", B, H, max_ctx);
-  hipLaunchKernelGGL(decode_attn_kernel, dim3(H, B), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)qkv, ld, (bf16_t*)kcache,
+  hipLaunchKernelGGL(decode_attn_kernel, dim3(H, B), dim3(DA_WAVES * 64), 0, (hipStream_t)stream, (const bf16_t*)qkv, ld, (bf16_t*)kcache,
                      (bf16_t*)vcache, cos_t, sin_t, pos, key_mask, ld_mask, (bf16_t*)out, ldo, H, max_ctx, scale);
   LHRS_CHECK_LAUNCH("decode_attn");
   return 0;
