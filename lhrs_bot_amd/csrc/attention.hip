@@ -808,15 +808,29 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_res_kernel(AttnArgs a) {
 #pragma unroll
       for (int db = 0; db < DB; ++db) { tqi.base[db] = tq.base[db] + i * TILE; tdi.base[db] = tdo.base[db] + i * TILE; }
       bf16x4 alo[DB], ahi[DB];
+      // only a tile on the causal diagonal, past the last query or past the last key computes the mask (a wave-uniform test: this wave's keys
+      // are g*16 .. g*16+15): the 16 index computations + compares + selects were a third of the loop's VALU work
+      const bool full = (i + 1) * 64 <= q_len && g * 16 + 15 < kv_len && (!CAUSAL || g * 16 + 15 <= i * 64 + coff);
+      if (full) {
 #pragma unroll
-      for (int qb = 0; qb < 4; ++qb) {
+        for (int qb = 0; qb < 4; ++qb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int q = i * 64 + qb * 16 + fg * 4 + r;
-          const bool ok = q < q_len && key < kv_len && (!CAUSAL || key <= q + coff);
-          const float pv = ok ? __expf(s[qb][r] * a.scale - lq[qb][r]) : 0.f;
-          dp[qb][r] = ok ? pv * (dp[qb][r] - dl[qb][r]) * a.scale : 0.f;
-          s[qb][r] = pv;
+          for (int r = 0; r < 4; ++r) {
+            const float pv = __expf(s[qb][r] * a.scale - lq[qb][r]);
+            dp[qb][r] = pv * (dp[qb][r] - dl[qb][r]) * a.scale;
+            s[qb][r] = pv;
+          }
+      } else {
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = i * 64 + qb * 16 + fg * 4 + r;
+            const bool ok = q < q_len && key < kv_len && (!CAUSAL || key <= q + coff);
+            const float pv = ok ? __expf(s[qb][r] * a.scale - lq[qb][r]) : 0.f;
+            dp[qb][r] = ok ? pv * (dp[qb][r] - dl[qb][r]) * a.scale : 0.f;
+            s[qb][r] = pv;
+          }
         }
       }
       const bf16x8 p0 = pack_frag(s[0], s[1]), p1 = pack_frag(s[2], s[3]);
