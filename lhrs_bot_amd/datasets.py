@@ -441,9 +441,19 @@ class RS5MDataset(torch.utils.data.IterableDataset):
         self.rank = rank if rank is not None else (dist.get_rank() if on else 0)
         self.world = world_size if world_size is not None else (dist.get_world_size() if on else 1)
         self.epoch = -1
+        self.worker_batches: Optional[int] = None   # with_epoch(n): items per worker per epoch (None: one pass over the shards)
+        self._shared_epoch = None                   # multiprocessing.Value once a loader with workers owns this dataset
         self.collate = DataCollatorForSupervisedDataset(tokenizer=tokenizer) if batch_size else None
 
+    def share_epoch(self) -> None:
+        """Keep the epoch in a `multiprocessing.Value` (the reference's SharedEpoch): persistent DataLoader workers hold their own copy
+        of this object, so a plain attribute set by `set_epoch` in the trainer process would never reach them."""
+        import multiprocessing
+        self._shared_epoch = multiprocessing.Value("i", max(self.epoch, 0))
+
     def set_epoch(self, epoch: int) -> None:
+        if self._shared_epoch is not None:
+            self._shared_epoch.value = int(epoch)
         self.epoch = int(epoch) - 1   # __iter__ advances it: the reference's SharedEpoch / detshuffle2 contract
 
     def _decode(self, s: Dict) -> Optional[Dict]:
@@ -475,8 +485,11 @@ class RS5MDataset(torch.utils.data.IterableDataset):
         info = torch.utils.data.get_worker_info()
         return mine if info is None else mine[info.id::info.num_workers]
 
-    def __iter__(self):
-        self.epoch += 1
+    def _epoch_value(self) -> int:
+        return self._shared_epoch.value if self._shared_epoch is not None else self.epoch
+
+    def _one_pass(self):
+        """One walk over this worker's shards of the current epoch: samples, or whole batches when `batch_size` is set."""
         info = torch.utils.data.get_worker_info()
         rng = random.Random((info.seed if info is not None else self.seed * 7919 + self.rank) + self.epoch)
         raw = itertools.chain.from_iterable(tar_samples(p) for p in self.my_shards())
@@ -491,6 +504,42 @@ class RS5MDataset(torch.utils.data.IterableDataset):
             if len(batch) == self.batch_size:
                 yield self.collate(batch)
                 batch = []                       # partial=False: a trailing short batch is dropped
+
+    def __iter__(self):
+        """`worker_batches` = the reference's `dataset.with_epoch(num_worker_batches)` (build_loader.py:140-142): every worker of every
+        rank yields EXACTLY that many items per epoch, walking its shards again when they run out, so that all ranks leave the epoch at
+        the same step (a rank that ran dry earlier would leave the others waiting in the gradient all-reduce)."""
+        if self._shared_epoch is not None:       # SharedEpoch (cap_dataset.py:523-534): persistent workers see the trainer's set_epoch
+            self.epoch = self._shared_epoch.value
+        else:
+            self.epoch += 1
+        if not self.worker_batches:
+            yield from self._one_pass()
+            return
+        n = 0
+        while n < self.worker_batches:
+            got = 0
+            for item in self._one_pass():
+                yield item
+                got += 1
+                n += 1
+                if n == self.worker_batches:
+                    return
+            if got == 0:
+                raise RuntimeError(f"RS5M: rank {self.rank} found no complete batch in its shards {self.my_shards()}")
+
+
+class _SizedLoader(torch.utils.data.DataLoader):
+    """DataLoader over the iterable RS5M pipeline that knows its epoch length (`Trainer.epoch_len` is `len(data_loader)`): every one
+    of its workers yields exactly `num_batches / num_workers` batches per epoch."""
+
+    num_batches = 0
+
+    def __len__(self) -> int:
+        return int(self.num_batches)
+
+    def set_epoch(self, epoch: int) -> None:
+        self.dataset.set_epoch(epoch)
 
 
 def build_rs5m_loader(config, transform, **kwargs):
@@ -507,11 +556,15 @@ def build_rs5m_loader(config, transform, **kwargs):
         raise FileNotFoundError(f"no RS5M shard found under {config['data_path']} (expected {ds.url})")
     ds.shards = [p for p in ds.shards if Path(p).exists()]
     assert len(ds.shards) >= max(1, workers) * world, "number of shards must be >= total workers"
-    loader = DataLoader(ds, batch_size=None, shuffle=False, num_workers=workers, persistent_workers=workers > 0)
     global_batch = bs * world
-    num_batches = math.ceil(RS5M_NUM_SAMPLES / global_batch)
+    num_samples = int(config.get("rs5m_num_samples", RS5M_NUM_SAMPLES) or RS5M_NUM_SAMPLES)
+    num_batches = math.ceil(num_samples / global_batch)
     nw = max(1, workers)
-    num_batches = math.ceil(num_batches / nw) * nw
+    ds.worker_batches = math.ceil(num_batches / nw)      # with_epoch(num_worker_batches)
+    num_batches = ds.worker_batches * nw
+    if workers > 0:
+        ds.share_epoch()
+    loader = _SizedLoader(ds, batch_size=None, shuffle=False, num_workers=workers, persistent_workers=workers > 0)
     loader.num_batches, loader.num_samples = num_batches, num_batches * global_batch
     loader.length = math.ceil(loader.num_samples / global_batch)
     return loader

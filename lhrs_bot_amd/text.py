@@ -239,6 +239,7 @@ class TextModal:
         self.p = {"embed": p["embed"].to(dev, bf), "norm_w": p["norm_w"].to(dev, bf), "lm_head": p["lm_head"].to(dev, bf),
                   "layers": [{k: v.to(dev, bf).contiguous() for k, v in L.items()} for L in p["layers"]]}
         self.nl = len(self.p["layers"])
+        self._merged_cache = None     # merged copies of the previous weights are stale
         self._finish()
 
     def from_pretrained(self, path: str, n_layers: Optional[int] = None) -> None:
@@ -637,6 +638,8 @@ class TextModal:
         when the caller fetched them already (UniBind.forward does, before it enqueues the ViT)."""
         if labels is None:
             raise ValueError("decode() computes the training loss: labels are required")
+        if save_ctx:
+            self._merged_cache = None     # a training step follows: do not pin ~13.5 GB of merged generate() weights through it
         ids_h, lab_h, msk_h = host_ints if host_ints is not None else self._ints_to_host(input_ids, labels, attention_mask)
         B, T = ids_h.shape
         if image_embedding is None:
@@ -753,6 +756,7 @@ class TextModal:
         reference Linear (q, k, v, o, gate, up, down - the statistics of `double_quant` are per Linear) is quantised by `hk.quant4_blocks`,
         the codes and statistics stay beside the weight (`<name>q4`), and the bf16 weight BECOMES `hk.dequant4_blocks` of them: the ordinary
         bf16 kernels then run the arithmetic bitsandbytes runs.  Parity: oracle/nf4_oracle.py (unpinned against the package)."""
+        self._merged_cache = None     # generate() must not answer from pre-quantisation merged weights
         if bits == 4:
             for L in self.p["layers"]:
                 self._drop_derived(L)

@@ -193,3 +193,27 @@ def test_rs5m_tar_shards_grouping_split_and_batches(tmp_path, monkeypatch):
     assert loader.num_batches == -(-DS.RS5M_NUM_SAMPLES // 2) and len(loader.dataset.shards) == 4
     b = next(iter(loader))
     assert set(b) >= {"rgb", "input_ids", "labels", "attention_mask"} and b["input_ids"].shape[0] == 2
+
+
+def test_rs5m_loader_has_an_epoch_length_and_every_rank_yields_exactly_that_many_batches(tmp_path, monkeypatch):
+    """`dataset.with_epoch(num_worker_batches)` (build_loader.py:131-142): every worker of every rank yields exactly
+    ceil(num_batches / workers) batches per epoch, walking its shards again when they run dry, so `len(loader)` exists (the trainer's
+    `epoch_len`) and two ranks whose shards hold different numbers of samples still leave the epoch at the same step."""
+    from lhrs_bot_amd import conversation as conversation_lib
+    from lhrs_bot_amd.trainer import ConfigDict
+    monkeypatch.setattr(conversation_lib, "default_conversation", conversation_lib.default_conversation)
+    root = str(tmp_path / "RS5M")
+    _make_rs5m_shards(root)                                             # 4 shards of 5 samples (one shard has a caption-less member)
+    tok = DC.ToyTok()
+    counts = []
+    for rank in range(2):
+        cfg = ConfigDict(dict(data_path=root, batch_size=2, workers=2, world_size=2, stage=1, rs5m_num_samples=44))
+        loader = DS.build_rs5m_loader(cfg, lambda im: torch.zeros(3, 4, 4), tokenizer=tok, prompt_type="plain", rank=rank, world_size=2)
+        assert len(loader) == loader.num_batches == 12 and loader.dataset.worker_batches == 6    # ceil(44 / 4) = 11 -> 2 workers x 6
+        loader.set_epoch(0)
+        n0 = sum(1 for _ in loader)
+        loader.set_epoch(1)                                             # persistent workers read the epoch from the shared value
+        n1 = sum(1 for _ in loader)
+        counts.append((n0, n1))
+        del loader
+    assert counts == [(12, 12), (12, 12)]                              # each worker holds ONE 5-sample shard = 2 batches per pass: it re-walks it
