@@ -209,6 +209,9 @@ def timed_run(engine, batch, steps, warmup, world, lib, on_timed_start=None):
     for _ in range(warmup):
         loss = step()
     torch.cuda.synchronize()
+    for r in getattr(engine, "reducers", {}).values():   # N > 1: time the compute stream spends waiting for the gradient collectives
+        r.measure = True
+        r.blocked_ms()
     lib.lhrs_gemm_profile_stride(PROFILE_STRIDE)
     _lib.check(lib.lhrs_gemm_profile_enable(int(os.environ.get("LHRS_GEMM_PROFILE_SAMPLES", "16000"))), "gemm_profile_enable")   # 0: A/B of the event overhead
     if world > 1:
@@ -231,9 +234,13 @@ def timed_run(engine, batch, steps, warmup, world, lib, on_timed_start=None):
     kinds = (ctypes.c_double * 12)()
     _lib.check(lib.lhrs_gemm_profile_read_kinds(ctypes.addressof(kinds)), "gemm_profile_read_kinds")
     lib.lhrs_gemm_profile_enable(0)
+    blocked = 0.0
+    for r in getattr(engine, "reducers", {}).values():
+        blocked += r.blocked_ms()[1]
+        r.measure = False
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
     median = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
-    return dict(dt=dt, loss=loss, prof=list(prof), kinds=list(kinds), median_ms=median)
+    return dict(dt=dt, loss=loss, prof=list(prof), kinds=list(kinds), median_ms=median, blocked_ms_per_step=blocked / max(1, steps))
 
 
 # every 7th launch of each GEMM variant is bracketed by HIP events: timing every launch costs 1.0 % (micro-batch 30) / 2.2 % (micro-batch 8) of
@@ -386,6 +393,26 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
     final_loss = float(loss.item())
+    dp = None
+    if world > 1:
+        # self-validating first contact of the N > 1 path (main_pretrain_stage1.py:54-60): after K optimizer steps on DIFFERENT
+        # per-rank batches every rank must hold the same trainable masters (same reduced gradients, same update) - compare an fp64 checksum
+        # and the sum of |x| of every trainable store across ranks; also gather what each rank's compute stream waited for its collectives
+        sums = torch.stack([torch.stack([st.master.double().sum(), st.master.double().abs().sum()]) for st in engine.stores]).flatten()
+        mine = torch.cat([sums, torch.tensor([run["blocked_ms_per_step"], 1e3 * run["dt"] / a.steps], device=dev, dtype=torch.float64)])
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allv, mine)
+        allv = torch.stack(allv).cpu()
+        n_ck = sums.numel()
+        same = bool((allv[:, :n_ck] == allv[0:1, :n_ck]).all())
+        if not same:
+            raise SystemExit(f"rank {rank}: trainable masters differ across the {world} ranks after {a.steps} steps: checksums {allv[:, :n_ck].tolist()}")
+        dp = {"rccl_ranks": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
+              "reduce_mode": next(iter(engine.reducers.values())).mode if engine.reducers else None,
+              "collectives_per_step": sum(len(r.buckets) for r in engine.reducers.values()),
+              "replica_checksum_equal_on_all_ranks": same, "master_checksum": [float(x) for x in allv[0, :n_ck]],
+              "ms_per_step_blocked_on_allreduce_per_rank": [round(float(x), 3) for x in allv[:, n_ck]],
+              "ms_per_step_per_rank": [round(float(x), 3) for x in allv[:, n_ck + 1]]}
 
     if rank == 0:
         sps = world * B * a.steps / dt
@@ -410,12 +437,13 @@ def main():
                        "lora": None if a.stage == 1 else ("r=8 on q,k,v,o, lora_dropout 0" if a.stage == 3 else "r=128 on all 7 linears, lora_dropout 0.05 (train mode)"),
                        "last_layer_rows": "supervised positions only (same loss and gradients; LHRS_TAIL_ROWS_ONLY=0 computes all)" if os.environ.get("LHRS_TAIL_ROWS_ONLY", "1") != "0" else "all",
                        "grad_allreduce": a.comm_dtype if world > 1 else "none",
-                       "dist_backend": (torch.distributed.get_backend() if world > 1 else None)},
+                       "dist_backend": (torch.distributed.get_backend() if world > 1 else None), "data_parallel": dp},
             "loss": round(final_loss, 4),
             "step_mfma_frac": round(sps / world * f_alg(S) / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 and a.stage == 1 else None,
             "step_mfma_frac_executed": round(sps / world * f_exec / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 and a.stage == 1 else None,
             "roofline": roofline_block(prof, kinds, a.steps, B, S, scale_layers, sclk, watts),
         }
+        res["config"]["step_mfma_frac_executed"] = res["step_mfma_frac_executed"]   # hardware utilisation of the whole step (F_alg minus the rows the engine skips)
         if world == 1 and not a.no_extra and a.stage == 1:
             extra = {}
             try:  # the reference script's micro-batch (Script/train_stage1.sh:11), same engine, its own timed region
@@ -427,12 +455,17 @@ def main():
                         "steps": 12, "warmup": 3, "micro_batch_per_gpu": 8, "loss": round(float(r8["loss"].item()), 4),
                         "step_mfma_frac": round(sps8 * f_alg(S) / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 else None,
                         "roofline": roofline_block(r8["prof"], r8["kinds"], 12, 8, S, scale_layers),
-                        "note": "the reference script's per-GPU batch (an 80 GB-GPU constraint): M = 2184 rows = sixteen 144-row tile rows"}
+                        "note": "the reference script's per-GPU batch (an 80 GB-GPU constraint): M = 2184 rows"}
+                    res["config"]["micro_batch_8"] = {"value": round(sps8, 2), "unit": "samples/s", "ms_per_step": round(1e3 * r8["dt"] / 12, 3),
+                                                      "roofline_frac": res["micro_batch_8"]["roofline"]["frac"],
+                                                      "step_mfma_frac": res["micro_batch_8"]["step_mfma_frac"]}
                 del engine
                 torch.cuda.empty_cache()
                 # one image, ~60-token prompt, 512 new tokens, greedy
                 extra["generate_bf16"] = decode_probe(model, dev, "bf16", new_tokens=512)
                 extra["generate_fp8"] = decode_probe(model, dev, "fp8", new_tokens=512)
+                res["config"]["generate_512_new_tokens"] = {k: {"tokens_per_s": extra[k]["value"], "ms_per_token_step": extra[k]["ms_per_token_step"],
+                                                                "hbm_roofline_frac": extra[k]["roofline"]["frac"]} for k in ("generate_bf16", "generate_fp8")}
             except Exception as e:  # extras must never take the headline number down
                 extra["error"] = f"{type(e).__name__}: {e}"
             res["extra"] = extra

@@ -100,6 +100,8 @@ class GradReducer:
         self.cuda = flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
         self.pending = []
+        self.measure = False     # bench.py: bracket the compute stream's wait in finish() with events (blocked_ms())
+        self._blocked = []
 
     def ready(self, key: str) -> None:
         if key in self.skip:
@@ -132,13 +134,31 @@ class GradReducer:
                     w.wait()
                     if low is not None:
                         buf.copy_(low)
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            if self.measure:   # time the COMPUTE stream spends waiting for the collectives = what the overlap did not hide
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream())
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+                e1.record(torch.cuda.current_stream())
+                self._blocked.append((e0, e1))
+            else:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
         else:
             for w, low, buf in self.pending:
                 w.wait()
                 if low is not None:
                     buf.copy_(low)
         self.pending.clear()
+
+
+    def blocked_ms(self, reset: bool = True):
+        """(finish() calls measured, summed ms the compute stream waited in them); synchronises the recorded events."""
+        n, ms = len(self._blocked), 0.0
+        for e0, e1 in self._blocked:
+            e1.synchronize()
+            ms += e0.elapsed_time(e1)
+        if reset:
+            self._blocked = []
+        return n, ms
 
 
 class _TrainStore:

@@ -73,6 +73,9 @@ def test_bench_gpus2_self_spawns_ranks():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
     assert d["config"]["grad_allreduce"] == "float32" and d["config"]["dist_backend"] == ("nccl" if two else "gloo")
     assert d["value"] > 0 and "cpu_baseline" not in d
+    dp = d["config"]["data_parallel"]   # the N > 1 line validates itself: equal trainable masters on every rank after the timed steps
+    assert dp["rccl_ranks"] == 2 and dp["replica_checksum_equal_on_all_ranks"] is True and dp["reduce_mode"] == "bucketed"
+    assert len(dp["ms_per_step_blocked_on_allreduce_per_rank"]) == 2 and len(dp["ms_per_step_per_rank"]) == 2 and dp["collectives_per_step"] >= 1
 
 
 @pytest.mark.timeout(1500)
@@ -92,3 +95,5 @@ def test_bench_gpus8_plumbing_on_a_shared_device():
     assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp8" and d["scaling"] == "weak"
     assert d["config"]["dist_backend"] == "gloo" and d["config"]["grad_allreduce"] == "float32" and d["value"] > 0
     assert "configs[2]" in d["config"]["workload"] and "cpu_baseline" not in d and "micro_batch_8" not in d
+    dp = d["config"]["data_parallel"]
+    assert dp["rccl_ranks"] == 8 and dp["replica_checksum_equal_on_all_ranks"] is True and len(dp["ms_per_step_per_rank"]) == 8

@@ -21,7 +21,7 @@ def rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
-def make(targets, r, train_pooler):
+def make(targets, r, train_pooler, B_=2, T=20, ragged=True):
     nl = 2
     P = {"vit": OP.make_vit_params(seed=2), "pooler": OP.make_pooler_params(seed=1), "llama": OP.make_llama_params(seed=3, layers=nl)}
     model = UniBind(("rgb", "text"), None, device=DEV, llama_layers=nl).load_params(P)
@@ -36,11 +36,11 @@ def make(targets, r, train_pooler):
             P["llama"]["layers"][l]["lora"][pr] = (A.cpu().clone().requires_grad_(True), Bn.clone().requires_grad_(True))
     lora.refresh()
     model.prepare_for_training(freeze_vision=True, freeze_text=False, tune_rgb_pooler=train_pooler)
-    B_, T = 2, 20
     ids = torch.randint(3, 32000, (B_, T), generator=g)
     ids[:, 0] = 1
     ids[:, 1] = -200
-    ids[1, 16:] = 0
+    if ragged:
+        ids[1, 16:] = 0
     labels = ids.clone()
     labels[:, :2] = -100
     labels[ids == 0] = -100
@@ -84,6 +84,34 @@ def test_lora_forward_backward_and_adamw(targets, r, train_pooler):
     # the refreshed operands are used by the next forward: loss must change and stay finite
     out2 = eng(batch)
     assert torch.isfinite(out2["total_loss"]) and out2["total_loss"].item() != out["total_loss"].item()
+
+
+@pytest.mark.timeout(2400)
+def test_stage3_shape_micro_batch_32_lora_r8_qkvo_vs_oracle():
+    """BASELINE configs[3]'s per-GPU part: LoRA r = 8 on q, k, v, o at micro-batch 32, S = 273 (M = 8736 = 34 full 256-row tile rows + 32
+    rows: the partial-round / tail path of the persistent GEMM with the fused LoRA operand pair), 2 layers, projector trained too:
+    loss, every adapter's dA / dB and d loss / d image against oracle autograd (fp32, host cores)."""
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    targets = ("q", "k", "v", "o")
+    model, lora, P, batch = make(targets, 8, True, B_=32, T=130, ragged=False)
+    out = model(batch)
+    d_image = model.text.backward(need_input_grad=True)
+    torch.cuda.synchronize()
+    col = {}
+    loss = O.unibind_forward(P, batch, col)
+    col["image"].retain_grad()
+    loss.backward()
+    assert abs(out["total_loss"].item() - loss.item()) < 1e-3 * loss.item(), (out["total_loss"].item(), loss.item())
+    bad = []
+    for l in range(2):
+        for pr in targets:
+            dA, dB = lora.grad_adapter(l, pr)
+            Ao, Bo = P["llama"]["layers"][l]["lora"][pr]
+            ea, eb = rel(dA, Ao.grad), rel(dB, Bo.grad)
+            if ea > 6e-2 or eb > 6e-2:
+                bad.append((l, pr, ea, eb))
+    assert not bad, bad
+    assert rel(d_image, col["image"].grad) < 5e-2
 
 
 @pytest.mark.timeout(900)

@@ -26,6 +26,22 @@ def rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
+def oracle_pooler_grads(P):
+    """name (the reference AttnPooler's state-dict key) -> oracle autograd gradient, for every one of the 87 projector tensors."""
+    out = {}
+    for name, t in OP.pooler_to_ref(P["pooler"]).items():
+        base = t if t.is_leaf else t._base          # only `query` is a view ([None]) of its leaf
+        out[name] = (P["pooler"]["query"].grad if name == "query" else base.grad).double()
+    return out
+
+
+def assert_projector_grads_directional(got, want, tol):
+    """Every projector gradient by relative L2 of the DIFFERENCE (a norm alone cannot see a transposed or permuted dW)."""
+    assert len(got) == 87 and set(got) == set(want)
+    bad = [(n, rel(got[n].reshape(want[n].shape), want[n])) for n in got if rel(got[n].reshape(want[n].shape), want[n]) > tol]
+    assert not bad, bad
+
+
 def test_pooler_forward_backward_vs_reference_golden():
     z = np.load(os.path.join(G, "pooler.npz"))
     g = torch.Generator().manual_seed(int(z["input_seed"]))
@@ -221,7 +237,7 @@ def test_full_depth_32_layers_s273_vs_oracle_on_host_cpu():
     against the fp32 oracle run on the GPU box's HOST cores with the same seeded parameters (27 GB fp32; the oracle is pinned to the
     reference at this sequence length by tests/test_oracle_cpu.py::test_unibind_headline_shape_s273_matches_reference and at depth by the
     8-layer fixture).  Checks bf16 drift over 32 residual layers: loss 1e-3, final-norm hidden 3e-2, d loss / d image 6e-2, every one
-    of the 87 projector gradient norms 6e-2."""
+    of the 87 projector gradients by rel-L2 of the difference 7e-2."""
     import gc
     torch.set_num_threads(min(64, os.cpu_count() or 1))
     NL, T = 32, 130
@@ -240,7 +256,7 @@ def test_full_depth_32_layers_s273_vs_oracle_on_host_cpu():
     d_image = model.text.backward()
     model.rgb_pooler.backward(d_image)
     torch.cuda.synchronize()
-    got_norms = {n: model.rgb_pooler.g[n].double().norm().item() for n, _ in model.rgb_pooler.named_parameters()}
+    got_grads = {n: model.rgb_pooler.g[n].double().cpu() for n, _ in model.rgb_pooler.named_parameters()}
     d_image = d_image.float().cpu()
     # ---- oracle on the host
     leaves = {}
@@ -285,15 +301,8 @@ def test_full_depth_32_layers_s273_vs_oracle_on_host_cpu():
     assert err_h < max(3e-2, 1.5 * yard_h), msg
     assert err_g < max(6e-2, 1.5 * yard_g), msg
     assert err_h2 < 1.1 * yard_h and err_g2 < 1.1 * yard_g, msg   # one rounding per fused kernel: not further from fp32 than op-by-op bf16
-    ref_sd = OP.pooler_to_ref(P["pooler"])
-    bad = []
-    for name, got in got_norms.items():
-        t = ref_sd[name]
-        base = t if t.is_leaf else t._base
-        w = (P["pooler"]["query"].grad if name == "query" else base.grad).double().norm().item()
-        if abs(got - w) > 6e-2 * w:
-            bad.append((name, got, w))
-    assert len(got_norms) == 87 and not bad, bad
+    # every one of the 87 projector gradients by rel-L2 of the difference (directional), not by norm
+    assert_projector_grads_directional(got_grads, oracle_pooler_grads(P), 7e-2)
     del P, model, col
     gc.collect()
 
@@ -344,12 +353,13 @@ def test_last_layer_on_supervised_rows_only_equals_every_row(ragged):
 
 
 @pytest.mark.timeout(2400)
-@pytest.mark.parametrize("B", [8, 30])
+@pytest.mark.parametrize("B", [8, 30, 60])
 def test_measured_micro_batches_end_to_end_vs_oracle(B):
     """The micro-batches bench.py measures - 8 (Script/train_stage1.sh:11) and 30 (the bench default) - at the
     headline sequence length S = 273 with 2 decoder layers, default engine settings (persistent 256x256 GEMM at M = 2184 / 8190 with its
-    tail-row rule, fused RoPE / SwiGLU epilogues, last layer on the supervised rows): loss, d loss / d image and all 87 projector
-    gradient norms against oracle autograd (fp32, host cores) on the same seeded parameters."""
+    tail-row rule, fused RoPE / SwiGLU epilogues, last layer on the supervised rows; 60 = the B = 60 line of DESIGN §4.1: 64 tile rows):
+    loss, the ViT taps of EVERY sample, d loss / d image and all 87 projector gradients - each by rel-L2 of the difference, so a
+    transposed or permuted dW cannot hide behind a matching norm - against oracle autograd (fp32, host cores) on the same seeded parameters."""
     torch.set_num_threads(min(64, os.cpu_count() or 1))
     P = {"vit": OP.make_vit_params(seed=2), "pooler": OP.make_pooler_params(seed=1), "llama": OP.make_llama_params(seed=3, layers=2)}
     model = UniBind(("rgb", "text"), None, device=DEV, llama_layers=2).load_params(P)
@@ -379,14 +389,5 @@ def test_measured_micro_batches_end_to_end_vs_oracle(B):
     want.backward()
     assert abs(loss - want.item()) < 1e-3 * want.item(), (loss, want.item())
     assert rel(d_image, col["image"].grad) < 5e-2
-    ref_sd = OP.pooler_to_ref(P["pooler"])
-    bad = []
-    for name, gv in got.items():
-        t = ref_sd[name]
-        base = t if t.is_leaf else t._base
-        w = (P["pooler"]["query"].grad if name == "query" else base.grad).double()
-        if abs(gv.norm().item() - w.norm().item()) > 5e-2 * w.norm().item():
-            bad.append((name, gv.norm().item(), w.norm().item()))
-    assert len(got) == 87 and not bad, bad
-    assert rel(got["out_proj.bias"], P["pooler"]["out_proj_b"].grad) < 5e-2
-    assert rel(got["query"], P["pooler"]["query"].grad.reshape(got["query"].shape)) < 5e-2
+    assert rel(model.rgb.encode(batch["rgb"]), col["taps"].detach()) < 2e-2          # all B samples, all 768 tap tokens
+    assert_projector_grads_directional(got, oracle_pooler_grads(P), 5e-2)
