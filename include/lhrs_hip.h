@@ -120,6 +120,23 @@ int lhrs_gemm_set_persistent(int on);
  * is 16 x 16 = 256 tiles of 144 x 256 instead of 144 tiles of 256 x 256 -, 2 = 144 rows wherever the kernel applies (A/B tests).  Results
  * are bit-identical between the two tile heights. */
 int lhrs_gemm_set_bm144(int mode);
+/* ---- stream-K for the last, partial round of the persistent 256x256 kernel (no reference counterpart: the reference's GEMMs are torch /
+ * hipBLASLt calls reached from lhrs/models/text_modal.py:258-294; this removes the wave-quantisation loss of OUR tile walk) ---------------
+ * T tiles on P CUs cost ceil(T / P) rounds; with a workspace registered the T % P tiles of the last round are cut along k into P contiguous
+ * ranges of 64-k stages (one per CU), partial fp32 accumulators travel through the workspace, the CU that holds a tile's first stage adds
+ * them in a fixed order and runs the (fused) epilogue.  Deterministic; differs from the unsplit kernel by fp32 re-association only.
+ * The workspace is CALLER-OWNED device memory of lhrs_gemm_streamk_workspace_bytes() bytes, 256-B aligned, registered per device; every
+ * GEMM launch that may use it must be ordered on one stream.  ws = NULL unregisters (stream-K off: whole rounds only).
+ * lhrs_gemm_set_streamk(0 | 1): default 0 - measured slower than whole rounds at every shape of the path on MI355X (the k-ranges lose the L2
+ * sharing of operand panels between the tiles of an XCD, and the slab exchange is exposed; numbers in csrc/gemm.hip and DESIGN.md §3.1). */
+long lhrs_gemm_streamk_workspace_bytes(void);
+int lhrs_gemm_set_streamk_workspace(void* ws, long bytes);
+int lhrs_gemm_set_streamk(int on);
+/* host replay of the decomposition (tests; launches nothing): T tiles of nk stages, nk2 of them from the second operand pair; returns -1
+ * when stream-K does not apply, else out[0..2] = {tiles of the whole rounds, stream-K tiles, units} and, for unit >= 0, out[3..9] = {first
+ * tile of the unit's range, first stage there, stages in that tile, stages in the next tile, first item is a partial, partials added to the
+ * first / second item}.  assume_ws != 0: plan as if a workspace were registered (CPU tests). */
+int lhrs_gemm_streamk_plan(long T, int nk, int nk2, int assume_ws, int unit, int* out);
 /* ---- LLM.int8() base (the reference's `bits: 8`: lhrs/models/text_modal.py:91-131 -> bitsandbytes MatMul8bitLt, 0.41 series) --------------
  * weights once: lhrs_quant_int8_rows -> int8 rows + factor absmax / 127 per row; lhrs_dequant_int8_rows -> the 16-bit weight CB * factor that
  * the backward (dx = dy . dequant(W)) and generate() use.  Per product: lhrs_int8_prepare scans x for outlier columns (any |x| >= thr = 6.0),

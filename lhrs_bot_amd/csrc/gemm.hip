@@ -70,6 +70,16 @@ struct GemmArgs {
   // 8-bit kernels: bf16 columns of the second pair whose count is only known on the device (LLM.int8 outlier columns; a multiple of 64),
   // appended behind the K2 host-known ones (nullptr = none)
   const int* k2_dev;
+  // persistent 16-wave kernel: the tiles one launch walks are the raster positions [0, ntiles) (ntiles = tilesM * tilesN unless a stream-K
+  // launch takes the positions behind them)
+  int ntiles;
+  // stream-K launch (gemm_nt_256s_kernel<..., SK = true>): the raster positions [sk_tile0, sk_tile0 + sk_tiles) - the tiles of the last,
+  // partial round of the CUs - are cut along k into sk_units contiguous ranges of stages, one per workgroup; a workgroup whose range starts
+  // inside a tile writes its fp32 accumulators to slab `unit` of sk_ws and raises sk_flags[unit]; the workgroup that holds the tile's stage
+  // 0 adds the slabs of the others and runs the epilogue (the caller owns sk_ws / sk_flags; the flags are zero between launches)
+  int sk_tile0, sk_tiles, sk_units;
+  float* sk_ws;
+  int* sk_flags;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -77,6 +87,17 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // tile `bid` of `nblk` (the order tiles are dispatched in) -> (tm, tn): consecutive bids alternate over the 8 XCDs (bid & 7), so each XCD
 // gets a contiguous run of the m-fastest raster grouped by 8 tile rows - the 32 tiles an XCD works on at a time share 8 A and 4 B panels
+// raster position `lin` -> (tm, tn): m-fastest inside groups of 8 tile rows
+__device__ __forceinline__ void tile_coords_raster(const GemmArgs& g, int lin, int& tm, int& tn) {
+  constexpr int GM = 8;
+  const int per_group = GM * g.tilesN;
+  const int group = lin / per_group;
+  const int first_m = group * GM;
+  const int gsize = min(g.tilesM - first_m, GM);
+  const int in_g = lin - group * per_group;
+  tm = first_m + in_g % gsize;
+  tn = in_g / gsize;
+}
 __device__ __forceinline__ void tile_coords_lin(const GemmArgs& g, int bid, int nblk, int& tm, int& tn) {
   const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
   const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -501,15 +522,27 @@ __device__ __forceinline__ void lds_wait8(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int ACT, int EPI, bool K2P>
+// SK = true: the stream-K launch for the tiles of the last, partial round (GemmArgs::sk_*): a workgroup computes a contiguous range of
+// k-stages that covers the end of one tile and / or the start of the next one instead of whole tiles.  Same main loop: a work item is the
+// stages [S0, S0 + nkl) of a tile (SK = false: S0 = 0, nkl = all of them - the compiler folds both).
+constexpr int SK_MINSEG = 4;   // no item shorter than this many stages (the pipeline needs 2); cut points closer to a tile edge snap to it
+// cut point `uu` of `units` over the sk_tiles * nk stages of the tail tiles (host + device: lhrs_gemm_streamk_plan replays it for the tests)
+__host__ __device__ __forceinline__ int sk_cut(int uu, int sk_tiles, int nk, int units) {
+  int x = (int)((long)uu * ((long)sk_tiles * nk) / units);
+  const int r = x % nk;
+  if (r < SK_MINSEG) x -= r;
+  else if (r > nk - SK_MINSEG) x += nk - r;
+  return x;
+}
+template <int ACT, int EPI, bool K2P, bool SK = false>
 __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
   constexpr int BM = 256, BN = 256, BK = 64;
   constexpr int A_BYTES = BM * BK * 2, STAGE = A_BYTES + BN * BK * 2;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
-  const int ntiles = g.tilesM * g.tilesN;
+  const int ntiles = g.ntiles;
   int t = blockIdx.x;
-  if (t >= ntiles) return;
+  if (!SK && t >= ntiles) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -576,13 +609,33 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
   const unsigned a0 = lds0 + (wm * 64 + (lane & 15)) * 128 + (((lane >> 4)) ^ sw) * 16;
   const unsigned b0 = lds0 + A_BYTES + (wn * 64 + (lane & 15)) * 128 + (((lane >> 4)) ^ sw) * 16;
 
+  int S0 = 0, nkl = nk;   // the current work item: stages [S0, S0 + nkl) of its tile
+  // stream-K: unit u of sk_units owns the stages [bnd(u), bnd(u + 1)) of the sk_tiles * nk stages of the tail tiles (cut points within
+  // SK_MINSEG stages of a tile edge snap to it).  Its range is the end of tile sk_i0 (from stage S0: a PARTIAL unless S0 == 0) and / or the
+  // first sk_n1 stages of tile sk_i0 + 1; the unit that holds a tile's stage 0 finishes the tile (adds the others' partials, epilogue)
+  int sk_u = 0, sk_i0 = 0, sk_n1 = 0, sk_seg = 0;
+  auto sk_bnd = [&](int uu) { return sk_cut(uu, g.sk_tiles, nk, g.sk_units); };
   int tm, tn;
-  tile_coords_lin(g, t, ntiles, tm, tn);
+  if constexpr (SK) {
+    const int U = g.sk_units;
+    sk_u = blockIdx.x;
+    if ((U & 7) == 0) sk_u = (sk_u & 7) * (U >> 3) + (sk_u >> 3);   // neighbouring units (they exchange partials) on one XCD
+    const int b0 = sk_bnd(sk_u), b1 = sk_bnd(sk_u + 1);
+    if (b1 <= b0) return;
+    sk_i0 = b0 / nk;
+    S0 = b0 - sk_i0 * nk;
+    const int e0 = min(b1, (sk_i0 + 1) * nk);
+    nkl = e0 - b0;
+    sk_n1 = b1 - e0;
+    tile_coords_raster(g, g.sk_tile0 + sk_i0, tm, tn);
+  } else {
+    tile_coords_lin(g, t, ntiles, tm, tn);
+  }
   unsigned off1[4];
   dma_rows(tm, tn, off1);
   int pb = 0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) issue1(off1, 0, 0, j);
+  for (int j = 0; j < 4; ++j) issue1(off1, S0, 0, j);   // (a stream-K item never starts inside the second operand pair: host rule)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   bf16x8 A[4], B[4];
@@ -592,7 +645,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
 
   for (;;) {
     const int tnext = t + (int)gridDim.x;
-    const bool has_next = tnext < ntiles;  // workgroup-uniform
+    const bool has_next = SK ? (sk_seg == 0 && sk_n1 > 0) : (tnext < ntiles);  // workgroup-uniform
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -603,8 +656,8 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (!K2P || nk1 > 1) issue1(off1, 1, pb ^ 1, j);
-      else issue2(tm, tn, 0, pb ^ 1, j);
+      if (!K2P || S0 + 1 < nk1) issue1(off1, S0 + 1, pb ^ 1, j);
+      else issue2(tm, tn, S0 + 1 - nk1, pb ^ 1, j);
     }
     {
       const unsigned aa = a0 ^ (unsigned)(pb * STAGE), ba = b0 ^ (unsigned)(pb * STAGE);
@@ -621,37 +674,87 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
       { const unsigned aa = a0 ^ (so | 64u), ba = b0 ^ (so | 64u); S_BLOCK0(aa, ba) }                           \
       { const unsigned aa = a0 ^ sn, ba = b0 ^ sn; S_BLOCK1(aa, ba) }                                           \
     }
-#define ISS(j) issue1(off1, s + 2, (s + pb) & 1, j);
-    for (int s = 0; s < nk1 - 2; ++s) STAGE_S(s)   // !K2P: nk1 == nk, every stage but the last two
+    // local stage s fetches the item's stage s + 2 = stage S0 + s + 2 of the tile: from the first pair while that is < nk1
+    const int nA = K2P ? min(nkl - 2, nk1 - 2 - S0) : nkl - 2;
+#define ISS(j) issue1(off1, S0 + s + 2, (s + pb) & 1, j);
+    for (int s = 0; s < nA; ++s) STAGE_S(s)   // !K2P: every stage but the last two
 #undef ISS
     if (K2P) {  // the stages whose DMA slot fetches the second pair
-#define ISS(j) issue2(tm, tn, s + 2 - nk1, (s + pb) & 1, j);
-      for (int s = max(nk1 - 2, 0); s < nk - 2; ++s) STAGE_S(s)
+#define ISS(j) issue2(tm, tn, S0 + s + 2 - nk1, (s + pb) & 1, j);
+      for (int s = max(nA, 0); s < nkl - 2; ++s) STAGE_S(s)
 #undef ISS
     }
     int ntm = 0, ntn = 0;
     if (has_next) {  // this tile's DMA rows are not needed any more (its last stage is in flight): the offsets become the next tile's
-      tile_coords_lin(g, tnext, ntiles, ntm, ntn);
+      if constexpr (SK) tile_coords_raster(g, g.sk_tile0 + sk_i0 + 1, ntm, ntn);
+      else tile_coords_lin(g, tnext, ntiles, ntm, ntn);
       dma_rows(ntm, ntn, off1);
     }
-    // stage nk - 2: the buffer its barrier frees takes stage 0 of the NEXT tile
-#define ISS(j) if (has_next) issue1(off1, 0, (nk + pb) & 1, j);
-    STAGE_S(nk - 2)
+    // stage nkl - 2: the buffer its barrier frees takes the first stage of the NEXT item (always a tile's stage 0)
+#define ISS(j) if (has_next) issue1(off1, 0, (nkl + pb) & 1, j);
+    STAGE_S(nkl - 2)
 #undef ISS
 #undef STAGE_S
     {  // last stage: nothing left to fetch behind it
-      const unsigned so = ((nk - 1 + pb) & 1) * STAGE;
+      const unsigned so = ((nkl - 1 + pb) & 1) * STAGE;
       { const unsigned aa = a0 ^ (so | 64u), ba = b0 ^ (so | 64u); S_BLOCK0(aa, ba) }
       S_BLOCK1_FINAL(0, 0)
     }
 
+    bool sk_partial = false;
+    if constexpr (SK) {
+      // slab layout: [unit][wave][mi][ni][lane] float4 - exactly this lane's accumulator registers, 1 KiB per wave instruction
+      if (S0 != 0) {
+        // PARTIAL of a tile another unit finishes: accumulators -> slab sk_u, then publish (agent-scope release behind every wave's
+        // drained stores, then the flag: cdna_hip_programming.md §6 Guideline 16)
+        sk_partial = true;
+        float4* dst = reinterpret_cast<float4*>(g.sk_ws + (size_t)sk_u * (BM * BN)) + wave * 1024 + lane;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            dst[(mi * 4 + ni) * 64] = make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(g.sk_flags + sk_u, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else if (nkl != nk) {
+        // this unit holds the tile's stage 0 but not all of it: add the partials of the units that hold the rest (units sk_u + 1 ... whose
+        // cut point lies inside this tile), in unit order (a fixed summation order: deterministic results)
+        const int tile_end = (sk_i0 + sk_seg + 1) * nk;
+        if (tid == 0) {
+          for (int p = sk_u + 1; p < g.sk_units && sk_bnd(p) < tile_end; ++p) {
+            if (sk_bnd(p + 1) <= sk_bnd(p)) continue;   // an empty unit writes nothing
+            while (__hip_atomic_load(g.sk_flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+            __hip_atomic_store(g.sk_flags + p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // flags are zero again when the launch ends
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        for (int p = sk_u + 1; p < g.sk_units && sk_bnd(p) < tile_end; ++p) {
+          if (sk_bnd(p + 1) <= sk_bnd(p)) continue;
+          const float4* src = reinterpret_cast<const float4*>(g.sk_ws + (size_t)p * (BM * BN)) + wave * 1024 + lane;
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+              const float4 v = src[(mi * 4 + ni) * 64];
+              acc[mi][ni][0] += v.x; acc[mi][ni][1] += v.y; acc[mi][ni][2] += v.z; acc[mi][ni][3] += v.w;
+            }
+        }
+      }
+    }
     // accumulator element acc[mi][ni][i]: m = wm*64 + mi*16 + fr, n = wn*64 + ni*16 + fg*4 + i.
     // Everything the epilogue derives from the lane id is derived from an opaque copy made HERE, per tile: otherwise those values are
     // loop-invariant across tiles, get hoisted in front of the tile loop and sit in (or spill from) registers all through the main loop
     int le = lane;
     asm volatile("" : "+v"(le));
     const int fr = le & 15, fg = le >> 4;
-    if (g.out_f32) {
+    if (sk_partial) {
+    } else if (g.out_f32) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
         const int m = tm * BM + wm * 64 + mi * 16 + fr;
@@ -665,7 +768,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
       }
     } else {
       __builtin_amdgcn_s_barrier();  // every wave has read its last fragments: the last stage's buffer becomes the staging area
-      char* reg = smem + ((nk - 1 + pb) & 1) * STAGE + wave * 4096;  // [32 rows][64 cols] bf16, wave private, one pass per 32 rows
+      char* reg = smem + ((nkl - 1 + pb) & 1) * STAGE + wave * 4096;  // [32 rows][64 cols] bf16, wave private, one pass per 32 rows
       const bool rope_tile = EPI == 3 && tn * BN < g.rope_cols;
       const int rsub = le >> 3, c = le & 7;
       const int n = EPI == 1   ? (c < 4 ? 0 : g.ff) + tn * 128 + wn * 32 + (c & 3) * 8
@@ -798,7 +901,8 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
     if (!has_next) break;
     if (g.out_f32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     t = tnext; tm = ntm; tn = ntn;
-    pb = (pb + nk) & 1;
+    pb = (pb + nkl) & 1;
+    if constexpr (SK) { sk_seg = 1; S0 = 0; nkl = sk_n1; }
   }
 #undef MF
 #undef SB
@@ -1168,12 +1272,6 @@ static int g_gemm_allow_256 = 2;
 // workgroup b takes tiles b, b + grid, ...  0 = one workgroup per tile (kernel A/B tests: lhrs_gemm_set_persistent)
 static int g_gemm_persist = 1;
 extern "C" int lhrs_gemm_set_persistent(int on) { g_gemm_persist = on; return 0; }
-// the 16-wave kernel; a second operand pair (K2 > 0: the fused LoRA product) is a template parameter of it
-#define LAUNCH_256(ACT_, EPI_, grid_, s_, g_)                                                                          \
-  do {                                                                                                                 \
-    if ((g_).K2 > 0) hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT_, EPI_, true>), grid_, dim3(1024), 0, s_, g_);        \
-    else hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT_, EPI_, false>), grid_, dim3(1024), 0, s_, g_);                   \
-  } while (0)
 #define LAUNCH_144(ACT_, EPI_, grid_, s_, g_) hipLaunchKernelGGL((gemm_nt_144s_kernel<ACT_, EPI_>), grid_, dim3(768), 0, s_, g_)
 static int num_cus() {
   static int n = 0;
@@ -1186,6 +1284,109 @@ static int num_cus() {
   return n;
 }
 static dim3 grid_256s(long tiles) { return dim3((unsigned)(g_gemm_persist ? (tiles < num_cus() ? tiles : num_cus()) : tiles)); }
+
+// ---- stream-K for the last, partial round of the persistent 16-wave kernel -------------------------------------------------------------
+// T tiles on P CUs run as ceil(T / P) rounds and a nearly empty last round costs a full one (M = 8190, N = 11008: 1376 tiles = 5.375 rounds
+// -> 6; M = 8736, N = 4096: 560 = 2.19 -> 3; M = 2184, N = 4096: 144 = 0.56 -> 1).  With a workspace registered the floor(T / P) full rounds
+// run as before and the T % P tiles behind them go to a second launch of the same kernel (SK = true) that cuts their k-loops into P
+// contiguous ranges of stages, one per CU: the tail then costs (T % P) / P of a round plus the exchange of the fp32 partials.  The
+// workspace belongs to the caller (P slabs of 256 x 256 floats behind 4 KiB of flags = 64 MiB + 4 KiB); launches that use it must be
+// ordered on ONE stream.  Summation order is fixed by the shape alone: results are deterministic, and differ from the unsplit kernel's
+// only by fp32 re-association inside the split tiles.
+static struct { float* slabs; int* flags; long units; } g_sk[16];
+// MEASURED (round 4, tools/gemm_sk_ab.py, one box, us per launch whole rounds / stream-K): M = 8190: d-down + SwiGLU' (5.375 rounds) 672 / 691-802,
+// gate|up + SwiGLU (10.75) 1121-1153 / 1198-1341, lm_head 773-791 / 799-873; M = 8736 (2.19 rounds): o 239 / 285; M = 2184 (0.56 rounds): o 69
+// (144-row tiles) / 126, down 171 / 268.  SLOWER everywhere, for two reasons that belong to this chip, not to the code: (1) the 32 tiles an XCD
+// walks concurrently share 8 A and 4 B panels through its L2 only while they sit at the SAME k; ranges that start at different stages of
+// their tiles stream every panel from the Infinity Cache on their own (2.8 us per stage instead of 1.5); (2) a 256 KiB fp32 slab costs
+// 10-30 us to publish (store-issue-bound, then the L2 write-back of the release) and the unit that needs it finishes at the same moment
+// as the unit that writes it, so the exchange is exposed.  Therefore OFF by default; kept, with its tests, as the correct starting point for an
+// XCD-lockstep variant (units = groups of 16-32 CUs on 16-32 tiles at one k): DESIGN.md §3.1.
+static int g_gemm_streamk = 0;   // lhrs_gemm_set_streamk
+extern "C" int lhrs_gemm_set_streamk(int on) { g_gemm_streamk = on; return 0; }
+extern "C" long lhrs_gemm_streamk_workspace_bytes() { return 4096 + (long)num_cus() * 256 * 256 * 4; }
+// ws == nullptr: forget the workspace of the current device (stream-K off)
+extern "C" int lhrs_gemm_set_streamk_workspace(void* ws, long bytes) {
+  int dev = 0;
+  LHRS_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "streamk_workspace: device %d", dev);
+  if (ws == nullptr) { g_sk[dev].slabs = nullptr; g_sk[dev].flags = nullptr; g_sk[dev].units = 0; return 0; }
+  LHRS_REQUIRE(bytes >= lhrs_gemm_streamk_workspace_bytes() && ((size_t)ws & 255) == 0, "streamk_workspace: %ld bytes (need %ld, 256-B aligned)", bytes,
+               lhrs_gemm_streamk_workspace_bytes());
+  LHRS_REQUIRE(hipMemset(ws, 0, 4096) == hipSuccess, "streamk_workspace: cannot clear the flags");
+  g_sk[dev].flags = (int*)ws; g_sk[dev].slabs = (float*)((char*)ws + 4096); g_sk[dev].units = num_cus();
+  return 0;
+}
+// rounds of the P CUs (in units of one full 256x256 tile's k-loop of nk stages) that T tiles cost on the 16-wave kernel, and whether the
+// tail goes to the stream-K launch.  Fixed costs of that launch: a kernel boundary, one prologue per range, the slab round trip ~ 8 stages
+static double rounds_256(long T, int nk, int nk2, bool drop, bool* use_sk) {
+  const long P = num_cus();
+  int dev = 0;
+  const long tail = T % P;
+  bool sk = g_gemm_streamk && g_gemm_persist && tail != 0 && !drop && nk2 < 4 && nk >= 16 && P <= 1020 &&
+            hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && g_sk[dev].slabs != nullptr && g_sk[dev].units >= P;
+  const double cost_sk = (double)(T / P) + (double)tail / P + 8.0 / nk;
+  if (sk && cost_sk > (double)(T / P) + 0.92) sk = false;
+  if (use_sk) *use_sk = sk;
+  return sk ? cost_sk : (double)((T + P - 1) / P);
+}
+static int sk_units_for(long sk_tiles, int nk) {
+  const long W = sk_tiles * nk, P = num_cus();
+  const long u = W / 10 < P ? W / 10 : P;          // >= 10 stages per range on average (>= SK_MINSEG after snapping)
+  return (int)(u < 1 ? 1 : u);
+}
+// The stream-K decomposition as the kernels compute it, replayed on the host (tests; no launch).  T tiles of nk stages (nk2 of them from the
+// second operand pair), workspace assumed registered when `assume_ws`.  out[0] = tiles of the whole rounds, out[1] = stream-K tiles, out[2] =
+// units.  unit >= 0: out[3] = first tile of the unit's range (relative to out[0]), out[4] = its first stage there, out[5] = stages in that
+// tile, out[6] = stages in the next tile, out[7] = 1 if the first item is a PARTIAL (another unit finishes the tile), out[8] / out[9] = partials
+// the unit adds to its first / second item.  Returns 0, or -1 when stream-K does not apply.
+extern "C" int lhrs_gemm_streamk_plan(long T, int nk, int nk2, int assume_ws, int unit, int* out) {
+  const long P = num_cus(), tail = T % P;
+  bool sk = tail != 0 && nk2 < 4 && nk >= 16 && (double)tail / P + 8.0 / nk <= 0.92;
+  if (!assume_ws) (void)rounds_256(T, nk, nk2, false, &sk);
+  if (!sk) return -1;
+  const int units = sk_units_for(tail, nk), st = (int)tail;
+  out[0] = (int)(T - tail); out[1] = st; out[2] = units;
+  if (unit < 0) return 0;
+  const int b0 = sk_cut(unit, st, nk, units), b1 = sk_cut(unit + 1, st, nk, units);
+  for (int i = 3; i < 10; ++i) out[i] = 0;
+  if (b1 <= b0) return 0;
+  const int i0 = b0 / nk, S0 = b0 - i0 * nk, e0 = b1 < (i0 + 1) * nk ? b1 : (i0 + 1) * nk;
+  out[3] = i0; out[4] = S0; out[5] = e0 - b0; out[6] = b1 - e0; out[7] = S0 != 0;
+  for (int seg = 0; seg < 2; ++seg) {
+    const int n = seg == 0 ? out[5] : out[6], s0 = seg == 0 ? S0 : 0;
+    if (n == 0 || s0 != 0 || n == nk) continue;
+    const int tile_end = (i0 + seg + 1) * nk;
+    for (int p = unit + 1; p < units && sk_cut(p, st, nk, units) < tile_end; ++p)
+      if (sk_cut(p + 1, st, nk, units) > sk_cut(p, st, nk, units)) out[8 + seg]++;
+  }
+  return 0;
+}
+template <int ACT, int EPI>
+static void launch_256s(GemmArgs& g, hipStream_t s) {
+  const long T = (long)g.tilesM * g.tilesN, P = num_cus();
+  const int nk = (g.K + g.K2) / 64;
+  bool sk = false;
+  (void)rounds_256(T, nk, g.K2 / 64, g.drop_thresh != 0, &sk);
+  g.ntiles = (int)T; g.sk_tile0 = 0; g.sk_tiles = 0; g.sk_units = 0; g.sk_ws = nullptr; g.sk_flags = nullptr;
+  if (sk) g.ntiles = (int)(T / P * P);
+  if (g.ntiles > 0) {
+    const dim3 grid = grid_256s(g.ntiles);
+    if (g.K2 > 0) hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT, EPI, true, false>), grid, dim3(1024), 0, s, g);
+    else hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT, EPI, false, false>), grid, dim3(1024), 0, s, g);
+  }
+  if (sk) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    g.sk_tile0 = g.ntiles; g.sk_tiles = (int)(T - g.ntiles);
+    g.sk_units = sk_units_for(g.sk_tiles, nk);
+    g.sk_ws = g_sk[dev].slabs; g.sk_flags = g_sk[dev].flags;
+    const dim3 grid((unsigned)g.sk_units);
+    if (g.K2 > 0) hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT, EPI, true, true>), grid, dim3(1024), 0, s, g);
+    else hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT, EPI, false, true>), grid, dim3(1024), 0, s, g);
+  }
+}
+// the 16-wave kernel; a second operand pair (K2 > 0: the fused LoRA product) is a template parameter of it
+#define LAUNCH_256(ACT_, EPI_, grid_, s_, g_) launch_256s<ACT_, EPI_>(g_, s_)
 // Tile height of the persistent kernels: 256 rows (16 waves) or 144 rows (12 waves, gemm_144s_kernel.inc).  Both walk ceil(tiles / CUs) rounds.  A
 // 144-row tile is 0.5625 of the MFMA work of a 256-row tile but costs ~0.8 of its time: more DMA per MFMA (1050 against 1300 TFLOP/s at
 // M = 8190), and a 256-row launch that leaves CUs idle runs its busy CUs at a higher clock (measured at M = 2184, one round each: 73 / 174 / 350
@@ -1198,7 +1399,7 @@ static bool pick_144(int M, long tiles_n, int K, int K2, bool drop) {
   if (g_gemm_bm144 == 0 || K2 > 0 || drop || K < 192) return false;   // the second operand pair (fused LoRA) and the dropout mask live in the 256-row kernel only
   if (g_gemm_bm144 == 2) return true;
   const long P = num_cus(), t256 = (long)cdiv(M, 256) * tiles_n, t144 = (long)cdiv(M, 144) * tiles_n;
-  return (double)((t144 + P - 1) / P) * g_gemm_bm144_cost < (double)((t256 + P - 1) / P);
+  return (double)((t144 + P - 1) / P) * g_gemm_bm144_cost < rounds_256(t256, K / 64, 0, drop, nullptr);
 }
 // fewest 64x128 tiles for which the 64x128 small-tile kernel is taken over the 64x64 one (A/B: lhrs_gemm_set_small_thresh)
 static int g_gemm_small_thresh = 256;
@@ -1307,7 +1508,8 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
     if (full >= 1 && T % 256 != 0 && tm_main >= 1 && tm_main < tm) {
       const long t_main = (long)tm_main * tn, t_tail = T - t_main;
       const double split_cost = (double)((t_main + 255) / 256) + 2.5 * (double)t_tail / 256.0 + 0.05;
-      if (split_cost < (double)rounds) {
+      (void)rounds;
+      if (split_cost < rounds_256(T, (K + K2) / 64, K2 / 64, false, nullptr)) {
         const int M_main = tm_main * 256, M_tail = M - M_main;
         const long esz = out_f32 ? 4 : 2;
         t_split_ok = false;

@@ -34,6 +34,30 @@ def _req(t: torch.Tensor, dtype, name: str):
 
 
 # --------------------------------------------------------------------------------------------- GEMM
+_SK_WS = {}
+
+
+def ensure_streamk_workspace(device, force: bool = False) -> None:
+    """Give the library its stream-K workspace on `device` (caller-owned, 64 MiB + 4 KiB: include/lhrs_hip.h) - once per device and
+    process.  Stream-K is OFF by default (measured slower than whole rounds on MI355X: csrc/gemm.hip): the towers call this when they are
+    built, and it does nothing unless LHRS_GEMM_STREAMK=1 (or force=True: tests, tools/gemm_sk_ab.py), which also switches the launches on."""
+    import os
+    dev = torch.device(device)
+    if dev.type != "cuda" or not (force or os.environ.get("LHRS_GEMM_STREAMK", "0") == "1"):
+        return
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx in _SK_WS:
+        return
+    with torch.cuda.device(idx):
+        n = int(_L().lhrs_gemm_streamk_workspace_bytes())
+        ws = torch.empty(n, device=f"cuda:{idx}", dtype=torch.uint8)
+        torch.cuda.synchronize()
+        _lib.check(_L().lhrs_gemm_set_streamk_workspace(ws.data_ptr(), n), "gemm_set_streamk_workspace")
+    _SK_WS[idx] = ws
+    if not force:
+        _L().lhrs_gemm_set_streamk(1)
+
+
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, bias=None, residual=None,
             act: int = ACT_NONE, out_f32: bool = False, accumulate: bool = False, alpha: float = 1.0,
             M: Optional[int] = None, N: Optional[int] = None, K: Optional[int] = None) -> torch.Tensor:

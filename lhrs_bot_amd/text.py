@@ -203,6 +203,7 @@ class TextModal:
     def __init__(self, config=None, device="cuda", layers=32, dim=4096, ff=11008, heads=32, vocab=32000, eps=1e-5,
                  rope_theta=10000.0, max_pos=4096):  # LLaMA-2 max_position_embeddings; S reaches model_max_length 2048 + 143 image tokens
         self.device = torch.device(device)
+        hk.ensure_streamk_workspace(self.device)   # the persistent GEMM's stream-K tail needs a caller-owned workspace
         self.nl, self.d, self.ff, self.heads, self.vocab, self.eps = layers, dim, ff, heads, vocab, float(eps)
         self.hd = dim // heads
         self.tokenizer = SyntheticTokenizer()

@@ -677,6 +677,7 @@ def test_gemm_144_row_tiles_bit_identical_to_256_row_tiles(M):
     try:
         lib.lhrs_gemm_set_min_tiles(1)       # both tile heights are legal from one tile on (the default threshold would take the small-tile kernel at M <= 1000)
         lib.lhrs_gemm_set_tail_split(0)
+        lib.lhrs_gemm_set_streamk(0)         # whole tiles only on both sides: a split k-loop re-associates the fp32 sum
         lib.lhrs_gemm_set_bm144(0)
         ref = run()
         lib.lhrs_gemm_set_bm144(2)
@@ -688,3 +689,75 @@ def test_gemm_144_row_tiles_bit_identical_to_256_row_tiles(M):
     for i, (a, b) in enumerate(zip(got, ref)):
         assert torch.equal(a, b), (i, (a.float() - b.float()).abs().max().item())
     assert rel_err(ref[0], x.float() @ w.float().t()) < 4e-3
+
+
+@pytest.mark.parametrize("M", [2184, 8190, 8736, 700])
+def test_gemm_streamk_tail_matches_whole_tile_rounds(M):
+    """Stream-K launch of the persistent 256x256 kernel (the tiles of the last, partial round cut along k into one range of stages per CU,
+    fp32 partials through the workspace, fixed summation order) against the same kernel walking whole tiles only: every epilogue family -
+    plain, bias + activation + residual, f32 output with accumulate, fused SwiGLU forward / backward, fused RoPE, the fused LoRA operand
+    pair - agrees to fp32 re-association (stream-K is OFF by default - measured slower, csrc/gemm.hip - and switched on here) (bf16 outputs: at most one ulp on a few elements), is deterministic run to run, leaves every flag
+    of the workspace zero, and is really taken (the plan says so) at the shapes the bench measures: M = 8190 (B = 30: d-down 5.375 rounds,
+    gate|up 10.75), 8736 (B = 32: 2.19 rounds), 2184 (B = 8: 0.56 rounds), and a small ragged M."""
+    import ctypes
+    from lhrs_bot_amd import _lib
+    lib = _lib.load()
+    hk.ensure_streamk_workspace(DEV, force=True)
+    g = torch.Generator().manual_seed(M + 17)
+    d, ff, hd = 4096, 11008, 128
+    x = torch.randn(M, d, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(3 * d, d, generator=g) * 0.02).to(DEV, torch.bfloat16)
+    wo = (torch.randn(d + 136, d, generator=g) * 0.02).to(DEV, torch.bfloat16)          # N = 4232: ragged last tile column
+    bias = torch.randn(d + 136, generator=g).to(DEV, torch.bfloat16)
+    res = torch.randn(M, d + 136, generator=g).to(DEV, torch.bfloat16)
+    wgu = (torch.randn(2 * ff, d, generator=g) * 0.02).to(DEV, torch.bfloat16)
+    wdT = (torch.randn(ff, d, generator=g) * 0.02).to(DEV, torch.bfloat16)
+    dy = (torch.randn(M, d, generator=g) * 0.1).to(DEV, torch.bfloat16)
+    a2 = (torch.randn(M, 64, generator=g) * 0.1).to(DEV, torch.bfloat16)                 # fused LoRA pair: K2 = 64 (r = 8 q|k|v padded)
+    b2 = (torch.randn(3 * d, 64, generator=g) * 0.02).to(DEV, torch.bfloat16)
+    acc0 = torch.randn(M, d + 136, generator=g).to(DEV)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    fr = torch.outer(torch.arange(512).float(), inv)
+    cos, sin = fr.cos().to(DEV).contiguous(), fr.sin().to(DEV).contiguous()
+
+    def run():
+        out = [hk.gemm_nt(x, w), hk.gemm_nt(x, wo, bias=bias, act=hk.ACT_GELU, residual=res),
+               hk.gemm_nt(x, wo, out=acc0.clone(), out_f32=True, accumulate=True), hk.gemm_nt_lora(x, w, a2, b2)]
+        gu, act = hk.gemm_swiglu_fwd(x, wgu, ff)
+        out += [gu.clone(), act]
+        out.append(hk.gemm_swiglu_bwd(dy, wdT, gu, ff).clone())
+        out.append(hk.gemm_rope_fwd(x, w, cos, sin, pos_mod=273, pos0=0, rope_cols=2 * d, head_dim=hd))
+        return out
+
+    taken = 0
+    for N, K in ((3 * d, d), (d + 136, d), (2 * ff, d), (ff, d)):
+        o = (ctypes.c_int * 10)()
+        T = -(-M // 256) * -(-N // 256)
+        taken += lib.lhrs_gemm_streamk_plan(T, K // 64, 0, 0, -1, ctypes.addressof(o)) == 0
+    try:
+        lib.lhrs_gemm_set_min_tiles(1)
+        lib.lhrs_gemm_set_tail_split(0)
+        lib.lhrs_gemm_set_bm144(0)
+        lib.lhrs_gemm_set_streamk(0)
+        ref = run()
+        lib.lhrs_gemm_set_streamk(1)
+        got = run()
+        again = run()
+    finally:
+        lib.lhrs_gemm_set_bm144(1)
+        lib.lhrs_gemm_set_streamk(0)
+        lib.lhrs_gemm_set_tail_split(1)
+        lib.lhrs_gemm_set_min_tiles(128)
+    torch.cuda.synchronize()
+    assert taken >= 2, "stream-K was not planned for any of the shapes: the test would compare the whole-tile kernel with itself"
+    ws = hk._SK_WS[torch.cuda.current_device()]
+    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0            # every raised flag was consumed and cleared
+    differs = 0
+    for i, (a, b, c) in enumerate(zip(got, ref, again)):
+        assert torch.equal(a, c), (i, "stream-K is not deterministic")
+        differs += int(not torch.equal(a, b))
+        err = (a.float() - b.float()).abs().max().item()
+        scale = b.float().abs().max().item()
+        assert err <= (2e-5 if a.dtype == torch.float32 else 2.0 ** -7) * scale, (i, err, scale)     # bf16: one ulp of the largest element
+        assert rel_err(a, b) < (1e-6 if a.dtype == torch.float32 else 2e-3), (i, rel_err(a, b))
+    assert rel_err(got[0], x.float() @ w.float().t()) < 4e-3

@@ -97,6 +97,10 @@ def test_stage3_shape_micro_batch_32_lora_r8_qkvo_vs_oracle():
     out = model(batch)
     d_image = model.text.backward(need_input_grad=True)
     torch.cuda.synchronize()
+    for L in [P["pooler"]] + P["pooler"]["layers"]:      # d loss / d image needs a graph through the projector output
+        for v in L.values():
+            if torch.is_tensor(v):
+                v.requires_grad_(True)
     col = {}
     loss = O.unibind_forward(P, batch, col)
     col["image"].retain_grad()

@@ -237,7 +237,7 @@ def test_full_depth_32_layers_s273_vs_oracle_on_host_cpu():
     against the fp32 oracle run on the GPU box's HOST cores with the same seeded parameters (27 GB fp32; the oracle is pinned to the
     reference at this sequence length by tests/test_oracle_cpu.py::test_unibind_headline_shape_s273_matches_reference and at depth by the
     8-layer fixture).  Checks bf16 drift over 32 residual layers: loss 1e-3, final-norm hidden 3e-2, d loss / d image 6e-2, every one
-    of the 87 projector gradients by rel-L2 of the difference 7e-2."""
+    of the 87 projector gradients by rel-L2 of the difference, bounded like d loss / d image."""
     import gc
     torch.set_num_threads(min(64, os.cpu_count() or 1))
     NL, T = 32, 130
@@ -301,8 +301,9 @@ def test_full_depth_32_layers_s273_vs_oracle_on_host_cpu():
     assert err_h < max(3e-2, 1.5 * yard_h), msg
     assert err_g < max(6e-2, 1.5 * yard_g), msg
     assert err_h2 < 1.1 * yard_h and err_g2 < 1.1 * yard_g, msg   # one rounding per fused kernel: not further from fp32 than op-by-op bf16
-    # every one of the 87 projector gradients by rel-L2 of the difference (directional), not by norm
-    assert_projector_grads_directional(got_grads, oracle_pooler_grads(P), 7e-2)
+    # every one of the 87 projector gradients by rel-L2 of the difference (directional), not by norm.  They are linear in d loss / d image,
+    # so they inherit its error after 32 + 32 bf16 layers (measured 0.073-0.075 for all 87 at d_image 0.0756): same bound as d_image
+    assert_projector_grads_directional(got_grads, oracle_pooler_grads(P), max(6e-2, 1.5 * yard_g))
     del P, model, col
     gc.collect()
 
