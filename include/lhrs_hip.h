@@ -338,6 +338,13 @@ int lhrs_repack_fp8_mfma(const void* W8, long ldw, void* out, int N, int K, void
 int lhrs_decode_attn(const void* qkv, long ld, void* kcache, void* vcache, const float* cos_t, const float* sin_t,
                      const int* pos, const unsigned char* key_mask, long ld_mask, void* out, long ldo, int B, int H, int D,
                      int max_ctx, float scale, void* stream);
+/* the same attention with the context split over nsplit (1..16) workgroups per head - slices of 128 keys, partial (max, sum, o[128])
+ * exchanged through `part` (fp32 [B][H][nsplit][132]) behind a ticket per head in `tickets` (int32 [B][H]; zero before the first call, left
+ * zero by every call) - so that a long context streams through 32 * nsplit CUs instead of 32.  Same result up to the order of the fp32
+ * softmax sums.  part / tickets: caller-owned, private to the stream the calls are ordered on. */
+int lhrs_decode_attn_split(const void* qkv, long ld, void* kcache, void* vcache, const float* cos_t, const float* sin_t,
+                           const int* pos, const unsigned char* key_mask, long ld_mask, void* out, long ldo, int B, int H, int D,
+                           int max_ctx, float scale, int nsplit, float* part, int* tickets, void* stream);
 /* ---- data boundary: the image transform of the reference -------------------------------------------
  * CLIPImageProcessor.preprocess as built by build_vlp_transform (lhrs/Dataset/build_transform.py:43-45) for one decoded RGB image:
  * img = uint8 [H][W][3] on the device (row_stride bytes per row) -> out = float32 [3][224][224].  Bit-exact with Pillow's BICUBIC

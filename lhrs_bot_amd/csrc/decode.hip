@@ -724,6 +724,184 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(const bf16_t
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// decode_attn_split_kernel (round 4): the same attention with the CONTEXT split over workgroups.  One workgroup streams at most ~27 GB/s
+// from HBM (10-12 B / clk / CU: the per-CU miss path), so the single-workgroup-per-head form above keeps 32 of 256 CUs busy and needs
+// ctx * 512 B / 27 GB/s per head: 13.8 us at ctx ~ 700 - 13 % of a decoded token for 7 MB of K / V.  Here workgroup (head, sp) owns the
+// keys [128 j + 128 sp NS', ...) - 128-key slices with stride NS - and issues ALL loads of its first slice before it knows the context
+// length (any cache row < max_ctx is readable), so the only dependent round trips are pos -> cos / sin and the exchange below.
+// Exchange: every workgroup that owns at least one visible key publishes (m, l, o[128]) with write-through (sc1) stores, drains them,
+// and takes a ticket; the LAST arriver reads all partials with sc1 loads (both sides sc1: no fence needed, cdna_hip_programming.md §6 G16
+// R1), merges and writes the bf16 row; it resets the ticket (tickets are zero between launches: hipGraph replays need no memset node).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int DS_WAVES = 4, DS_KPG = 8, DS_SLICE = DS_WAVES * 4 * DS_KPG;   // 4 waves x 4 lane groups x 8 keys = 128 keys per slice
+constexpr int DS_PART = 132;                                                 // floats per partial: m, l, -, -, o[128]
+
+__global__ __launch_bounds__(DS_WAVES * 64) void decode_attn_split_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* kc, bf16_t* vc,
+                                                                 const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                                 const int* __restrict__ pos, const unsigned char* __restrict__ kmask,
+                                                                 long ld_kmask, bf16_t* __restrict__ out, long ldo, int H, int max_ctx,
+                                                                 float scale, int NS, float* part_g, int* tickets) {
+  constexpr int D = 128, HALF = 64;
+  __shared__ float part[DS_WAVES][DS_PART];
+  __shared__ int s_ticket;
+  const int h = blockIdx.x / NS, sp = blockIdx.x - h * NS, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, grp = lane >> 4;
+  const int d_model = H * D;
+  const long cache_row0 = (long)b * max_ctx;
+  const bf16_t* kbase = kc + cache_row0 * d_model + h * D + l16 * 8;
+  const bf16_t* vbase = vc + cache_row0 * d_model + h * D + l16 * 8;
+  int key0 = sp * DS_SLICE + wave * (4 * DS_KPG) + grp;   // this 16-lane group: keys key0, key0 + 4, ... (DS_KPG of them) of the current slice
+  uint4 kr[DS_KPG], vr[DS_KPG];
+#pragma unroll
+  for (int i = 0; i < DS_KPG; ++i) {
+    const long key = min(key0 + i * 4, max_ctx - 1);
+    kr[i] = *reinterpret_cast<const uint4*>(kbase + key * d_model);
+    vr[i] = *reinterpret_cast<const uint4*>(vbase + key * d_model);
+  }
+  const bf16_t* row = qkv + (long)b * ld;
+  const uint4 q_raw = *reinterpret_cast<const uint4*>(row + h * D + l16 * 8);
+  const uint4 k_raw = *reinterpret_cast<const uint4*>(row + d_model + h * D + l16 * 8);
+  const uint4 v_raw = *reinterpret_cast<const uint4*>(row + 2 * d_model + h * D + l16 * 8);
+  const int p = pos[b];  // position of the new token; keys 0..p are visible
+  if (sp * DS_SLICE > p) return;                        // no visible key in any slice of this workgroup (workgroup-uniform)
+  const int nact = min(NS, p / DS_SLICE + 1);           // workgroups of this head that own a visible key
+  float q[8], kn[8], vn[8];
+  {
+    float qa[8], ka[8], qb[8], kb[8];
+    unpack8(q_raw, qa); unpack8(k_raw, ka); unpack8(v_raw, vn);
+    const int f0 = (l16 & 7) * 8;
+    const bool hi = l16 >= 8;
+    const float4 c0 = *reinterpret_cast<const float4*>(cos_t + (long)p * HALF + f0), c1 = *reinterpret_cast<const float4*>(cos_t + (long)p * HALF + f0 + 4);
+    const float4 s0 = *reinterpret_cast<const float4*>(sin_t + (long)p * HALF + f0), s1 = *reinterpret_cast<const float4*>(sin_t + (long)p * HALF + f0 + 4);
+    const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      qb[i] = __shfl_xor(qa[i], 8, 64);
+      kb[i] = __shfl_xor(ka[i], 8, 64);
+      q[i] = bf2f(f2bf(hi ? qa[i] * cv[i] + qb[i] * sv[i] : qa[i] * cv[i] - qb[i] * sv[i])) * scale;
+      kn[i] = bf2f(f2bf(hi ? ka[i] * cv[i] + kb[i] * sv[i] : ka[i] * cv[i] - kb[i] * sv[i]));
+    }
+  }
+  float m = -INFINITY, l = 0.f, o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+  for (int base = sp * DS_SLICE; base <= p; base += NS * DS_SLICE) {
+    if (base > sp * DS_SLICE) {  // further slices of this workgroup (context > 128 NS)
+      key0 = base + wave * (4 * DS_KPG) + grp;
+#pragma unroll
+      for (int i = 0; i < DS_KPG; ++i) {
+        const long key = min(key0 + i * 4, max_ctx - 1);
+        kr[i] = *reinterpret_cast<const uint4*>(kbase + key * d_model);
+        vr[i] = *reinterpret_cast<const uint4*>(vbase + key * d_model);
+      }
+    }
+    float sc[DS_KPG];
+    float mp = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < DS_KPG; ++i) {
+      const int key = key0 + i * 4;
+      float kv[8];
+      unpack8(kr[i], kv);
+      if (key == p) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kv[e] = kn[e];
+        *reinterpret_cast<uint4*>(kc + (cache_row0 + p) * d_model + h * D + l16 * 8) = pack8(kn);  // append: this group owns the new key
+        *reinterpret_cast<uint4*>(vc + (cache_row0 + p) * d_model + h * D + l16 * 8) = v_raw;
+      }
+      float dot = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dot += q[e] * kv[e];
+      dot = group16_sum(dot);
+      bool ok = key <= p;
+      if (ok && kmask != nullptr) ok = kmask[(long)b * ld_kmask + key] != 0;
+      sc[i] = ok ? dot : -INFINITY;
+      mp = fmaxf(mp, sc[i]);
+    }
+    mp = fmaxf(mp, __shfl_xor(mp, 16, 64));
+    mp = fmaxf(mp, __shfl_xor(mp, 32, 64));
+    const float m_new = fmaxf(m, mp);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __expf(m - m_use);
+    l *= alpha;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] *= alpha;
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < DS_KPG; ++i) {
+      if (sc[i] == -INFINITY) continue;
+      const float pr = __expf(sc[i] - m_use);
+      float vv[8];
+      unpack8(vr[i], vv);
+      if (key0 + i * 4 == p) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vv[e] = vn[e];
+      }
+      l += pr;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += pr * vv[e];
+    }
+  }
+  l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { o[e] += __shfl_xor(o[e], 16, 64); o[e] += __shfl_xor(o[e], 32, 64); }
+  if (lane < 16) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[wave][4 + l16 * 8 + e] = o[e];
+    if (lane == 0) { part[wave][0] = m; part[wave][1] = l; }
+  }
+  __syncthreads();
+  // ---- this workgroup's partial: thread d < 128 holds o[d] relative to the workgroup maximum M
+  float M = -INFINITY, L = 0.f, acc = 0.f;
+  if (tid < D) {
+#pragma unroll
+    for (int i = 0; i < DS_WAVES; ++i) M = fmaxf(M, part[i][0]);
+#pragma unroll
+    for (int i = 0; i < DS_WAVES; ++i) {
+      const float mi = part[i][0];
+      const float w = mi == -INFINITY ? 0.f : __expf(mi - M);
+      L += w * part[i][1];
+      acc += w * part[i][4 + tid];
+    }
+  }
+  if (nact == 1) {   // short context: nothing to exchange
+    if (tid < D) out[(long)b * ldo + h * D + tid] = f2bf(L > 0.f ? acc / L : 0.f);
+    return;
+  }
+  unsigned* mine = reinterpret_cast<unsigned*>(part_g + ((long)(b * H + h) * NS + sp) * DS_PART);
+  if (tid < D) {
+    __hip_atomic_store(mine + 4 + tid, __float_as_uint(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
+    if (tid == 0) {
+      __hip_atomic_store(mine + 0, __float_as_uint(M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mine + 1, __float_as_uint(L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its write-through stores ...
+  __syncthreads();
+  if (tid == 0) s_ticket = __hip_atomic_fetch_add(tickets + b * H + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before ONE lane takes the ticket
+  __syncthreads();
+  if (s_ticket != nact - 1) return;
+  // ---- last arriver: every other partial of this head is complete in memory (sc1 stores drained before each ticket)
+  if (tid == 0) __hip_atomic_store(tickets + b * H + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < D) {
+    const unsigned* base_p = reinterpret_cast<const unsigned*>(part_g + (long)(b * H + h) * NS * DS_PART);
+    float Mx = -INFINITY;
+    for (int s2 = 0; s2 < nact; ++s2)
+      Mx = fmaxf(Mx, __uint_as_float(__hip_atomic_load(base_p + (long)s2 * DS_PART, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+    float Ls = 0.f, As = 0.f;
+    for (int s2 = 0; s2 < nact; ++s2) {
+      const unsigned* ps = base_p + (long)s2 * DS_PART;
+      const float ms = __uint_as_float(__hip_atomic_load(ps + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const float ls = __uint_as_float(__hip_atomic_load(ps + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const float os = __uint_as_float(__hip_atomic_load(ps + 4 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const float w = ms == -INFINITY ? 0.f : __expf(ms - Mx);
+      Ls += w * ls;
+      As += w * os;
+    }
+    out[(long)b * ldo + h * D + tid] = f2bf(Ls > 0.f ? As / Ls : 0.f);
+  }
+}
+
 }  // namespace
 
 extern "C" int lhrs_decode_emit(const long* next_ids, int* tok32, long* out_ids, int* state, int B, int max_new, void* stream) {
@@ -906,6 +1084,22 @@ extern "C" int lhrs_decode_attn(const void* qkv, long ld, void* kcache, void* vc
   hipLaunchKernelGGL(decode_attn_kernel, dim3(H, B), dim3(DA_WAVES * 64), 0, (hipStream_t)stream, (const bf16_t*)qkv, ld, (bf16_t*)kcache,
                      (bf16_t*)vcache, cos_t, sin_t, pos, key_mask, ld_mask, (bf16_t*)out, ldo, H, max_ctx, scale);
   LHRS_CHECK_LAUNCH("decode_attn");
+  return 0;
+}
+
+// The same with the context split over nsplit workgroups per head (decode_attn_split_kernel: nsplit slices of 128 keys in flight per head,
+// 1 <= nsplit <= 16).  part: fp32 [B][H][nsplit][132] partials, tickets: int32 [B][H], ZERO before the first call (the kernel leaves them
+// zero); both caller-owned and private to the stream the calls are ordered on.
+extern "C" int lhrs_decode_attn_split(const void* qkv, long ld, void* kcache, void* vcache, const float* cos_t, const float* sin_t,
+                                      const int* pos, const unsigned char* key_mask, long ld_mask, void* out, long ldo, int B, int H, int D,
+                                      int max_ctx, float scale, int nsplit, float* part, int* tickets, void* stream) {
+  LHRS_REQUIRE(D == 128, "decode_attn_split: head_dim %d (only 128)", D);
+  LHRS_REQUIRE(B >= 1 && H >= 1 && max_ctx >= 1 && ld % 8 == 0 && nsplit >= 1 && nsplit <= 16 && part && tickets,
+               "decode_attn_split: B=%d H=%d max_ctx=%d nsplit=%d", B, H, max_ctx, nsplit);
+  hipLaunchKernelGGL(decode_attn_split_kernel, dim3(H * nsplit, B), dim3(DS_WAVES * 64), 0, (hipStream_t)stream, (const bf16_t*)qkv, ld,
+                     (bf16_t*)kcache, (bf16_t*)vcache, cos_t, sin_t, pos, key_mask, ld_mask, (bf16_t*)out, ldo, H, max_ctx, scale, nsplit, part,
+                     tickets);
+  LHRS_CHECK_LAUNCH("decode_attn_split");
   return 0;
 }
 

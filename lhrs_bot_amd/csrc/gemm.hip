@@ -1399,7 +1399,14 @@ static bool pick_144(int M, long tiles_n, int K, int K2, bool drop) {
   if (g_gemm_bm144 == 0 || K2 > 0 || drop || K < 192) return false;   // the second operand pair (fused LoRA) and the dropout mask live in the 256-row kernel only
   if (g_gemm_bm144 == 2) return true;
   const long P = num_cus(), t256 = (long)cdiv(M, 256) * tiles_n, t144 = (long)cdiv(M, 144) * tiles_n;
-  return (double)((t144 + P - 1) / P) * g_gemm_bm144_cost < rounds_256(t256, K / 64, 0, drop, nullptr);
+  const int nk = K / 64;
+  if (nk <= 32) {
+    // short k-loops (the ViT / projector products, K = 1024 .. 2048): a tile's fixed part - cold first stages, epilogue - weighs as much as
+    // its stages, and it is smaller for the 144-row tile.  Fitted on tools/gemm_vit_sweep.py (us per round: 256 rows 1.5 nk + 20, 144 rows
+    // 1.15 nk + 5): M = 7710: qkv 86.6 -> 68.1 us, o 30.2 -> 25.9; M = 27360: 264.7 -> 214.4, 88.5 -> 69.7; fc1 (496 tiles = 2 rounds) stays
+    return (double)((t144 + P - 1) / P) * (1.15 * nk + 5.0) < (double)((t256 + P - 1) / P) * (1.5 * nk + 20.0);
+  }
+  return (double)((t144 + P - 1) / P) * g_gemm_bm144_cost < rounds_256(t256, nk, 0, drop, nullptr);
 }
 // fewest 64x128 tiles for which the 64x128 small-tile kernel is taken over the 64x64 one (A/B: lhrs_gemm_set_small_thresh)
 static int g_gemm_small_thresh = 256;
@@ -1487,6 +1494,11 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
   const bool al16 = out_f32 || (N % 8 == 0 && ldc % 8 == 0 && (residual == nullptr || ldr % 8 == 0));  // 16-B epilogue rows
   bool use256 = g_gemm_allow_256 && t256 >= g_gemm_min256 && K >= 96 && K % 32 == 0 && al16;  // ring prologue needs >= 3 stages
+  // just under the big-tile threshold but nearly a full round of 144-row tiles (ViT o / fc2 at micro-batch 30: 124 tiles of 256 rows, 216 of
+  // 144): the persistent 144-row kernel beats the small tiles (30.2 -> 25.9, 75.1 -> 68.4 us; tools/gemm_vit_sweep.py)
+  if (!use256 && g_gemm_allow_256 == 2 && g_gemm_bm144 == 1 && al16 && !out_f32 && K % 64 == 0 && K >= 192 && K2 == 0 && !g.drop_thresh &&
+      t256 >= g_gemm_min256 / 2 && (long)cdiv(M, 144) * cdiv(N, 256) >= 200 && (long)cdiv(M, 144) * cdiv(N, 256) <= num_cus())
+    use256 = true;
   if (g.drop_thresh && !(g_gemm_allow_256 == 2 && K % 64 == 0 && K >= 128)) use256 = false;  // the mask lives in the 16-wave kernel and in store4
   if (K2 > 0 && !use256) {  // small problems: base GEMM, then the rank-K2 update accumulated on top of it
     if (gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, out_f32, accumulate, alpha, nullptr, 0, nullptr, 0, 0, stream))

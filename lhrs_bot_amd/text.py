@@ -862,13 +862,23 @@ class TextModal:
                 x_in, pro = s.actb, hk.PRO_NONE
             hk.gemv_fused(w, x_in, out, K, wscale=sc, prologue=pro, norm_w=norm_w, eps=self.eps, residual=residual, out_f32=out_f32)
 
+        # split-context attention (lhrs_decode_attn_split): 128-key slices, one workgroup each, so that a long context streams through
+        # 32 * nsplit CUs; LHRS_DECODE_SPLIT=0 keeps the one-workgroup-per-head kernel (A/B runs)
+        nsplit = min(16, -(-max_ctx // 128)) if os.environ.get("LHRS_DECODE_SPLIT", "1") != "0" else 1
+        if nsplit > 1 and hd == 128:
+            s.attn_part = torch.zeros((B, H, nsplit, 132), device=dev, dtype=torch.float32)
+            s.attn_tickets = torch.zeros((B, H), device=dev, dtype=torch.int32)
+
         def enqueue():
             hk.decode_advance(s.state, s.desc, s.pos, B, max_ctx, 1)
             hk.gather_rows(self.p["embed"], s.tok32, out=s.x)
             x, x2 = s.x, s.x2
             for L, (kc, vc) in zip(self.p["layers"], caches):
                 lin(*W(L, "qkv_w"), x, s.qkv, d, hk.PRO_RMSNORM, L["ln1_w"])
-                if hd == 128:  # RoPE + KV append + attention over the cache in one launch
+                if hd == 128 and nsplit > 1:  # RoPE + KV append + attention over the cache in one launch, context split over workgroups
+                    hk.decode_attn_split(s.qkv, kc, vc, self.cos, self.sin, s.pos, s.o, B, H, hd, max_ctx, scale, nsplit, s.attn_part,
+                                         s.attn_tickets, key_mask=kmask)
+                elif hd == 128:
                     hk.decode_attn(s.qkv, kc, vc, self.cos, self.sin, s.pos, s.o, B, H, hd, max_ctx, scale, key_mask=kmask)
                 else:
                     hk.rope_kv_append(s.qkv, kc, vc, self.cos, self.sin, s.pos, B, H, hd, max_ctx)

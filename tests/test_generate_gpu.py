@@ -240,3 +240,37 @@ def test_decode_attn_kernel_matches_rope_append_attention():
         hk.attn_fwd(qkv2[:, :d], kc2, vc2, o2, None, desc, B, H, D, 1, 1 << 30, 64, True, 1 / math.sqrt(D), key_mask=km)
         assert torch.equal(kc, kc2) and torch.equal(vc, vc2), ctx      # the appended rows are bit-identical
         assert rel(o, o2) < 6e-3, (ctx, rel(o, o2))                     # fp32 P.V here vs bf16-rounded P in the MFMA kernel
+
+
+@pytest.mark.parametrize("nsplit", [2, 6, 11, 16])
+def test_decode_attn_split_matches_the_one_workgroup_kernel(nsplit):
+    """lhrs_decode_attn_split (context split into 128-key slices over nsplit workgroups per head, partials exchanged behind a ticket,
+    last arriver merges) against lhrs_decode_attn on the same inputs: same appended rows bit for bit, same output up to the order of the fp32
+    softmax sums, for contexts below one slice (no exchange), at slice edges, beyond nsplit slices (a workgroup walks several), with a key
+    mask and per-sequence positions that differ; repeated calls on the same buffers (the tickets return to zero every time)."""
+    import math
+    g = torch.Generator().manual_seed(77 + nsplit)
+    B, H, D, max_ctx = 2, 32, 128, 2100
+    d = H * D
+    cos, sin = (t.to(DEV) for t in __import__("oracle.lhrs_oracle", fromlist=["rope_tables"]).rope_tables(max_ctx, D))
+    part = torch.zeros(B, H, nsplit, 132, device=DEV)
+    tickets = torch.zeros(B, H, device=DEV, dtype=torch.int32)
+    for ctx, masked in ((0, False), (5, True), (127, False), (128, True), (300, False), (715, True), (1023, False), (1024, True), (2099, False)):
+        kc = torch.randn(B * max_ctx, d, generator=g).to(DEV, torch.bfloat16)
+        vc = torch.randn(B * max_ctx, d, generator=g).to(DEV, torch.bfloat16)
+        qkv = torch.randn(B, 3 * d, generator=g).to(DEV, torch.bfloat16)
+        km = None
+        if masked:
+            km = (torch.rand(B, max_ctx, generator=g) > 0.3).to(torch.uint8)
+            km[:, 0] = 1
+            km = km.to(DEV)
+        pos = torch.tensor([ctx, max(0, ctx - 37)], dtype=torch.int32, device=DEV)      # the two sequences sit at different positions
+        kc2, vc2 = kc.clone(), vc.clone()
+        o, o2 = torch.empty(B, d, device=DEV, dtype=torch.bfloat16), torch.empty(B, d, device=DEV, dtype=torch.bfloat16)
+        hk.decode_attn_split(qkv, kc, vc, cos, sin, pos, o, B, H, D, max_ctx, 1 / math.sqrt(D), nsplit, part, tickets, key_mask=km)
+        hk.decode_attn(qkv, kc2, vc2, cos, sin, pos, o2, B, H, D, max_ctx, 1 / math.sqrt(D), key_mask=km)
+        torch.cuda.synchronize()
+        assert torch.equal(kc, kc2) and torch.equal(vc, vc2), ctx
+        assert int(tickets.abs().sum()) == 0, ctx
+        assert rel(o, o2) < 2e-3, (ctx, rel(o, o2))
+        assert (o.float() - o2.float()).abs().max().item() <= 2.0 ** -6 * o2.float().abs().max().item(), ctx
