@@ -126,7 +126,9 @@ int lhrs_gemm_set_bm144(int mode);
  * ranges of 64-k stages (one per CU), partial fp32 accumulators travel through the workspace, the CU that holds a tile's first stage adds
  * them in a fixed order and runs the (fused) epilogue.  Deterministic; differs from the unsplit kernel by fp32 re-association only.
  * The workspace is CALLER-OWNED device memory of lhrs_gemm_streamk_workspace_bytes() bytes, 256-B aligned, registered per device; every
- * GEMM launch that may use it must be ordered on one stream.  ws = NULL unregisters (stream-K off: whole rounds only).
+ * GEMM launch that may use it must be ordered on one stream.  ws = NULL unregisters.  A second user of the same workspace, always on while
+ * it is registered: the tail rows of a row-split product (M = 8736: 8192 rows on 256-row tiles + 544 rows) with K >= 8192 are computed
+ * split-K (f32 slabs per K slice, summed in a fixed order together with the residual) instead of by 160 small tiles walking all of K.
  * lhrs_gemm_set_streamk(0 | 1): default 0 - measured slower than whole rounds at every shape of the path on MI355X (the k-ranges lose the L2
  * sharing of operand panels between the tiles of an XCD, and the slab exchange is exposed; numbers in csrc/gemm.hip and DESIGN.md §3.1). */
 long lhrs_gemm_streamk_workspace_bytes(void);

@@ -1164,7 +1164,9 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256_kernel(GemmArgs g) {
 }
 
 // sum of `splits` f32 slabs [M, ldc] -> bf16 C[M, N] * alpha
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, bf16_t* __restrict__ C, long ldc, int M, int N, int splits, float alpha) {
+// (+ residual[M, ldr] added in fp32 before the one rounding, as the GEMM epilogues do; res may alias C)
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, bf16_t* C, long ldc, int M, int N, int splits, float alpha,
+                                     const bf16_t* res = nullptr, long ldr = 0) {
   const long total = (long)M * (N / 4);
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long m = i / (N / 4);
@@ -1174,7 +1176,12 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, bf16_t* __r
       const float4 v = *reinterpret_cast<const float4*>(part + ((long)k * M + m) * N + n);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    *reinterpret_cast<uint2*>(C + m * ldc + n) = make_uint2(pack2bf(s.x * alpha, s.y * alpha), pack2bf(s.z * alpha, s.w * alpha));
+    s.x *= alpha; s.y *= alpha; s.z *= alpha; s.w *= alpha;
+    if (res) {
+      const uint2 r = *reinterpret_cast<const uint2*>(res + m * ldr + n);
+      s.x += bflo(r.x); s.y += bfhi(r.x); s.z += bflo(r.y); s.w += bfhi(r.y);
+    }
+    *reinterpret_cast<uint2*>(C + m * ldc + n) = make_uint2(pack2bf(s.x, s.y), pack2bf(s.z, s.w));
   }
 }
 
@@ -1526,6 +1533,28 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
         const long esz = out_f32 ? 4 : 2;
         t_split_ok = false;
         int rc = gemm_launch(A, lda, B, ldb, C, ldc, M_main, N, K, bias, residual, ldr, act, out_f32, accumulate, alpha, A2, lda2, B2, ldb2, K2, stream);
+        // the tail rows of a LONG k-loop (M = 8736: 544 rows x 4096 columns = 160 tiles of 128^2, each walking K = 11008 .. 22016 alone: 100 - 190
+        // us at 500 TFLOP/s, tools/gemm_tail_sweep.py): cut K into slabs of ~4096 across blockIdx.y - f32 slabs in the registered workspace,
+        // summed in a fixed order with the residual by one small launch - so that every CU has work for the whole tail
+        int dev = 0;
+        const int splits = K >= 8192 ? (K + 2048) / 4096 : 1;
+        if (!rc && splits > 1 && !out_f32 && K2 == 0 && bias == nullptr && act == 0 && N % 128 == 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 &&
+            dev < 16 && g_sk[dev].slabs != nullptr && (long)splits * M_tail * N * 4 <= g_sk[dev].units * 256 * 256 * 4) {
+          const int ks = cdiv(K / 64, splits) * 64, used = cdiv(K, ks);
+          GemmArgs gt; memset(&gt, 0, sizeof(gt));
+          gt.A = (const bf16_t*)A + (long)M_main * lda; gt.B = (const bf16_t*)B; gt.C = g_sk[dev].slabs; gt.M = M_tail; gt.N = N; gt.K = K;
+          gt.lda = lda; gt.ldb = ldb; gt.ldc = N; gt.alpha = 1.f; gt.out_f32 = 1; gt.ksplit = ks; gt.drop_scale = 1.f;
+          gt.tilesM = cdiv(M_tail, 128); gt.tilesN = cdiv(N, 128);
+          if (g_prof.on) { g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M_tail * N * K; }
+          hipLaunchKernelGGL((gemm_nt_kernel<4, 4, 0>), dim3(gt.tilesM * gt.tilesN, used), dim3(256), 0, s, gt);
+          const long work = (long)M_tail * (N / 4);
+          int rg = (int)((work + 255) / 256); if (rg > 8192) rg = 8192;
+          hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, s, (const float*)g_sk[dev].slabs, (bf16_t*)C + (long)M_main * ldc, (long)ldc, M_tail, N,
+                             used, alpha, residual ? (const bf16_t*)residual + (long)M_main * ldr : nullptr, (long)ldr);
+          t_split_ok = true;
+          LHRS_CHECK_LAUNCH("gemm_tail_splitk");
+          return 0;
+        }
         if (!rc)
           rc = gemm_launch((const bf16_t*)A + (long)M_main * lda, lda, B, ldb, (char*)C + (long)M_main * ldc * esz, ldc, M_tail, N, K, bias,
                            residual ? (const bf16_t*)residual + (long)M_main * ldr : nullptr, ldr, act, out_f32, accumulate, alpha,

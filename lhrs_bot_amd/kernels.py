@@ -38,12 +38,14 @@ _SK_WS = {}
 
 
 def ensure_streamk_workspace(device, force: bool = False) -> None:
-    """Give the library its stream-K workspace on `device` (caller-owned, 64 MiB + 4 KiB: include/lhrs_hip.h) - once per device and
-    process.  Stream-K is OFF by default (measured slower than whole rounds on MI355X: csrc/gemm.hip): the towers call this when they are
-    built, and it does nothing unless LHRS_GEMM_STREAMK=1 (or force=True: tests, tools/gemm_sk_ab.py), which also switches the launches on."""
+    """Give the library its GEMM workspace on `device` (caller-owned, 64 MiB + 4 KiB: include/lhrs_hip.h) - once per device and process;
+    the towers call this when they are built.  Two users inside the library: the split-K launch for the tail rows of a row-split product
+    with a long k-loop (always on), and the stream-K launch of the persistent kernel's last partial round, which is OFF unless
+    LHRS_GEMM_STREAMK=1 (measured slower than whole rounds on MI355X: csrc/gemm.hip).  LHRS_GEMM_WORKSPACE=0: nothing is registered.
+    force=True (tests, tools/gemm_sk_ab.py): register, leave the stream-K switch to the caller."""
     import os
     dev = torch.device(device)
-    if dev.type != "cuda" or not (force or os.environ.get("LHRS_GEMM_STREAMK", "0") == "1"):
+    if dev.type != "cuda" or (not force and os.environ.get("LHRS_GEMM_WORKSPACE", "1") == "0"):
         return
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     if idx in _SK_WS:
@@ -54,7 +56,7 @@ def ensure_streamk_workspace(device, force: bool = False) -> None:
         torch.cuda.synchronize()
         _lib.check(_L().lhrs_gemm_set_streamk_workspace(ws.data_ptr(), n), "gemm_set_streamk_workspace")
     _SK_WS[idx] = ws
-    if not force:
+    if not force and os.environ.get("LHRS_GEMM_STREAMK", "0") == "1":
         _L().lhrs_gemm_set_streamk(1)
 
 

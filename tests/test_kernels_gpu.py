@@ -730,10 +730,6 @@ def test_gemm_streamk_tail_matches_whole_tile_rounds(M):
         return out
 
     taken = 0
-    for N, K in ((3 * d, d), (d + 136, d), (2 * ff, d), (ff, d)):
-        o = (ctypes.c_int * 10)()
-        T = -(-M // 256) * -(-N // 256)
-        taken += lib.lhrs_gemm_streamk_plan(T, K // 64, 0, 0, -1, ctypes.addressof(o)) == 0
     try:
         lib.lhrs_gemm_set_min_tiles(1)
         lib.lhrs_gemm_set_tail_split(0)
@@ -741,6 +737,10 @@ def test_gemm_streamk_tail_matches_whole_tile_rounds(M):
         lib.lhrs_gemm_set_streamk(0)
         ref = run()
         lib.lhrs_gemm_set_streamk(1)
+        for N, K in ((3 * d, d), (d + 136, d), (2 * ff, d), (ff, d)):      # what the launcher decides with the switch on and the workspace registered
+            o = (ctypes.c_int * 10)()
+            T = -(-M // 256) * -(-N // 256)
+            taken += lib.lhrs_gemm_streamk_plan(T, K // 64, 0, 0, -1, ctypes.addressof(o)) == 0
         got = run()
         again = run()
     finally:
@@ -761,3 +761,30 @@ def test_gemm_streamk_tail_matches_whole_tile_rounds(M):
         assert err <= (2e-5 if a.dtype == torch.float32 else 2.0 ** -7) * scale, (i, err, scale)     # bf16: one ulp of the largest element
         assert rel_err(a, b) < (1e-6 if a.dtype == torch.float32 else 2e-3), (i, rel_err(a, b))
     assert rel_err(got[0], x.float() @ w.float().t()) < 4e-3
+
+
+def test_gemm_tail_rows_split_k_matches_unsplit():
+    """M = 8736 (micro-batch 32, BASELINE configs[3]): the 544 rows behind the last whole round of 256-row tiles are a separate launch; for the
+    long k-loops (down K = 11008, d-gate|up K = 22016, d-qkv K = 12288) that launch is split-K over the registered workspace (f32 slabs, fixed
+    summation order, residual added before the one rounding).  Against the same product with the row split switched off, and fp32 torch."""
+    from lhrs_bot_amd import _lib
+    lib = _lib.load()
+    hk.ensure_streamk_workspace(DEV, force=True)
+    g = torch.Generator().manual_seed(8736)
+    M, N = 8736, 4096
+    for K, with_res in ((11008, True), (22016, False), (12288, False), (4096, True)):
+        x = (torch.randn(M, K, generator=g) * 0.5).to(DEV, torch.bfloat16)
+        w = (torch.randn(N, K, generator=g) * 0.02).to(DEV, torch.bfloat16)
+        res = torch.randn(M, N, generator=g).to(DEV, torch.bfloat16) if with_res else None
+        got = hk.gemm_nt(x, w, residual=res)
+        again = hk.gemm_nt(x, w, residual=res)
+        try:
+            lib.lhrs_gemm_set_tail_split(0)
+            ref = hk.gemm_nt(x, w, residual=res)
+        finally:
+            lib.lhrs_gemm_set_tail_split(1)
+        assert torch.equal(got, again)                                   # deterministic
+        assert torch.equal(got[:8192], ref[:8192]), K                    # the rows of the whole rounds: same kernel, same tiles
+        assert rel_err(got[8192:], ref[8192:]) < 2e-3, (K, rel_err(got[8192:], ref[8192:]))
+        want = x[8192:].float() @ w.float().t() + (res[8192:].float() if with_res else 0)
+        assert rel_err(got[8192:], want) < 4e-3, K

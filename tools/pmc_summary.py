@@ -26,11 +26,11 @@ def per_kernel(rows, counter):
 if sys.argv[1] == "traffic":
     fdir, wdir, out = sys.argv[2:5]
     fetch, write = per_kernel(load(fdir), "FETCH_SIZE"), per_kernel(load(wdir), "WRITE_SIZE")
-    dom = next(k for k in fetch if "gemm_nt_256s_kernel<0, 0, false>" in k)
+    dom = next(k for k in fetch if "gemm_nt_256s_kernel<0, 0, false" in k)
     cast = next((k for k in fetch if "cast_f32_bf16" in k or "cast_f32_to_bf16" in k), None)
     mean = lambda v: sum(v) / len(v)  # noqa: E731
     res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE  /  --pmc WRITE_SIZE (two separate passes) -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra (B=30)",
-           "kernel": "gemm_nt_256s_kernel<0, 0, false> (16x16x32 MFMA, persistent, round 2)", "launches": len(fetch[dom]), "fetch_size_kb_mean": mean(fetch[dom]),
+           "kernel": "gemm_nt_256s_kernel<0, 0, false, false> (16x16x32 MFMA, persistent)", "launches": len(fetch[dom]), "fetch_size_kb_mean": mean(fetch[dom]),
            "write_size_kb_mean": mean(write[dom])}
     if cast:
         res["calibration"] = {"kernel": cast, "fetch_size_kb_mean": mean(fetch[cast]), "write_size_kb_mean": mean(write[cast]),
