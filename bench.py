@@ -265,9 +265,22 @@ def roofline_block(prof, kinds, steps, B, S, scale_layers, sclk=None, watts=None
                             "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
     all_ms = sum(kinds[3 * k + 1] for k in range(4))
     all_fl = sum(kinds[3 * k + 2] for k in range(4))
+    # HBM-side bytes per launch of the dominant kernel: a PMC pass cannot run inside this process (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE are
+    # separate profiled runs of this same command); the committed summary of that pass on this tree is quoted, with its provenance
+    traffic, traffic_note = None, "not measured in this run (PMC passes are separate rocprofv3 runs)"
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r04_gemm_traffic.json")))
+        if B == 30 and scale_layers == 1.0:
+            traffic = int(tj["traffic_bytes_per_launch"])
+            traffic_note = ("bytes per launch of the dominant kernel from profiles/r04_gemm_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate "
+                            "passes of `bench.py --steps 1 --warmup 1` at micro-batch 30 on this tree), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 and "
+                            "calibrated on a kernel of known byte count in the same run; memory-side L2 traffic, Infinity-Cache hits included (~3x the algorithmic bytes: "
+                            "every XCD streams its own copy of the operand panels); NOT measured in this process")
+    except Exception:  # noqa: BLE001
+        pass
     return {"bound": "mfma", "kernel": GEMM_KERNEL_DESC, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-            "traffic_note": "not measured in this run (PMC passes are separate rocprofv3 runs: profiles/r03_gemm_traffic.json: 1.06 GB per launch of the dominant kernel = 3.0x its algorithmic bytes, Infinity-Cache hits included)",
+            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "traffic_note": traffic_note,
             "variants": variants, "all_variants_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else None,
             "launches_timed": int(n_samp), "timed_every_nth_launch": PROFILE_STRIDE, "avg_launch_us": round(1e3 * ms / max(n_samp, 1), 2),
             "sclk_mhz_during_timed_region": round(sclk) if sclk else None, "package_power_w": round(watts) if watts else None,

@@ -298,6 +298,9 @@ int lhrs_quant_fp8_rows(const void* W, long ldw, void* W8, long ld8, float* scal
 int lhrs_rope_kv_append(void* qkv, long ld, void* kcache, void* vcache, const float* cos_t, const float* sin_t, const int* pos, int B,
                         int H, int D, int max_ctx, void* stream);
 int lhrs_decode_advance(int* state, int* desc, int* pos, int B, int max_ctx, int step_inc, void* stream);
+/* the same, and cs [B][128] floats = the cos | sin rows (head_dim 128) of the new position, for lhrs_decode_attn_split */
+int lhrs_decode_advance_cs(int* state, int* desc, int* pos, const float* cos_t, const float* sin_t, float* cs, int B, int max_ctx,
+                           int step_inc, void* stream);
 int lhrs_kv_append(const void* qkv, long ld, void* kcache, void* vcache, const int* pos, int B, int d, int max_ctx, void* stream);
 int lhrs_decode_emit(const long* next_ids, int* tok32, long* out_ids, int* state, int B, int max_new, void* stream);
 int lhrs_graph_begin(void* stream);
@@ -343,10 +346,11 @@ int lhrs_decode_attn(const void* qkv, long ld, void* kcache, void* vcache, const
 /* the same attention with the context split over nsplit (1..16) workgroups per head - slices of 128 keys, partial (max, sum, o[128])
  * exchanged through `part` (fp32 [B][H][nsplit][132]) behind a ticket per head in `tickets` (int32 [B][H]; zero before the first call, left
  * zero by every call) - so that a long context streams through 32 * nsplit CUs instead of 32.  Same result up to the order of the fp32
- * softmax sums.  part / tickets: caller-owned, private to the stream the calls are ordered on. */
+ * softmax sums.  part / tickets: caller-owned, private to the stream the calls are ordered on.  cs (NULL allowed): the cos | sin rows
+ * lhrs_decode_advance_cs wrote for pos[b]; with it the rotation of the new q / k does not wait for pos[b] to index the tables. */
 int lhrs_decode_attn_split(const void* qkv, long ld, void* kcache, void* vcache, const float* cos_t, const float* sin_t,
                            const int* pos, const unsigned char* key_mask, long ld_mask, void* out, long ldo, int B, int H, int D,
-                           int max_ctx, float scale, int nsplit, float* part, int* tickets, void* stream);
+                           int max_ctx, float scale, int nsplit, float* part, int* tickets, const float* cs, void* stream);
 /* ---- data boundary: the image transform of the reference -------------------------------------------
  * CLIPImageProcessor.preprocess as built by build_vlp_transform (lhrs/Dataset/build_transform.py:43-45) for one decoded RGB image:
  * img = uint8 [H][W][3] on the device (row_stride bytes per row) -> out = float32 [3][224][224].  Bit-exact with Pillow's BICUBIC

@@ -532,9 +532,16 @@ __global__ void rope_kv_append_kernel(bf16_t* qkv, long ld, bf16_t* __restrict__
 }
 
 // state: int32 [4] = {ctx, -, -, -}; desc: int32 [B][8]; pos: int32 [B]
-__global__ void decode_advance_kernel(int* state, int* desc, int* pos, int B, int max_ctx, int step_inc) {
+// cs (optional): float [B][128] = cos / sin row of the new position, so that the attention kernel's q / k rotation does not have to wait for
+// the position before it can ask for its table row (one dependent round trip less on the latency-bound decode attention)
+__global__ void decode_advance_kernel(int* state, int* desc, int* pos, int B, int max_ctx, int step_inc, const float* __restrict__ cos_t = nullptr,
+                                      const float* __restrict__ sin_t = nullptr, float* __restrict__ cs = nullptr) {
   const int b = threadIdx.x;
   const int ctx = state[0];
+  if (cs != nullptr) {
+    const float c = cos_t[(long)ctx * 64 + threadIdx.x], sn = sin_t[(long)ctx * 64 + threadIdx.x];
+    for (int i = 0; i < B; ++i) { cs[i * 128 + threadIdx.x] = c; cs[i * 128 + 64 + threadIdx.x] = sn; }
+  }
   if (b < B) {
     desc[b * 8 + 0] = b;            // q_off  (one new row per sequence)
     desc[b * 8 + 1] = 1;            // q_len
@@ -741,7 +748,7 @@ __global__ __launch_bounds__(DS_WAVES * 64) void decode_attn_split_kernel(const 
                                                                  const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                                  const int* __restrict__ pos, const unsigned char* __restrict__ kmask,
                                                                  long ld_kmask, bf16_t* __restrict__ out, long ldo, int H, int max_ctx,
-                                                                 float scale, int NS, float* part_g, int* tickets) {
+                                                                 float scale, int NS, float* part_g, int* tickets, const float* __restrict__ cs) {
   constexpr int D = 128, HALF = 64;
   __shared__ float part[DS_WAVES][DS_PART];
   __shared__ int s_ticket;
@@ -763,6 +770,13 @@ __global__ __launch_bounds__(DS_WAVES * 64) void decode_attn_split_kernel(const 
   const uint4 q_raw = *reinterpret_cast<const uint4*>(row + h * D + l16 * 8);
   const uint4 k_raw = *reinterpret_cast<const uint4*>(row + d_model + h * D + l16 * 8);
   const uint4 v_raw = *reinterpret_cast<const uint4*>(row + 2 * d_model + h * D + l16 * 8);
+  // cos | sin of the new position: from the row lhrs_decode_advance_cs left for this sequence (no dependence on `pos`), else from the tables
+  float4 c0, c1, s0, s1;
+  if (cs != nullptr) {
+    const float* r = cs + (long)b * 128 + (l16 & 7) * 8;
+    c0 = *reinterpret_cast<const float4*>(r); c1 = *reinterpret_cast<const float4*>(r + 4);
+    s0 = *reinterpret_cast<const float4*>(r + 64); s1 = *reinterpret_cast<const float4*>(r + 68);
+  }
   const int p = pos[b];  // position of the new token; keys 0..p are visible
   if (sp * DS_SLICE > p) return;                        // no visible key in any slice of this workgroup (workgroup-uniform)
   const int nact = min(NS, p / DS_SLICE + 1);           // workgroups of this head that own a visible key
@@ -772,8 +786,10 @@ __global__ __launch_bounds__(DS_WAVES * 64) void decode_attn_split_kernel(const 
     unpack8(q_raw, qa); unpack8(k_raw, ka); unpack8(v_raw, vn);
     const int f0 = (l16 & 7) * 8;
     const bool hi = l16 >= 8;
-    const float4 c0 = *reinterpret_cast<const float4*>(cos_t + (long)p * HALF + f0), c1 = *reinterpret_cast<const float4*>(cos_t + (long)p * HALF + f0 + 4);
-    const float4 s0 = *reinterpret_cast<const float4*>(sin_t + (long)p * HALF + f0), s1 = *reinterpret_cast<const float4*>(sin_t + (long)p * HALF + f0 + 4);
+    if (cs == nullptr) {
+      c0 = *reinterpret_cast<const float4*>(cos_t + (long)p * HALF + f0); c1 = *reinterpret_cast<const float4*>(cos_t + (long)p * HALF + f0 + 4);
+      s0 = *reinterpret_cast<const float4*>(sin_t + (long)p * HALF + f0); s1 = *reinterpret_cast<const float4*>(sin_t + (long)p * HALF + f0 + 4);
+    }
     const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -1034,8 +1050,17 @@ extern "C" int lhrs_rope_kv_append(void* qkv, long ld, void* kcache, void* vcach
 
 extern "C" int lhrs_decode_advance(int* state, int* desc, int* pos, int B, int max_ctx, int step_inc, void* stream) {
   LHRS_REQUIRE(B >= 1 && B <= 64, "decode_advance: B=%d", B);
-  hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, desc, pos, B, max_ctx, step_inc);
+  hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, desc, pos, B, max_ctx, step_inc, (const float*)nullptr,
+                     (const float*)nullptr, (float*)nullptr);
   LHRS_CHECK_LAUNCH("decode_advance");
+  return 0;
+}
+// the same, and cs[B][128] = the cos | sin rows (head_dim 128: 64 + 64 floats) of the new position for lhrs_decode_attn_split
+extern "C" int lhrs_decode_advance_cs(int* state, int* desc, int* pos, const float* cos_t, const float* sin_t, float* cs, int B, int max_ctx,
+                                      int step_inc, void* stream) {
+  LHRS_REQUIRE(B >= 1 && B <= 64 && cos_t && sin_t && cs, "decode_advance_cs: B=%d", B);
+  hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, desc, pos, B, max_ctx, step_inc, cos_t, sin_t, cs);
+  LHRS_CHECK_LAUNCH("decode_advance_cs");
   return 0;
 }
 
@@ -1089,16 +1114,17 @@ extern "C" int lhrs_decode_attn(const void* qkv, long ld, void* kcache, void* vc
 
 // The same with the context split over nsplit workgroups per head (decode_attn_split_kernel: nsplit slices of 128 keys in flight per head,
 // 1 <= nsplit <= 16).  part: fp32 [B][H][nsplit][132] partials, tickets: int32 [B][H], ZERO before the first call (the kernel leaves them
-// zero); both caller-owned and private to the stream the calls are ordered on.
+// zero); both caller-owned and private to the stream the calls are ordered on.  cs (may be NULL): float [B][128], the cos | sin rows of pos[b]
+// written by lhrs_decode_advance_cs - the kernel then takes the rotation from there instead of waiting for pos[b] to index the tables.
 extern "C" int lhrs_decode_attn_split(const void* qkv, long ld, void* kcache, void* vcache, const float* cos_t, const float* sin_t,
                                       const int* pos, const unsigned char* key_mask, long ld_mask, void* out, long ldo, int B, int H, int D,
-                                      int max_ctx, float scale, int nsplit, float* part, int* tickets, void* stream) {
+                                      int max_ctx, float scale, int nsplit, float* part, int* tickets, const float* cs, void* stream) {
   LHRS_REQUIRE(D == 128, "decode_attn_split: head_dim %d (only 128)", D);
   LHRS_REQUIRE(B >= 1 && H >= 1 && max_ctx >= 1 && ld % 8 == 0 && nsplit >= 1 && nsplit <= 16 && part && tickets,
                "decode_attn_split: B=%d H=%d max_ctx=%d nsplit=%d", B, H, max_ctx, nsplit);
   hipLaunchKernelGGL(decode_attn_split_kernel, dim3(H * nsplit, B), dim3(DS_WAVES * 64), 0, (hipStream_t)stream, (const bf16_t*)qkv, ld,
                      (bf16_t*)kcache, (bf16_t*)vcache, cos_t, sin_t, pos, key_mask, ld_mask, (bf16_t*)out, ldo, H, max_ctx, scale, nsplit, part,
-                     tickets);
+                     tickets, cs);
   LHRS_CHECK_LAUNCH("decode_attn_split");
   return 0;
 }

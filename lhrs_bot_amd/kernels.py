@@ -721,18 +721,23 @@ def decode_attn(qkv, kc, vc, cos_t, sin_t, pos, out, B, H, D, max_ctx, scale, ke
     return out
 
 
-def decode_attn_split(qkv, kc, vc, cos_t, sin_t, pos, out, B, H, D, max_ctx, scale, nsplit, part, tickets, key_mask=None):
+def decode_attn_split(qkv, kc, vc, cos_t, sin_t, pos, out, B, H, D, max_ctx, scale, nsplit, part, tickets, key_mask=None, cs=None):
     """decode_attn with the context split over `nsplit` workgroups per head (lhrs_decode_attn_split); part fp32 [B, H, nsplit, 132],
     tickets int32 [B, H] (zero before the first call)."""
     assert part.dtype == torch.float32 and part.numel() >= B * H * nsplit * 132 and tickets.dtype == torch.int32 and tickets.numel() >= B * H
     st = _L().lhrs_decode_attn_split(qkv.data_ptr(), qkv.stride(0), kc.data_ptr(), vc.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(),
                                      pos.data_ptr(), _p(key_mask), key_mask.stride(0) if key_mask is not None else 0, out.data_ptr(),
-                                     out.stride(0), B, H, D, max_ctx, float(scale), int(nsplit), part.data_ptr(), tickets.data_ptr(), _stream())
+                                     out.stride(0), B, H, D, max_ctx, float(scale), int(nsplit), part.data_ptr(), tickets.data_ptr(), _p(cs), _stream())
     _lib.check(st, "decode_attn_split")
     return out
 
 
-def decode_advance(state, desc, pos, B, max_ctx, inc=1):
+def decode_advance(state, desc, pos, B, max_ctx, inc=1, cos_t=None, sin_t=None, cs=None):
+    """cs (float32 [B, 128]) with the tables: also leave the cos | sin rows of the new position there (lhrs_decode_advance_cs)"""
+    if cs is not None:
+        _lib.check(_L().lhrs_decode_advance_cs(state.data_ptr(), desc.data_ptr(), pos.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), cs.data_ptr(),
+                                               B, max_ctx, inc, _stream()), "decode_advance_cs")
+        return
     _lib.check(_L().lhrs_decode_advance(state.data_ptr(), desc.data_ptr(), pos.data_ptr(), B, max_ctx, inc, _stream()), "decode_advance")
 
 

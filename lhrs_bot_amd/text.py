@@ -868,16 +868,18 @@ class TextModal:
         if nsplit > 1 and hd == 128:
             s.attn_part = torch.zeros((B, H, nsplit, 132), device=dev, dtype=torch.float32)
             s.attn_tickets = torch.zeros((B, H), device=dev, dtype=torch.int32)
+            s.attn_cs = torch.zeros((B, 128), device=dev, dtype=torch.float32)   # cos | sin of the new position, written by decode_advance
 
         def enqueue():
-            hk.decode_advance(s.state, s.desc, s.pos, B, max_ctx, 1)
+            cs = getattr(s, "attn_cs", None)
+            hk.decode_advance(s.state, s.desc, s.pos, B, max_ctx, 1, self.cos, self.sin, cs)
             hk.gather_rows(self.p["embed"], s.tok32, out=s.x)
             x, x2 = s.x, s.x2
             for L, (kc, vc) in zip(self.p["layers"], caches):
                 lin(*W(L, "qkv_w"), x, s.qkv, d, hk.PRO_RMSNORM, L["ln1_w"])
                 if hd == 128 and nsplit > 1:  # RoPE + KV append + attention over the cache in one launch, context split over workgroups
                     hk.decode_attn_split(s.qkv, kc, vc, self.cos, self.sin, s.pos, s.o, B, H, hd, max_ctx, scale, nsplit, s.attn_part,
-                                         s.attn_tickets, key_mask=kmask)
+                                         s.attn_tickets, key_mask=kmask, cs=cs)
                 elif hd == 128:
                     hk.decode_attn(s.qkv, kc, vc, self.cos, self.sin, s.pos, s.o, B, H, hd, max_ctx, scale, key_mask=kmask)
                 else:

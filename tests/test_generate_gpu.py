@@ -274,3 +274,8 @@ def test_decode_attn_split_matches_the_one_workgroup_kernel(nsplit):
         assert int(tickets.abs().sum()) == 0, ctx
         assert rel(o, o2) < 2e-3, (ctx, rel(o, o2))
         assert (o.float() - o2.float()).abs().max().item() <= 2.0 ** -6 * o2.float().abs().max().item(), ctx
+        # the cos | sin rows handed over by lhrs_decode_advance_cs instead of read from the tables behind pos[b]: the same numbers, bit for bit
+        cs = torch.cat([cos[pos.long()], sin[pos.long()]], dim=1).contiguous()
+        kc3, vc3, o3 = kc2.clone(), vc2.clone(), torch.empty_like(o)
+        hk.decode_attn_split(qkv, kc3, vc3, cos, sin, pos, o3, B, H, D, max_ctx, 1 / math.sqrt(D), nsplit, part, tickets, key_mask=km, cs=cs)
+        assert torch.equal(o3, o) and torch.equal(kc3, kc), ctx
