@@ -785,6 +785,8 @@ def test_gemm_tail_rows_split_k_matches_unsplit():
             lib.lhrs_gemm_set_tail_split(1)
         assert torch.equal(got, again)                                   # deterministic
         assert torch.equal(got[:8192], ref[:8192]), K                    # the rows of the whole rounds: same kernel, same tiles
-        assert rel_err(got[8192:], ref[8192:]) < 2e-3, (K, rel_err(got[8192:], ref[8192:]))
+        # tail rows: another k order, and ONE rounding behind the residual add where the 256-row kernel's epilogue rounds the product first (as the unfused
+        # GEMM -> add sequence does): a bf16 ulp on a fraction of the elements
+        assert rel_err(got[8192:], ref[8192:]) < 4e-3, (K, rel_err(got[8192:], ref[8192:]))
         want = x[8192:].float() @ w.float().t() + (res[8192:].float() if with_res else 0)
         assert rel_err(got[8192:], want) < 4e-3, K
