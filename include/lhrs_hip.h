@@ -369,6 +369,26 @@ long lhrs_image_preprocess_workspace(int H, int W, int short_edge);
 int lhrs_image_preprocess(const unsigned char* img, int H, int W, long row_stride, float* out, void* workspace, long workspace_bytes,
                           int short_edge, int crop_round, int rescale_mode, const float* mean, const float* stdv, void* stream);
 
+/* ---- module-level entry points: one call = one HF LlamaDecoderLayer ----------------------------------------------
+ * lhrs_llama_layer_forward : x -> x + o_proj(attn(RoPE(q_proj(n1)), RoPE(k_proj(n1)), v_proj(n1))) =: x_mid -> x_mid + down(silu(gate(n2)) * up(n2)),
+ *   n = RMSNorm; replaces the decoder layer inside HF LlamaForCausalLM.forward (lhrs/models/text_modal.py:281-292) for the frozen bf16
+ *   base without adapters.  x, x_mid, x_out, o, h: [B*S, d] bf16; qkv [B*S, 3d] (q, k rotated); gu [B*S, 2ff]; act [B*S, ff]; lse f32
+ *   [B, heads, LT]; desc int32 [B][8] attention records; LT = S rounded up to 64.  h and act are scratch, the rest is what the backward reads.
+ * lhrs_llama_layer_backward: d loss / d x_out -> d loss / d x (activation gradients only: the weights are frozen), what engine.backward
+ *   (lhrs/CustomTrainer/hook/deepspeed_hook.py:6-9) does inside one decoder layer.  *_wT = transposed weight copies; gu is overwritten
+ *   with d(gate|up); scratch dh, d_o [B*S, d], dqkv [B*S, 3d], delta f32 [B, heads, LT], dact [B*S, ff] (NULL allowed when
+ *   lhrs_gemm_swiglu_fusable() == 1); dx_in [B*S, d].
+ * Both compose the operator entry points above in the order lhrs_bot_amd/text.py uses (bit-identical results); caller-owned buffers. */
+int lhrs_llama_layer_forward(const void* x, const void* ln1_w, const void* qkv_w, const void* o_w, const void* ln2_w, const void* gu_w,
+                             const void* down_w, const float* cos_t, const float* sin_t, const int* desc, int B, int S, int LT, int d,
+                             int heads, int ff, float eps, void* h, void* qkv, void* o, float* lse, void* x_mid, void* gu, void* act,
+                             void* x_out, void* stream);
+int lhrs_llama_layer_backward(const void* dx_out, const void* x_in, const void* x_mid, const void* qkv, const void* o, const float* lse,
+                              void* gu, const void* ln1_w, const void* ln2_w, const void* qkv_wT, const void* o_wT, const void* gu_wT,
+                              const void* down_wT, const float* cos_t, const float* sin_t, const int* desc, int B, int S, int LT, int d,
+                              int heads, int ff, float eps, void* dh, void* d_o, void* dqkv, float* delta, void* dact, void* dx_in,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

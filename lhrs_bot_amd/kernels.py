@@ -413,6 +413,44 @@ def attn_bwd_o(q, k, v, dout, o, lse, delta, dq, dk, dv, desc, nseq, H, D, max_q
     _lib.check(st, "attn_bwd_o")
 
 
+# --------------------------------------------------------------------------------------------- whole decoder layer (module-level ABI)
+def llama_layer_forward(x, L, cos_t, sin_t, desc, B, S, LT, heads, ff, eps, h_scratch):
+    """One frozen bf16 decoder layer in ONE library call (lhrs_llama_layer_forward): -> (x_out, saved dict like TextModal._layer_fwd's)."""
+    M, d = x.shape
+    dev, bf = x.device, torch.bfloat16
+    qkv = torch.empty((M, 3 * d), device=dev, dtype=bf)
+    o = torch.empty((M, d), device=dev, dtype=bf)
+    lse = torch.empty((B, heads, LT), device=dev, dtype=torch.float32)
+    x_mid = torch.empty((M, d), device=dev, dtype=bf)
+    gu = torch.empty((M, 2 * ff), device=dev, dtype=bf)
+    act = torch.empty((M, ff), device=dev, dtype=bf)
+    x_out = torch.empty((M, d), device=dev, dtype=bf)
+    st = _L().lhrs_llama_layer_forward(x.data_ptr(), L["ln1_w"].data_ptr(), L["qkv_w"].data_ptr(), L["o_w"].data_ptr(), L["ln2_w"].data_ptr(),
+                                       L["gu_w"].data_ptr(), L["down_w"].data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), desc.data_ptr(), B, S, LT, d,
+                                       heads, ff, float(eps), h_scratch.data_ptr(), qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), x_mid.data_ptr(),
+                                       gu.data_ptr(), act.data_ptr(), x_out.data_ptr(), _stream())
+    _lib.check(st, "llama_layer_forward")
+    return x_out, dict(x_in=x, qkv=qkv, o=o, o_full=o, lse=lse, x_mid=x_mid, gu=gu)
+
+
+def llama_layer_backward(dx_out, s, L, cos_t, sin_t, desc, B, S, LT, heads, ff, eps, delta, dqkv):
+    """d loss / d x_out -> d loss / d x of one frozen bf16 decoder layer in ONE library call (lhrs_llama_layer_backward); s = the saved dict."""
+    M, d = dx_out.shape
+    dev, bf = dx_out.device, torch.bfloat16
+    dh = torch.empty((M, d), device=dev, dtype=bf)
+    d_o = torch.empty((M, d), device=dev, dtype=bf)
+    dx_in = torch.empty((M, d), device=dev, dtype=bf)
+    lib = _L()
+    dact = None if lib.lhrs_gemm_swiglu_fusable(M, ff, d, d, 0) else torch.empty((M, ff), device=dev, dtype=bf)
+    st = lib.lhrs_llama_layer_backward(dx_out.data_ptr(), s["x_in"].data_ptr(), s["x_mid"].data_ptr(), s["qkv"].data_ptr(), s["o_full"].data_ptr(),
+                                       s["lse"].data_ptr(), s["gu"].data_ptr(), L["ln1_w"].data_ptr(), L["ln2_w"].data_ptr(), L["qkv_wT"].data_ptr(),
+                                       L["o_wT"].data_ptr(), L["gu_wT"].data_ptr(), L["down_wT"].data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(),
+                                       desc.data_ptr(), B, S, LT, d, heads, ff, float(eps), dh.data_ptr(), d_o.data_ptr(), dqkv.data_ptr(),
+                                       delta.data_ptr(), _p(dact), dx_in.data_ptr(), _stream())
+    _lib.check(st, "llama_layer_backward")
+    return dx_in, dh          # (d loss / d x, d loss / d x_mid)
+
+
 # --------------------------------------------------------------------------------------------- element-wise
 def patchify(rgb, P=14, KP=640):
     B, C, H, W = rgb.shape

@@ -468,6 +468,13 @@ class TextModal:
         all B*S.  HF computes every row and the loss ignores them: same loss, same gradients, ~0.4 of a layer's linear work less."""
         d, H, hd, ff = self.d, self.heads, self.hd, self.ff
         M = x.shape[0]
+        if self._native_layer(tail):   # frozen bf16 base, no adapters, every row: the whole layer is ONE call into the library (same launches, same order)
+            if getattr(self, "_h_scratch", None) is None or self._h_scratch.shape != x.shape:
+                self._h_scratch = torch.empty_like(x)
+            x_out, rec = hk.llama_layer_forward(x, L, self.cos, self.sin, desc, B, S, LT, H, ff, self.eps, self._h_scratch)
+            if save is not None:
+                save.append(rec)
+            return x_out
         rec = {} if save is not None else None
         lo = self.lora
         hq = None
@@ -496,6 +503,12 @@ class TextModal:
             rec.update(x_in=x, qkv=qkv, o=o, o_full=o_full, lse=lse, x_mid=x_mid, gu=gu)
             save.append(rec)
         return x_out
+
+    def _native_layer(self, tail) -> bool:
+        """True when a decoder layer can go through the module-level entry points (lhrs_llama_layer_forward / _backward): the frozen bf16
+        base without adapters, on every row (the compact last layer keeps the operator path).  LHRS_NATIVE_LAYER=0: operator path (A/B, tests)."""
+        return (tail is None and self.lora is None and not self.base8 and not self.base_int8 and self.hd == 128
+                and os.environ.get("LHRS_NATIVE_LAYER", "1") != "0")
 
     def forward_hidden(self, embeds, mask_u8, save_ctx=True, kv_len=None, tail=None):
         """embeds [B,S,d] bf16, mask [B,S] uint8 (right padding) -> final-norm hidden [B*S, d].  kv_len: the per-sequence key counts when
@@ -1085,8 +1098,14 @@ class TextModal:
         nl = len(p["layers"])
         for li in reversed(range(nl)):
             L, s = p["layers"][li], c["layers"][li]
-            gu, qkv = s["gu"], s["qkv"]
             tl = tail if li == nl - 1 else None  # tail layer: dx, dgu, dh, dx_mid, do below have n rows until they are scattered back
+            if self._native_layer(tl):
+                dx, _ = hk.llama_layer_backward(dx, s, L, self.cos, self.sin, desc, B, S, LT, H, ff, self.eps, delta, dqkv)
+                s.clear()
+                if on_layer_ready is not None:
+                    on_layer_ready(li)
+                continue
+            gu, qkv = s["gu"], s["qkv"]
             act = hk.swiglu_fwd(gu, ff) if lo is not None and "down" in lo.groups else None      # x of the down projection
             dgu = self._down_bwd(li, dx, L["down_wT"], gu, act, s.get("T_down"), q8=self._q8(L, "down_wT"), dyq=dxq, drop=self._drop(s, "down"))
             dguq = None

@@ -392,3 +392,34 @@ def test_measured_micro_batches_end_to_end_vs_oracle(B):
     assert rel(d_image, col["image"].grad) < 5e-2
     assert rel(model.rgb.encode(batch["rgb"]), col["taps"].detach()) < 2e-2          # all B samples, all 768 tap tokens
     assert_projector_grads_directional(got, oracle_pooler_grads(P), 5e-2)
+
+
+@pytest.mark.timeout(900)
+def test_module_level_layer_entry_points_equal_the_operator_path(monkeypatch):
+    """lhrs_llama_layer_forward / lhrs_llama_layer_backward (one library call per decoder layer: include/lhrs_hip.h) against the
+    operator-by-operator path of text.py on the same batch: the same launches in the same order, so loss, d loss / d image and every projector
+    gradient are bit-identical; the compact last layer (supervised rows only) stays on the operator path in both runs."""
+    P = {"vit": OP.make_vit_params(seed=2), "pooler": OP.make_pooler_params(seed=1), "llama": OP.make_llama_params(seed=3, layers=3)}
+    g = torch.Generator().manual_seed(404)
+    B, T = 3, 40
+    ids = torch.randint(3, 32000, (B, T), generator=g)
+    ids[:, 0], ids[:, 1] = 1, -200
+    ids[2, 31:] = 0                                                  # one right-padded sequence: key counts differ per sequence
+    labels = ids.clone()
+    labels[:, :2] = -100
+    labels[ids == 0] = -100
+    batch = dict(rgb=torch.randn(B, 3, 224, 224, generator=g), input_ids=ids, labels=labels, attention_mask=ids.ne(0))
+    res = {}
+    for native in ("1", "0"):
+        monkeypatch.setenv("LHRS_NATIVE_LAYER", native)
+        model = UniBind(("rgb", "text"), None, device=DEV, llama_layers=3).load_params(P)
+        model.prepare_for_training()
+        assert model.text._native_layer(None) == (native == "1")
+        loss = model(batch)["total_loss"]
+        d_image = model.text.backward()
+        model.rgb_pooler.backward(d_image)
+        torch.cuda.synchronize()
+        res[native] = (loss.clone(), d_image.clone(), model.rgb_pooler.grad.clone())
+    assert torch.equal(res["1"][0], res["0"][0])
+    assert torch.equal(res["1"][1], res["0"][1])
+    assert torch.equal(res["1"][2], res["0"][2])
