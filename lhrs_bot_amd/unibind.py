@@ -94,8 +94,6 @@ class UniBind:
                                       "model.enable_lora(...) first; full LLaMA fine-tuning is not on the reference's path")
         self.rgb_pooler.requires_grad = bool(tune_rgb_pooler)
         self.train()
-        if model_path is not None:
-            self.custom_load_state_dict(model_path)
         if self.bits in (4, 8) and not (self.text.base8 or self.text.base_int8 or getattr(self.text, "base4", None)) and self.text.p.get("layers"):
             # the YAML's `bits: 8`: LLM.int8 storage and arithmetic of the (now loaded) frozen decoder linears, as the reference runs stages 2/3;
             # LHRS_BASE8=e4m3 selects the faster MI355X-native 8-bit base instead (a deviation: no outlier decomposition).
@@ -103,6 +101,11 @@ class UniBind:
             import os
             self.text.quantize_base(self.bits, os.environ.get("LHRS_BASE8", "int8"), quant_type=str(_get(self.config, "quant_type", "nf4")),
                                     double_quant=bool(_get(self.config, "double_quant", True)))
+        # AFTER the base is quantised, as in the reference: TextModal.__init__ loads the decoder through bitsandbytes (text_modal.py:91-131) and
+        # only then UniBind.custom_load_state_dict attaches / merges the adapters (UniBind.py:105-115) - a stage-0 merge therefore computes
+        # Q(D(Q(W)) + s B A) (merge_lora re-quantises the merged weight), not Q(W + s B A)
+        if model_path is not None:
+            self.custom_load_state_dict(model_path)
 
     def train(self):
         self.training = True
