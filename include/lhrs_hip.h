@@ -383,6 +383,13 @@ int lhrs_llama_layer_forward(const void* x, const void* ln1_w, const void* qkv_w
                              const void* down_w, const float* cos_t, const float* sin_t, const int* desc, int B, int S, int LT, int d,
                              int heads, int ff, float eps, void* h, void* qkv, void* o, float* lse, void* x_mid, void* gu, void* act,
                              void* x_out, void* stream);
+/* one pre-LN encoder layer of the frozen CLIP ViT IN PLACE on x [B * n, d] (HF CLIPEncoderLayer, reached from VisionModal.encode,
+ * lhrs/models/rgb_vision_modal.py:166-179): LN -> qkv (+bias) -> attention (no mask) -> out_proj (+bias, +x) -> LN -> fc1 (+bias, quick_gelu)
+ * -> fc2 (+bias, +x).  Scratch: h, o [B*n, d], qkv [B*n, 3d], f [B*n, ff]; desc int32 [B][8]; LT = n rounded up to 64. */
+int lhrs_vit_layer_forward(void* x, const void* ln1_w, const void* ln1_b, const void* qkv_w, const void* qkv_b, const void* o_w,
+                           const void* o_b, const void* ln2_w, const void* ln2_b, const void* fc1_w, const void* fc1_b, const void* fc2_w,
+                           const void* fc2_b, const int* desc, int B, int n, int LT, int d, int heads, int ff, void* h, void* qkv, void* o,
+                           void* f, void* stream);
 int lhrs_llama_layer_backward(const void* dx_out, const void* x_in, const void* x_mid, const void* qkv, const void* o, const float* lse,
                               void* gu, const void* ln1_w, const void* ln2_w, const void* qkv_wT, const void* o_wT, const void* gu_wT,
                               const void* down_wT, const float* cos_t, const float* sin_t, const int* desc, int B, int S, int LT, int d,

@@ -74,3 +74,26 @@ extern "C" int lhrs_llama_layer_backward(const void* dx_out, const void* x_in, c
   TRY(lhrs_rmsnorm_bwd(dx_in, x_in, ln1_w, nullptr, dh, dx_in, M, d, eps, stream));
   return 0;
 }
+
+// One pre-LN encoder layer of the frozen CLIP ViT (HF CLIPEncoderLayer inside CLIPVisionModel, reached from VisionModal.encode,
+// /root/reference lhrs/models/rgb_vision_modal.py:166-179): x <- x + out_proj(attn(q,k,v of LN1(x))), x <- x + fc2(quick_gelu(fc1(LN2(x)))),
+// IN PLACE on x [B * n, d] (n = 257 tokens per image).  Scratch: h [B*n, d], qkv [B*n, 3d], o [B*n, d], f [B*n, ff].  No mask, LN eps 1e-5.
+extern "C" int lhrs_vit_layer_forward(void* x, const void* ln1_w, const void* ln1_b, const void* qkv_w, const void* qkv_b, const void* o_w,
+                                      const void* o_b, const void* ln2_w, const void* ln2_b, const void* fc1_w, const void* fc1_b, const void* fc2_w,
+                                      const void* fc2_b, const int* desc, int B, int n, int LT, int d, int heads, int ff, void* h, void* qkv, void* o,
+                                      void* f, void* stream) {
+  LAYER_REQUIRE(B > 0 && n > 0 && d > 0 && heads > 0 && d % heads == 0 && ff > 0 && LT >= n, "vit_layer_forward: B=%d n=%d d=%d heads=%d ff=%d LT=%d", B, n, d,
+                heads, ff, LT);
+  LAYER_REQUIRE(x && ln1_w && ln1_b && qkv_w && qkv_b && o_w && o_b && ln2_w && ln2_b && fc1_w && fc1_b && fc2_w && fc2_b && desc && h && qkv && o && f,
+                "vit_layer_forward: null buffer");
+  const int M = B * n, hd = d / heads;
+  const char* q = (const char*)qkv;
+  TRY(lhrs_layernorm_fwd(x, d, ln1_w, ln1_b, h, d, nullptr, nullptr, M, d, 1e-5f, stream));
+  TRY(lhrs_gemm_bf16_nt(h, d, qkv_w, d, qkv, 3 * d, M, 3 * d, d, qkv_b, nullptr, 0, 0, 0, 0, 1.0f, stream));
+  TRY(lhrs_attn_fwd(q, 3 * d, q + (long)d * 2, 3 * d, q + (long)2 * d * 2, 3 * d, o, d, nullptr, desc, B, heads, hd, n, n, LT, 0, 1.0f / sqrtf((float)hd), stream));
+  TRY(lhrs_gemm_bf16_nt(o, d, o_w, d, x, d, M, d, d, o_b, x, d, 0, 0, 0, 1.0f, stream));
+  TRY(lhrs_layernorm_fwd(x, d, ln2_w, ln2_b, h, d, nullptr, nullptr, M, d, 1e-5f, stream));
+  TRY(lhrs_gemm_bf16_nt(h, d, fc1_w, d, f, ff, M, ff, d, fc1_b, nullptr, 0, 1 /* quick_gelu */, 0, 0, 1.0f, stream));
+  TRY(lhrs_gemm_bf16_nt(f, ff, fc2_w, ff, x, d, M, d, ff, fc2_b, x, d, 0, 0, 0, 1.0f, stream));
+  return 0;
+}

@@ -433,6 +433,17 @@ def llama_layer_forward(x, L, cos_t, sin_t, desc, B, S, LT, heads, ff, eps, h_sc
     return x_out, dict(x_in=x, qkv=qkv, o=o, o_full=o, lse=lse, x_mid=x_mid, gu=gu)
 
 
+def vit_layer_forward(x, L, desc, B, n, LT, heads, ff, h, qkv, o, f):
+    """One frozen CLIP ViT encoder layer IN PLACE on x, in one library call (lhrs_vit_layer_forward)."""
+    d = x.shape[1]
+    st = _L().lhrs_vit_layer_forward(x.data_ptr(), L["ln1_w"].data_ptr(), L["ln1_b"].data_ptr(), L["qkv_w"].data_ptr(), L["qkv_b"].data_ptr(),
+                                     L["o_w"].data_ptr(), L["o_b"].data_ptr(), L["ln2_w"].data_ptr(), L["ln2_b"].data_ptr(), L["fc1_w"].data_ptr(),
+                                     L["fc1_b"].data_ptr(), L["fc2_w"].data_ptr(), L["fc2_b"].data_ptr(), desc.data_ptr(), B, n, LT, d, heads, ff,
+                                     h.data_ptr(), qkv.data_ptr(), o.data_ptr(), f.data_ptr(), _stream())
+    _lib.check(st, "vit_layer_forward")
+    return x
+
+
 def llama_layer_backward(dx_out, s, L, cos_t, sin_t, desc, B, S, LT, heads, ff, eps, delta, dqkv):
     """d loss / d x_out -> d loss / d x of one frozen bf16 decoder layer in ONE library call (lhrs_llama_layer_backward); s = the saved dict."""
     M, d = dx_out.shape

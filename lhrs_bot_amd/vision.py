@@ -7,6 +7,7 @@ are skipped here.  All arithmetic is liblhrs_hip.so; torch on
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List
 
 import torch
@@ -96,14 +97,21 @@ class VisionModal:
         out = torch.empty((B, len(self.extract_stage) * self.n_patch, d), device=self.device, dtype=torch.bfloat16)
         o = torch.empty((B * n, d), device=self.device, dtype=torch.bfloat16)
         scale = (d // H) ** -0.5
+        native = os.environ.get("LHRS_NATIVE_LAYER", "1") != "0"   # one library call per encoder layer (lhrs_vit_layer_forward: same launches, same order)
+        if native:
+            h, qkv = torch.empty_like(x), torch.empty((B * n, 3 * d), device=self.device, dtype=torch.bfloat16)
+            f = torch.empty((B * n, self.ff), device=self.device, dtype=torch.bfloat16)
         for li, L in enumerate(p["layers"]):
-            h = hk.layernorm_fwd(x, L["ln1_w"], L["ln1_b"])
-            qkv = hk.gemm_nt(h, L["qkv_w"], bias=L["qkv_b"])
-            hk.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, None, desc, B, H, d // H, n, n, LT, False, scale)
-            x = hk.gemm_nt(o, L["o_w"], bias=L["o_b"], residual=x, out=x)
-            h = hk.layernorm_fwd(x, L["ln2_w"], L["ln2_b"], out=h)
-            f = hk.gemm_nt(h, L["fc1_w"], bias=L["fc1_b"], act=hk.ACT_QUICK_GELU)
-            x = hk.gemm_nt(f, L["fc2_w"], bias=L["fc2_b"], residual=x, out=x)
+            if native:
+                hk.vit_layer_forward(x, L, desc, B, n, LT, H, self.ff, h, qkv, o, f)
+            else:
+                h = hk.layernorm_fwd(x, L["ln1_w"], L["ln1_b"])
+                qkv = hk.gemm_nt(h, L["qkv_w"], bias=L["qkv_b"])
+                hk.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, None, desc, B, H, d // H, n, n, LT, False, scale)
+                x = hk.gemm_nt(o, L["o_w"], bias=L["o_b"], residual=x, out=x)
+                h = hk.layernorm_fwd(x, L["ln2_w"], L["ln2_b"], out=h)
+                f = hk.gemm_nt(h, L["fc1_w"], bias=L["fc1_b"], act=hk.ACT_QUICK_GELU)
+                x = hk.gemm_nt(f, L["fc2_w"], bias=L["fc2_b"], residual=x, out=x)
             if li + 1 in self.extract_stage:  # hidden_states[li+1]; drop CLS, place tap g at rows [g*256, (g+1)*256)
                 gi = self.extract_stage.index(li + 1)
                 row_b = d * 2
