@@ -67,13 +67,17 @@ def test_text_only_generate_matches_oracle():
 def test_sampling_path_runs_and_respects_eos():
     model = UniBind(("rgb", "text"), None, device=DEV, llama_layers=1).init_random(seed=0).eval()
     ids = torch.tensor([[1, -200, 5, 6, 7]])
-    rgb = torch.randn(1, 3, 224, 224)
+    rgb = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(67))   # (seeded: the image used to depend on what ran before in the process)
     torch.manual_seed(0)
     out = model.generate(ids, images=rgb, do_sample=True, temperature=0.4, top_p=0.9, top_k=50, max_new_tokens=5)
     assert out.shape == (1, 5) and int(out.min()) >= 0 and int(out.max()) < 32000
     first = model.generate(ids, images=rgb, do_sample=False, max_new_tokens=4)
-    stop = model.generate(ids, images=rgb, do_sample=False, max_new_tokens=4, eos_token_id=int(first[0, 1]))
-    assert stop.shape[1] == 2 and torch.equal(stop[0], first[0, :2])
+    # stop on the first token that has not appeared before it (a random-init one-layer model may repeat its first token: stopping on a
+    # repeated token ends the sequence at its FIRST occurrence)
+    toks = first[0].tolist()
+    j = max(i for i in range(len(toks)) if toks[i] not in toks[:i])
+    stop = model.generate(ids, images=rgb, do_sample=False, max_new_tokens=4, eos_token_id=int(toks[j]))
+    assert stop.shape[1] == j + 1 and torch.equal(stop[0], first[0, :j + 1])
 
 
 def test_gemv_and_graph_decode_equal_eager_decode():

@@ -790,3 +790,17 @@ def test_gemm_tail_rows_split_k_matches_unsplit():
         assert rel_err(got[8192:], ref[8192:]) < 4e-3, (K, rel_err(got[8192:], ref[8192:]))
         want = x[8192:].float() @ w.float().t() + (res[8192:].float() if with_res else 0)
         assert rel_err(got[8192:], want) < 4e-3, K
+
+
+def test_copy_2d_kernel_and_runtime_fallback():
+    """lhrs_copy_2d: pitched device-to-device block copy - one kernel launch for 16-byte aligned blocks (the ViT taps, the K / V rows of a
+    prefill), the runtime's pitched copy otherwise; both against torch slicing, bytes outside the block untouched."""
+    g = torch.Generator().manual_seed(3)
+    src = torch.randint(0, 255, (37, 4096), generator=g, dtype=torch.uint8).to(DEV)
+    for (r0, c0, h, w) in ((0, 0, 37, 4096), (3, 32, 30, 2048), (1, 16, 5, 48), (2, 6, 7, 100), (0, 1, 37, 15)):     # the last two: not 16-byte aligned
+        dst = torch.full((40, 8192), 7, dtype=torch.uint8, device=DEV)
+        hk.copy_2d(dst.data_ptr() + 2 * 8192 + 64, 8192, src.data_ptr() + r0 * 4096 + c0, 4096, w, h)
+        torch.cuda.synchronize()
+        want = torch.full((40, 8192), 7, dtype=torch.uint8, device=DEV)
+        want[2:2 + h, 64:64 + w] = src[r0:r0 + h, c0:c0 + w]
+        assert torch.equal(dst, want), (r0, c0, h, w)
