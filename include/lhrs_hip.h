@@ -168,13 +168,14 @@ int lhrs_gemm_set_small_thresh(int n);
 /* kernel A/B tests only: fewest 256x256 tiles for which lhrs_gemm_bf16_nt picks the big-tile kernel (default 128) */
 int lhrs_gemm_set_min_tiles(int n);
 /* live HIP-event timing of the 16-wave 256x256 GEMM launches, on their launch stream, for bench.py's roofline leg (gemm.hip):
- * enable(n) arms n event pairs (0 = off); read() -> {launches of the dominant <ACT,0> kernel, their ms, their flops, all GEMM launches,
- * all GEMM flops}; read_kinds() -> [4][3] = {launches, ms, flops} per epilogue variant (0 plain, 1 SwiGLU fwd, 2 SwiGLU bwd, 3 RoPE) */
+ * enable(n) arms n event pairs (0 = off); read() -> {launches of the plain-epilogue persistent kernels (256-row + 144-row tiles), their ms, their
+ * flops, all GEMM launches, all GEMM flops}; read_kinds() -> [5][3] = {launches, ms, flops} per kind: 0 plain <ACT,0> of the 256x256 kernel (the
+ * dominant kernel), 1 SwiGLU fwd, 2 SwiGLU bwd, 3 RoPE epilogue of the same kernel, 4 the plain 144-row kernel */
 int lhrs_gemm_profile_enable(int max_samples);
 /* bracket only every n-th launch of each epilogue variant (default 1): the event records themselves cost stream time (1-2 % of a step) */
 int lhrs_gemm_profile_stride(int n);
 int lhrs_gemm_profile_read(double* out5_host);
-int lhrs_gemm_profile_read_kinds(double* out12_host);
+int lhrs_gemm_profile_read_kinds(double* out15_host);
 
 /* ---- LoRA gradients (peft lora.Linear backward; lhrs/models/text_modal.py:133-151) ------------------------- *
  * C[KP,N] (+)= P[M,KP]^T . Q[M,N]: dA = (s dy B)^T x and dB^T = (s x A^T)^T dy straight from token-major operands.  */

@@ -1215,7 +1215,7 @@ struct GemmProf {
   double total_flops_all = 0; // every GEMM launch while enabled (sampled or not)
   long launches_all = 0;
   int stride = 1;             // every stride-th launch of each epilogue variant is bracketed (lhrs_gemm_profile_stride)
-  long seen[4] = {0, 0, 0, 0};
+  long seen[5] = {0, 0, 0, 0, 0};
   bool take(int kind) { return (seen[kind]++ % stride) == 0; }
 } g_prof;
 }  // namespace
@@ -1234,7 +1234,7 @@ extern "C" int lhrs_gemm_profile_enable(int max_samples) {
   }
   g_prof.on = max_samples > 0; g_prof.cap = max_samples > 0 ? max_samples : 0; g_prof.used = 0;
   g_prof.total_flops_all = 0; g_prof.launches_all = 0;
-  for (int k = 0; k < 4; ++k) g_prof.seen[k] = 0;
+  for (int k = 0; k < 5; ++k) g_prof.seen[k] = 0;
   if (g_prof.on) {
     g_prof.ev = new hipEvent_t[2 * g_prof.cap];
     g_prof.flops = new double[g_prof.cap];
@@ -1250,7 +1250,7 @@ extern "C" int lhrs_gemm_profile_enable(int max_samples) {
 extern "C" int lhrs_gemm_profile_read(double* out) {
   double ms = 0, fl = 0, n = 0;
   for (int i = 0; i < g_prof.used; ++i) {
-    if (g_prof.kind[i] != 0) continue;  // the dominant kernel only; the fused-epilogue variants: lhrs_gemm_profile_read_kinds
+    if (g_prof.kind[i] != 0 && g_prof.kind[i] != 4) continue;  // the plain-epilogue persistent kernels (256-row + 144-row tiles); per kernel / variant: lhrs_gemm_profile_read_kinds
     float t = 0;
     if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) LHRS_FAIL("gemm_profile_read: event sync failed");
     if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) LHRS_FAIL("gemm_profile_read: elapsed failed");
@@ -1260,10 +1260,11 @@ extern "C" int lhrs_gemm_profile_read(double* out) {
   return 0;
 }
 
-// out[4][3]: per epilogue variant k (0 plain <ACT,0>, 1 SwiGLU fwd <0,1>, 2 SwiGLU bwd <0,2>, 3 RoPE <0,3>) of the 16-wave 256x256 kernel:
+// out[5][3]: per kind k - 0 plain <ACT,0> of the 16-wave 256x256 kernel (THE dominant kernel), 1 SwiGLU fwd <0,1>, 2 SwiGLU bwd <0,2>, 3 RoPE <0,3> of
+// the same kernel, 4 the plain 144-row persistent kernel (gemm_nt_144s_kernel<ACT, 0>: ViT / projector products, micro-batch 8) -:
 // sampled launches, their summed duration (ms), their summed flops
 extern "C" int lhrs_gemm_profile_read_kinds(double* out) {
-  for (int i = 0; i < 12; ++i) out[i] = 0;
+  for (int i = 0; i < 15; ++i) out[i] = 0;
   for (int i = 0; i < g_prof.used; ++i) {
     float t = 0;
     if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) LHRS_FAIL("gemm_profile_read_kinds: event sync failed");
@@ -1569,10 +1570,11 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   if (g_prof.on) {
     g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * (K + K2);
     const bool dominant = use256 && g_gemm_allow_256 == 2 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128;
-    if (dominant && g_prof.used < g_prof.cap && g_prof.take(0)) {  // time the launches rocprof lists as gemm_nt_256s / 144s_kernel<ACT, 0 ...>
+    const int pkind = bm144 ? 4 : 0;
+    if (dominant && g_prof.used < g_prof.cap && g_prof.take(pkind)) {  // time the launches rocprof lists as gemm_nt_256s_kernel<ACT, 0 ...> (kind 0) / gemm_nt_144s_kernel<ACT, 0> (kind 4)
       slot = g_prof.used++;
       g_prof.flops[slot] = 2.0 * M * N * (K + K2);
-      g_prof.kind[slot] = 0;
+      g_prof.kind[slot] = pkind;
       (void)hipEventRecord(g_prof.ev[2 * slot], s);
     }
   }

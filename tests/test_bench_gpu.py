@@ -29,7 +29,8 @@ def test_bench_emits_the_contract_line():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["launches_timed"] > 0
     assert r["traffic"] is None and "not measured in this run" in r["traffic_note"] and d["ms_per_step_median"] > 0
     v = r["variants"]
-    assert {"<ACT,0> plain", "<0,1> SwiGLU-fwd epilogue", "<0,2> SwiGLU-bwd epilogue", "<0,3> RoPE epilogue"} <= set(v), v
+    assert {"<ACT,0> plain, 256-row tiles", "<0,1> SwiGLU-fwd epilogue", "<0,2> SwiGLU-bwd epilogue", "<0,3> RoPE epilogue"} <= set(v), v
+    assert "gemm_nt_256s_kernel" in r["kernel"] and abs(r["achieved"] - v["<ACT,0> plain, 256-row tiles"]["achieved_tflops"]) < 0.11   # quoted on ONE kernel
     assert all(0 < x["frac"] < 1 and x["launches"] > 0 for x in v.values())
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "samples/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
