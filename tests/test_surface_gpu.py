@@ -70,3 +70,19 @@ def test_uint8_pictures_of_different_sizes_equal_the_float_path(tmp_path):
     a = model(dict(rgb=pics, input_ids=ids, labels=labels, attention_mask=ids.ne(0)))["total_loss"].item()
     b = model(dict(rgb=px, input_ids=ids, labels=labels, attention_mask=ids.ne(0)))["total_loss"].item()
     assert a == b
+
+
+@pytest.mark.timeout(1200)
+def test_stage1_driver_on_rs5m_tar_shards_has_an_epoch_length(tmp_path):
+    """Stage 1 on an RS5M path (`"RS5M" in config.data_path` -> the tar-shard pipeline, build_loader.py:110-160) through the trainer: the loader
+    has a length (`Trainer.epoch_len` = len(data_loader): the reference's `with_epoch(num_worker_batches)`), every worker yields exactly its share
+    of batches - walking its shards again when they run dry - and the epoch ends after exactly that many optimizer steps."""
+    import main_pretrain_stage1 as drv
+    from test_datasets_cpu import _make_rs5m_shards
+    root = str(tmp_path / "RS5M")
+    _make_rs5m_shards(root)                                           # 4 shards x 5 samples
+    os.makedirs(tmp_path / "out" / "checkpoints", exist_ok=True)
+    cfg = _config(tmp_path, data_path=root, workers=2, epochs=1, rs5m_num_samples=28)     # ceil(28 / 2) = 14 batches = 2 workers x 7: more than one pass over a worker's 10 samples
+    t = drv.main(cfg)
+    assert len(t.data_loader) == 14 and t.max_iters == 14 and t.model.global_steps == 14
+    assert len(t.history) == 14 and all(torch.isfinite(torch.tensor(h["loss"])) for h in t.history)
