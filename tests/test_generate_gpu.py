@@ -283,3 +283,46 @@ def test_decode_attn_split_matches_the_one_workgroup_kernel(nsplit):
         kc3, vc3, o3 = kc2.clone(), vc2.clone(), torch.empty_like(o)
         hk.decode_attn_split(qkv, kc3, vc3, cos, sin, pos, o3, B, H, D, max_ctx, 1 / math.sqrt(D), nsplit, part, tickets, key_mask=km, cs=cs)
         assert torch.equal(o3, o) and torch.equal(kc3, kc), ctx
+
+
+@pytest.mark.timeout(600)
+def test_decode_attn_split_exchange_under_load_is_stable():
+    """The cross-workgroup hand-off of lhrs_decode_attn_split (write-through partials, drained, one ticket per head, last arriver reads with
+    sc1 loads) under UNEVEN load and with a warm L1 - the conditions under which a missing release / acquire shows (MI355X_MICROARCH.md,
+    inter-workgroup visibility): a side stream keeps the chip busy with GEMMs of varying size while 300 launches walk contexts of 130 - 1500
+    keys over the SAME partial buffer (every launch overwrites what the previous one's last arrivers just read).  Every output is compared
+    in full with the one-workgroup kernel's, every launch is repeated and must reproduce itself bit for bit, and the tickets must be back
+    at zero each time."""
+    import math
+    g = torch.Generator().manual_seed(5150)
+    B, H, D, max_ctx, NS = 2, 32, 128, 1536, 12
+    d = H * D
+    cos, sin = (t.to(DEV) for t in __import__("oracle.lhrs_oracle", fromlist=["rope_tables"]).rope_tables(max_ctx, D))
+    kc0 = torch.randn(B * max_ctx, d, generator=g).to(DEV, torch.bfloat16)
+    vc0 = torch.randn(B * max_ctx, d, generator=g).to(DEV, torch.bfloat16)
+    part = torch.zeros(B, H, NS, 132, device=DEV)
+    tickets = torch.zeros(B, H, device=DEV, dtype=torch.int32)
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=DEV).bfloat16()
+    w = torch.randn(4096, 4096, device=DEV).bfloat16()
+    outs = [torch.empty(B, d, device=DEV, dtype=torch.bfloat16) for _ in range(3)]
+    bad = []
+    for it in range(300):
+        ctx = 130 + (it * 37) % 1370
+        with torch.cuda.stream(side):                              # uneven background load: 1 - 4 GEMMs of 512 - 4096 rows
+            for j in range(1 + it % 4):
+                hk.gemm_nt(a[: 512 << (j % 4)], w)
+        qkv = torch.randn(B, 3 * d, generator=g).to(DEV, torch.bfloat16)
+        pos = torch.tensor([ctx, ctx - 1 - it % 100], dtype=torch.int32, device=DEV)
+        res = []
+        for o in outs[:2]:
+            kc, vc = kc0.clone(), vc0.clone()
+            hk.decode_attn_split(qkv, kc, vc, cos, sin, pos, o, B, H, D, max_ctx, 1 / math.sqrt(D), NS, part, tickets)
+            res.append(o)
+        kc, vc = kc0.clone(), vc0.clone()
+        hk.decode_attn(qkv, kc, vc, cos, sin, pos, outs[2], B, H, D, max_ctx, 1 / math.sqrt(D))
+        torch.cuda.synchronize()
+        if not torch.equal(res[0], res[1]) or int(tickets.abs().sum()) != 0 or rel(res[0], outs[2]) > 2e-3 or \
+                (res[0].float() - outs[2].float()).abs().max().item() > 2.0 ** -6 * outs[2].float().abs().max().item():
+            bad.append((it, ctx, rel(res[0], outs[2]), bool(torch.equal(res[0], res[1])), int(tickets.abs().sum())))
+    assert not bad, bad[:5]
