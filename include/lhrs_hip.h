@@ -92,6 +92,20 @@ int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int ldw, const
                          int K2, void* gu, int ld_gu, void* act, int ld_act, int M, int ff, int K, void* stream);
 int lhrs_gemm_swiglu_bwd(const void* dY, int ldy, const void* WdT, int ldw, const void* A2, int lda2, const void* B2, int ldb2,
                          int K2, const void* gu, void* dgu, int ld_gu, void* dact_scratch, int M, int ff, int K, void* stream);
+/* ---- RMSNorm backward inside the dX GEMM (no pass of its own over HBM; HF LlamaRMSNorm in front of LlamaMLP, text_modal.py:281-292) ----
+ * The backward of h = w o (x * rstd) needs c = sum_j dh_j w_j x_j over the whole row of dh = d(gate|up) . W_gu; since c = (1 / rstd) *
+ * <d(gate|up), gate|up>, the fused d-down + SwiGLU' launch can emit it: lhrs_gemm_swiglu_bwd_rowdot = lhrs_gemm_swiglu_bwd that also writes
+ * row_dot [4 * ff / 256][M] fp32 partial sums; lhrs_rowsum_partials folds them into s [M] in a fixed order; lhrs_gemm_rmsnorm_bwd computes
+ * out = rstd * (w o (dY . WT^T)) - x * (rstd^2 * s / N) + add in the epilogue of the dX GEMM (dY [M, K], WT [N, K] = transposed weight copy,
+ * x / add / out [M, N], w [N] bf16, rstd / s [M] fp32; add may be NULL).  Only where lhrs_gemm_rmsnorm_bwd_fusable(M, d, ff) == 1 (both
+ * products whole rounds of the 256-row persistent kernel); elsewhere callers keep lhrs_gemm_swiglu_bwd -> lhrs_gemm_bf16_nt -> lhrs_rmsnorm_bwd.
+ * Same function up to rounding: dh is used as the unfused path stores it (bf16), s comes from the stored bf16 d(gate|up) and gate|up. */
+int lhrs_gemm_rmsnorm_bwd_fusable(int M, int d, int ff);
+int lhrs_gemm_swiglu_bwd_rowdot(const void* dY, int ldy, const void* WdT, int ldw, const void* gu, void* dgu, int ld_gu, float* row_dot,
+                                int M, int ff, int K, void* stream);
+int lhrs_rowsum_partials(const float* part, float* out, int P, int M, void* stream);
+int lhrs_gemm_rmsnorm_bwd(const void* dY, int ldy, const void* WT, int ldw, const void* x, int ldx, const void* w, const float* rstd,
+                          const float* s_row, const void* add, int ld_add, void* out, int ldo, int M, int N, int K, void* stream);
 /* qkv projection with the RoPE of its q / k heads in the GEMM epilogue (HF LlamaAttention.forward: apply_rotary_pos_emb on
  * q_proj / k_proj outputs, rotate_half convention; text_modal.py:258-294): C[M, N] = X.W^T (+ A2.B2^T); the heads of width
  * head_dim in columns [0, rope_cols) are rotated with position m %% pos_mod + pos0 of their row (cos / sin fp32 [pos][head_dim/2]),
@@ -378,12 +392,14 @@ int lhrs_image_preprocess(const unsigned char* img, int H, int W, long row_strid
  * lhrs_llama_layer_backward: d loss / d x_out -> d loss / d x (activation gradients only: the weights are frozen), what engine.backward
  *   (lhrs/CustomTrainer/hook/deepspeed_hook.py:6-9) does inside one decoder layer.  *_wT = transposed weight copies; gu is overwritten
  *   with d(gate|up); scratch dh, d_o [B*S, d], dqkv [B*S, 3d], delta f32 [B, heads, LT], dact [B*S, ff] (NULL allowed when
- *   lhrs_gemm_swiglu_fusable() == 1); dx_in [B*S, d].
+ *   lhrs_gemm_swiglu_fusable() == 1); dx_in [B*S, d].  Optional (NULL = off): rstd2 f32 [B*S] as the forward saved it + scratch rowdot_part
+ *   f32 [4 * ff / 256][B*S] and rowdot_sum f32 [B*S]: where lhrs_gemm_rmsnorm_bwd_fusable says so, the second norm's backward then rides in the
+ *   d-gate|up GEMM's epilogue instead of being a pass of its own.
  * Both compose the operator entry points above in the order lhrs_bot_amd/text.py uses (bit-identical results); caller-owned buffers. */
 int lhrs_llama_layer_forward(const void* x, const void* ln1_w, const void* qkv_w, const void* o_w, const void* ln2_w, const void* gu_w,
                              const void* down_w, const float* cos_t, const float* sin_t, const int* desc, int B, int S, int LT, int d,
-                             int heads, int ff, float eps, void* h, void* qkv, void* o, float* lse, void* x_mid, void* gu, void* act,
-                             void* x_out, void* stream);
+                             int heads, int ff, float eps, void* h, void* qkv, void* o, float* lse, void* x_mid, float* rstd2, void* gu,
+                             void* act, void* x_out, void* stream);
 /* one pre-LN encoder layer of the frozen CLIP ViT IN PLACE on x [B * n, d] (HF CLIPEncoderLayer, reached from VisionModal.encode,
  * lhrs/models/rgb_vision_modal.py:166-179): LN -> qkv (+bias) -> attention (no mask) -> out_proj (+bias, +x) -> LN -> fc1 (+bias, quick_gelu)
  * -> fc2 (+bias, +x).  Scratch: h, o [B*n, d], qkv [B*n, 3d], f [B*n, ff]; desc int32 [B][8]; LT = n rounded up to 64. */
@@ -395,7 +411,7 @@ int lhrs_llama_layer_backward(const void* dx_out, const void* x_in, const void* 
                               void* gu, const void* ln1_w, const void* ln2_w, const void* qkv_wT, const void* o_wT, const void* gu_wT,
                               const void* down_wT, const float* cos_t, const float* sin_t, const int* desc, int B, int S, int LT, int d,
                               int heads, int ff, float eps, void* dh, void* d_o, void* dqkv, float* delta, void* dact, void* dx_in,
-                              void* stream);
+                              const float* rstd2, float* rowdot_part, float* rowdot_sum, void* stream);
 
 #ifdef __cplusplus
 }

@@ -50,7 +50,13 @@ struct GemmArgs {
   //   epi 1: B = [gate; up] weight [2*ff, K]; tile tn holds gate AND up of columns [tn*128, +128) (wave wn: 32 gate + 32 up);
   //          C = gate|up [M, 2*ff] in the usual layout, aux_out = silu(gate) * up [M, ff]
   //   epi 2: A.B^T = d_act [M, ff]; aux = gate|up [M, 2*ff]; C = d(gate|up) [M, 2*ff] (may alias aux)
+  //   epi 5: epi 2, and row_dot[(tn * 4 + wn) * M + m] = sum over the wave's 64 columns of d(gate|up) * gate|up (fp32) - the partial sums of
+  //          the row dot product <d(gate|up), gate|up> that the RMSNorm backward behind the NEXT product needs (epi 4)
+  //   epi 4: RMSNorm backward in the epilogue (HF LlamaRMSNorm, no recompute): A.B^T = dh = d loss / d (normalised row) [M, N], N = the whole
+  //          normalised width; C = rstd * (w o dh) - x * (rstd^2 * s / N) + add with x = aux [M, ld_aux], add = res [M, ldr] (may be null),
+  //          w = bias [N], rstd = sa [M], s = sb [M] = sum_j dh_j w_j x_j * rstd (= <d(gate|up), gate|up> of the linear the norm feeds)
   int epi, ff;
+  float* row_dot;
   const bf16_t* aux;
   bf16_t* aux_out;
   long ld_aux;
@@ -774,20 +780,24 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
       const int n = EPI == 1   ? (c < 4 ? 0 : g.ff) + tn * 128 + wn * 32 + (c & 3) * 8
                     : rope_tile ? tn * BN + (wn >> 1) * 128 + (c < 4 ? 0 : 64) + (wn & 1) * 32 + (c & 3) * 8
                                 : tn * BN + wn * 64 + c * 8;
-      const int nlim = EPI == 2 ? g.ff : g.N;
+      constexpr bool SWB = EPI == 2 || EPI == 5;   // SwiGLU-backward epilogue (5: + row dot partials)
+      const int nlim = SWB ? g.ff : g.N;
       const bool col_ok = n < nlim;
 #pragma unroll
       for (int ps = 0; ps < 2; ++ps) {
         uint4 pre_a[4], pre_b[4];
-        if (EPI == 2 || (EPI == 0 && g.res)) {
+        if (SWB || EPI == 4 || (EPI == 0 && g.res)) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int m = tm * BM + wm * 64 + ps * 32 + i * 8 + rsub;
             pre_a[i] = make_uint4(0, 0, 0, 0); pre_b[i] = make_uint4(0, 0, 0, 0);
             if (m < g.M && col_ok) {
-              if (EPI == 2) {
+              if (SWB) {
                 pre_a[i] = *reinterpret_cast<const uint4*>(g.aux + (long)m * g.ld_aux + n);
                 pre_b[i] = *reinterpret_cast<const uint4*>(g.aux + (long)m * g.ld_aux + g.ff + n);
+              } else if (EPI == 4) {
+                pre_a[i] = *reinterpret_cast<const uint4*>(g.aux + (long)m * g.ld_aux + n);                        // x
+                if (g.res) pre_b[i] = *reinterpret_cast<const uint4*>(g.res + (long)m * g.ldr + n);              // add
               } else {
                 pre_a[i] = *reinterpret_cast<const uint4*>(g.res + (long)m * g.ldr + n);
               }
@@ -842,20 +852,37 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
           const int r32 = i * 8 + rsub;
           const int m = tm * BM + wm * 64 + ps * 32 + r32;
           uint4 val = *reinterpret_cast<const uint4*>(reg + r32 * 128 + ((c ^ (r32 & 7)) << 4));
-          if (m < g.M && col_ok) {
-            if (EPI == 2) {
-              const uint4 gq = pre_a[i], uq = pre_b[i];
-              float d[8], gg[8], uu[8], dg[8], du[8];
-              unpack8(val, d); unpack8(gq, gg); unpack8(uq, uu);
+          float rowp = 0.f;   // EPI 5: this lane's 8 columns of <d(gate|up), gate|up> of row m
+          if (SWB && m < g.M && col_ok) {
+            const uint4 gq = pre_a[i], uq = pre_b[i];
+            float d[8], gg[8], uu[8], dg[8], du[8];
+            unpack8(val, d); unpack8(gq, gg); unpack8(uq, uu);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const float sg = 1.f / (1.f + __expf(-gg[e]));
-                du[e] = d[e] * gg[e] * sg;
-                dg[e] = d[e] * uu[e] * sg * (1.f + gg[e] * (1.f - sg));
-              }
-              bf16_t* out = reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n;
-              *reinterpret_cast<uint4*>(out) = pack8(dg);
-              *reinterpret_cast<uint4*>(out + g.ff) = pack8(du);
+            for (int e = 0; e < 8; ++e) {
+              const float sg = 1.f / (1.f + __expf(-gg[e]));
+              du[e] = d[e] * gg[e] * sg;
+              dg[e] = d[e] * uu[e] * sg * (1.f + gg[e] * (1.f - sg));
+              if (EPI == 5) rowp += bf2f(f2bf(dg[e])) * gg[e] + bf2f(f2bf(du[e])) * uu[e];   // on the values as they are stored
+            }
+            bf16_t* out = reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n;
+            *reinterpret_cast<uint4*>(out) = pack8(dg);
+            *reinterpret_cast<uint4*>(out + g.ff) = pack8(du);
+          }
+          if (EPI == 5) {   // the 8 lanes c = 0..7 of a row hold its 64 columns of this wave: fold them, lane c == 0 stores the partial
+            rowp += __shfl_xor(rowp, 1, 64); rowp += __shfl_xor(rowp, 2, 64); rowp += __shfl_xor(rowp, 4, 64);
+            if (c == 0 && m < g.M) g.row_dot[(long)(tn * 4 + wn) * g.M + m] = rowp;
+          }
+          if (SWB) continue;
+          if (m < g.M && col_ok) {
+            if (EPI == 4) {
+              // dx = rstd * (w o dh) - x * (rstd^2 * s / N) + add, fp32, one rounding (dh as the unfused path sees it: rounded to bf16)
+              float dh[8], xv[8], av[8], wv[8], o8[8];
+              unpack8(val, dh); unpack8(pre_a[i], xv); unpack8(pre_b[i], av);
+              unpack8(*reinterpret_cast<const uint4*>(g.bias + n), wv);
+              const float r = g.sa[m], coef = r * r * g.sb[m] / (float)g.N;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o8[e] = r * (wv[e] * dh[e]) - xv[e] * coef + av[e];
+              *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n) = pack8(o8);
               continue;
             }
             if (EPI == 0 && g.res) {
@@ -1374,9 +1401,13 @@ static void launch_256s(GemmArgs& g, hipStream_t s) {
   const long T = (long)g.tilesM * g.tilesN, P = num_cus();
   const int nk = (g.K + g.K2) / 64;
   bool sk = false;
-  (void)rounds_256(T, nk, g.K2 / 64, g.drop_thresh != 0, &sk);
+  if (EPI < 4) (void)rounds_256(T, nk, g.K2 / 64, g.drop_thresh != 0, &sk);
   g.ntiles = (int)T; g.sk_tile0 = 0; g.sk_tiles = 0; g.sk_units = 0; g.sk_ws = nullptr; g.sk_flags = nullptr;
   if (sk) g.ntiles = (int)(T / P * P);
+  if constexpr (EPI >= 4) {   // the RMSNorm-backward epilogues: whole rounds, no second operand pair (their launchers guarantee both)
+    hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT, EPI, false, false>), grid_256s(g.ntiles), dim3(1024), 0, s, g);
+    return;
+  }
   if (g.ntiles > 0) {
     const dim3 grid = grid_256s(g.ntiles);
     if (g.K2 > 0) hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT, EPI, true, false>), grid, dim3(1024), 0, s, g);
@@ -1750,6 +1781,100 @@ extern "C" int lhrs_gemm_swiglu_bwd(const void* dY, int ldy, const void* WdT, in
   else LAUNCH_256(0, 2, grid_256s((long)g.tilesM * g.tilesN), s, g);
   prof_end(pslot, s);
   LHRS_CHECK_LAUNCH("gemm_swiglu_bwd");
+  return 0;
+}
+
+// ---- RMSNorm backward without its own pass over HBM (round 4) ------------------------------------------------------------------------
+// HF LlamaRMSNorm in front of the MLP: h = w o (x * rstd), gate|up = h W_gu^T.  Its backward needs c = sum_j dh_j w_j x_j over the WHOLE row
+// of dh = d(gate|up) W_gu - a full-row reduction that a tiled GEMM epilogue does not have.  But c = (1 / rstd) <d(gate|up), gate|up> (write
+// h_j = w_j x_j rstd and pull W_gu through the sum), and both factors sit in the SwiGLU-backward epilogue one launch earlier:
+//   lhrs_gemm_swiglu_bwd_rowdot : the fused d-down + SwiGLU' launch, which also writes the 4 * ff/256 per-wave-column partial sums per row
+//   lhrs_rowsum_partials        : s[m] = sum of the partials (fixed order: deterministic)
+//   lhrs_gemm_rmsnorm_bwd       : dx = rstd * (w o (dgu W_gu)) - x * (rstd^2 s / d) + add in the epilogue of the dX GEMM
+// instead of GEMM -> [dh to HBM] -> rmsnorm_bwd (4 row passes, 43 us at M = 8190).  Only where both products are whole rounds of the 256-row
+// persistent kernel (lhrs_gemm_rmsnorm_bwd_fusable); everywhere else the callers keep the three-launch sequence.
+// MEASURED (round 4, micro-batch 30, rocprofv3): the SwiGLU' launch grows 642 -> 678 us with the row dot, the d-gate|up launch 1118 -> 1133 us with
+// the norm epilogue, + the partial sum: +51 us of EXPOSED epilogue per layer for the 43 us rmsnorm_bwd pass it removes - the step is 0.4 ms
+// SLOWER (2.3 ms with the first, latency-bound version of the partial-sum kernel).  In this persistent kernel every wave runs the epilogue at
+// the same time, nothing overlaps it, and it moves bytes less efficiently than a dedicated bandwidth kernel at 6.2 TB/s.  The callers therefore
+// use it only on request (LHRS_FUSE_NORM_BWD=1); correct and tested (test_rmsnorm_backward_inside_the_dx_gemm_*).
+namespace {
+__global__ __launch_bounds__(512) void rowsum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int P, int M) {
+  // block = 64 rows x 8 slices of the partial index: slice y adds partials y, y + 8, ... (coalesced over the rows), then slice 0 adds the eight slice
+  // sums in slice order - a fixed summation order (deterministic), 8 loads in flight per row instead of a chain of P dependent ones
+  __shared__ float red[8][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int m = blockIdx.x * 64 + tx;
+  float acc = 0.f;
+  if (m < M)
+    for (int p = ty; p < P; p += 8) acc += part[(long)p * M + m];
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && m < M) {
+    float t = red[0][tx];
+#pragma unroll
+    for (int y = 1; y < 8; ++y) t += red[y][tx];
+    out[m] = t;
+  }
+}
+}  // namespace
+extern "C" int lhrs_gemm_rmsnorm_bwd_fusable(int M, int d, int ff) {
+  const long P = num_cus();
+  if (g_gemm_allow_256 != 2 || !g_gemm_persist || d % 256 != 0 || ff % 256 != 0) return 0;
+  const long t_down = (long)cdiv(M, 256) * (ff / 256), t_gu = (long)cdiv(M, 256) * (d / 256);
+  if (!swiglu_fusable(t_down, ff, d, 0, d, d) || pick_144(M, ff / 256, d, 0, false)) return 0;                 // d-down + SwiGLU': one fused 256-row launch
+  if (t_gu < g_gemm_min256 || t_gu % P != 0 || pick_144(M, d / 256, 2 * ff, 0, false)) return 0;               // d-gate|up: whole rounds of the 256-row kernel
+  return 1;
+}
+extern "C" int lhrs_gemm_swiglu_bwd_rowdot(const void* dY, int ldy, const void* WdT, int ldw, const void* gu, void* dgu, int ld_gu, float* row_dot,
+                                           int M, int ff, int K, void* stream) {
+  LHRS_REQUIRE(M > 0 && ff > 0 && K > 0 && ff % 256 == 0 && ld_gu >= 2 * ff && ld_gu % 8 == 0 && row_dot != nullptr, "gemm_swiglu_bwd_rowdot: M=%d ff=%d K=%d", M, ff, K);
+  LHRS_REQUIRE(swiglu_fusable((long)cdiv(M, 256) * (ff / 256), ff, K, 0, ldy, ldw) && !pick_144(M, ff / 256, K, 0, false),
+               "gemm_swiglu_bwd_rowdot: not a single fused 256-row launch for M=%d ff=%d K=%d (ask lhrs_gemm_rmsnorm_bwd_fusable first)", M, ff, K);
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  g.A = (const bf16_t*)dY; g.B = (const bf16_t*)WdT; g.C = dgu; g.M = M; g.N = ff; g.K = K; g.lda = ldy; g.ldb = ldw; g.ldc = ld_gu;
+  g.alpha = 1.f; g.epi = 5; g.ff = ff; g.aux = (const bf16_t*)gu; g.ld_aux = ld_gu; g.row_dot = row_dot; g.drop_scale = 1.f;
+  g.tilesM = cdiv(M, 256); g.tilesN = ff / 256;
+  hipStream_t s = (hipStream_t)stream;
+  const int pslot = prof_count(M, ff, K, 2, s);
+  LAUNCH_256(0, 5, 0, s, g);
+  prof_end(pslot, s);
+  LHRS_CHECK_LAUNCH("gemm_swiglu_bwd_rowdot");
+  return 0;
+}
+// s[m] = sum_{p < P} part[p * M + m]
+extern "C" int lhrs_rowsum_partials(const float* part, float* out, int P, int M, void* stream) {
+  LHRS_REQUIRE(part && out && P > 0 && M > 0, "rowsum_partials: P=%d M=%d", P, M);
+  hipLaunchKernelGGL(rowsum_partials_kernel, dim3(cdiv(M, 64)), dim3(512), 0, (hipStream_t)stream, part, out, P, M);
+  LHRS_CHECK_LAUNCH("rowsum_partials");
+  return 0;
+}
+// out[M, N] = rstd o (w o (dY . WT^T)) - x o (rstd^2 s / N) + add;  dY [M, K], WT [N, K] (the transposed weight copy), x / add / out [M, N]
+extern "C" int lhrs_gemm_rmsnorm_bwd(const void* dY, int ldy, const void* WT, int ldw, const void* x, int ldx, const void* w, const float* rstd,
+                                     const float* s_row, const void* add, int ld_add, void* out, int ldo, int M, int N, int K, void* stream) {
+  LHRS_REQUIRE(M > 0 && N > 0 && K >= 128 && K % 64 == 0 && N % 256 == 0 && ldy % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 &&
+               (add == nullptr || ld_add % 8 == 0) && x && w && rstd && s_row, "gemm_rmsnorm_bwd: M=%d N=%d K=%d", M, N, K);
+  const long T = (long)cdiv(M, 256) * (N / 256);
+  LHRS_REQUIRE(g_gemm_allow_256 == 2 && g_gemm_persist && T >= g_gemm_min256 && T % num_cus() == 0 && !pick_144(M, N / 256, K, 0, false),
+               "gemm_rmsnorm_bwd: M=%d N=%d is not whole rounds of the 256-row kernel (ask lhrs_gemm_rmsnorm_bwd_fusable first)", M, N);
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  g.A = (const bf16_t*)dY; g.B = (const bf16_t*)WT; g.C = out; g.M = M; g.N = N; g.K = K; g.lda = ldy; g.ldb = ldw; g.ldc = ldo;
+  g.alpha = 1.f; g.epi = 4; g.aux = (const bf16_t*)x; g.ld_aux = ldx; g.res = (const bf16_t*)add; g.ldr = ld_add; g.bias = (const bf16_t*)w;
+  g.sa = rstd; g.sb = s_row; g.drop_scale = 1.f;
+  g.tilesM = cdiv(M, 256); g.tilesN = N / 256;
+  hipStream_t s = (hipStream_t)stream;
+  int slot = -1;
+  if (g_prof.on) {
+    g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * K;
+    if (g_prof.used < g_prof.cap && g_prof.take(0)) {   // counted with the plain launches of the 256-row kernel: it is that kernel with a heavier epilogue
+      slot = g_prof.used++;
+      g_prof.flops[slot] = 2.0 * M * N * K; g_prof.kind[slot] = 0;
+      (void)hipEventRecord(g_prof.ev[2 * slot], s);
+    }
+  }
+  LAUNCH_256(0, 4, 0, s, g);
+  if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], s);
+  LHRS_CHECK_LAUNCH("gemm_rmsnorm_bwd");
   return 0;
 }
 

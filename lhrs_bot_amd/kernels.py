@@ -138,6 +138,33 @@ def gemm_swiglu_bwd(dy, w_down_t, gu, ff, a2=None, b2=None, out=None):
     return dgu
 
 
+def mlp_norm_bwd_fusable(M: int, d: int, ff: int) -> bool:
+    """True when the RMSNorm backward in front of the MLP is to ride in the epilogue of the d-gate|up GEMM: the library can
+    (lhrs_gemm_rmsnorm_bwd_fusable) AND LHRS_FUSE_NORM_BWD=1 asks for it - it is OFF by default: measured 0.4 ms per step SLOWER than the
+    rmsnorm_bwd pass it removes (the epilogue of the persistent GEMM is exposed time; csrc/gemm.hip)."""
+    import os
+    return os.environ.get("LHRS_FUSE_NORM_BWD", "0") == "1" and bool(_L().lhrs_gemm_rmsnorm_bwd_fusable(int(M), int(d), int(ff)))
+
+
+def mlp_backward_fused(dy, w_down_t, gu, w_gu_t, x_mid, ln_w, rstd, ff, add=None):
+    """The MLP half of a frozen decoder layer's backward with the RMSNorm backward inside the dX GEMM (no rmsnorm_bwd pass):
+    dgu (over gu) = swiglu'(gu) * (dy @ w_down_t^T) + per-row partial sums of <dgu, gu>; s = their sum; returns
+    rstd * (ln_w o (dgu @ w_gu_t^T)) - x_mid * (rstd^2 s / d) + add   [M, d].  Requires mlp_norm_bwd_fusable(M, d, ff)."""
+    M, d = dy.shape
+    L = _L()
+    P = 4 * (ff // 256)
+    part = torch.empty((P, M), device=dy.device, dtype=torch.float32)
+    s_row = torch.empty(M, device=dy.device, dtype=torch.float32)
+    _lib.check(L.lhrs_gemm_swiglu_bwd_rowdot(dy.data_ptr(), dy.stride(0), w_down_t.data_ptr(), w_down_t.stride(0), gu.data_ptr(), gu.data_ptr(),
+                                             gu.stride(0), part.data_ptr(), M, ff, d, _stream()), "gemm_swiglu_bwd_rowdot")
+    _lib.check(L.lhrs_rowsum_partials(part.data_ptr(), s_row.data_ptr(), P, M, _stream()), "rowsum_partials")
+    out = torch.empty((M, d), device=dy.device, dtype=torch.bfloat16)
+    _lib.check(L.lhrs_gemm_rmsnorm_bwd(gu.data_ptr(), gu.stride(0), w_gu_t.data_ptr(), w_gu_t.stride(0), x_mid.data_ptr(), x_mid.stride(0),
+                                       ln_w.data_ptr(), rstd.data_ptr(), s_row.data_ptr(), _p(add), add.stride(0) if add is not None else 0,
+                                       out.data_ptr(), out.stride(0), M, d, 2 * ff, _stream()), "gemm_rmsnorm_bwd")
+    return out
+
+
 def gemm_fp8_nt(a8, sa, b8, sb, out=None, *, residual=None, alpha=1.0, a2=None, b2=None):
     """out[M, N] bf16 = alpha * (sa[:, None] * sb[None, :] * (a8 @ b8^T) + a2 @ b2^T) (+ residual); a8 [M, K], b8 [N, K] uint8 e4m3 with
     per-row fp32 scales; the optional bf16 pair a2 [M, K2], b2 [N, K2] (LoRA update) is accumulated by the same launch."""
@@ -422,15 +449,16 @@ def llama_layer_forward(x, L, cos_t, sin_t, desc, B, S, LT, heads, ff, eps, h_sc
     o = torch.empty((M, d), device=dev, dtype=bf)
     lse = torch.empty((B, heads, LT), device=dev, dtype=torch.float32)
     x_mid = torch.empty((M, d), device=dev, dtype=bf)
+    rstd2 = torch.empty(M, device=dev, dtype=torch.float32)
     gu = torch.empty((M, 2 * ff), device=dev, dtype=bf)
     act = torch.empty((M, ff), device=dev, dtype=bf)
     x_out = torch.empty((M, d), device=dev, dtype=bf)
     st = _L().lhrs_llama_layer_forward(x.data_ptr(), L["ln1_w"].data_ptr(), L["qkv_w"].data_ptr(), L["o_w"].data_ptr(), L["ln2_w"].data_ptr(),
                                        L["gu_w"].data_ptr(), L["down_w"].data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), desc.data_ptr(), B, S, LT, d,
                                        heads, ff, float(eps), h_scratch.data_ptr(), qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), x_mid.data_ptr(),
-                                       gu.data_ptr(), act.data_ptr(), x_out.data_ptr(), _stream())
+                                       rstd2.data_ptr(), gu.data_ptr(), act.data_ptr(), x_out.data_ptr(), _stream())
     _lib.check(st, "llama_layer_forward")
-    return x_out, dict(x_in=x, qkv=qkv, o=o, o_full=o, lse=lse, x_mid=x_mid, gu=gu)
+    return x_out, dict(x_in=x, qkv=qkv, o=o, o_full=o, lse=lse, x_mid=x_mid, gu=gu, rstd2=rstd2)
 
 
 def vit_layer_forward(x, L, desc, B, n, LT, heads, ff, h, qkv, o, f):
@@ -453,11 +481,14 @@ def llama_layer_backward(dx_out, s, L, cos_t, sin_t, desc, B, S, LT, heads, ff, 
     dx_in = torch.empty((M, d), device=dev, dtype=bf)
     lib = _L()
     dact = None if lib.lhrs_gemm_swiglu_fusable(M, ff, d, d, 0) else torch.empty((M, ff), device=dev, dtype=bf)
+    fuse = s.get("rstd2") is not None and mlp_norm_bwd_fusable(M, d, ff)
+    part = torch.empty((4 * (ff // 256), M), device=dev, dtype=torch.float32) if fuse else None
+    srow = torch.empty(M, device=dev, dtype=torch.float32) if fuse else None
     st = lib.lhrs_llama_layer_backward(dx_out.data_ptr(), s["x_in"].data_ptr(), s["x_mid"].data_ptr(), s["qkv"].data_ptr(), s["o_full"].data_ptr(),
                                        s["lse"].data_ptr(), s["gu"].data_ptr(), L["ln1_w"].data_ptr(), L["ln2_w"].data_ptr(), L["qkv_wT"].data_ptr(),
                                        L["o_wT"].data_ptr(), L["gu_wT"].data_ptr(), L["down_wT"].data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(),
                                        desc.data_ptr(), B, S, LT, d, heads, ff, float(eps), dh.data_ptr(), d_o.data_ptr(), dqkv.data_ptr(),
-                                       delta.data_ptr(), _p(dact), dx_in.data_ptr(), _stream())
+                                       delta.data_ptr(), _p(dact), dx_in.data_ptr(), _p(s.get("rstd2")) if fuse else None, _p(part), _p(srow), _stream())
     _lib.check(st, "llama_layer_backward")
     return dx_in, dh          # (d loss / d x, d loss / d x_mid)
 

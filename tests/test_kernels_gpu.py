@@ -804,3 +804,42 @@ def test_copy_2d_kernel_and_runtime_fallback():
         want = torch.full((40, 8192), 7, dtype=torch.uint8, device=DEV)
         want[2:2 + h, 64:64 + w] = src[r0:r0 + h, c0:c0 + w]
         assert torch.equal(dst, want), (r0, c0, h, w)
+
+
+@pytest.mark.parametrize("M", [8190, 4095])
+def test_rmsnorm_backward_inside_the_dx_gemm_matches_the_three_launch_sequence(M):
+    """The MLP half of the decoder backward with the RMSNorm backward folded into the d-gate|up GEMM's epilogue (row dot <d(gate|up), gate|up> from
+    the SwiGLU-backward epilogue, lhrs_rowsum_partials, lhrs_gemm_rmsnorm_bwd) against lhrs_gemm_swiglu_bwd -> lhrs_gemm_bf16_nt -> lhrs_rmsnorm_bwd on
+    a CONSISTENT forward state (gate|up really is RMSNorm(x) W_gu^T: the identity c = <dgu, gu> / rstd needs that), and against fp32 torch."""
+    g = torch.Generator().manual_seed(M)
+    d, ff, eps = 4096, 11008, 1e-5
+    from lhrs_bot_amd import _lib
+    assert _lib.load().lhrs_gemm_rmsnorm_bwd_fusable(M, d, ff) == 1          # (the Python-level switch is off by default: measured slower)
+    x = torch.randn(M, d, generator=g).to(DEV, torch.bfloat16)
+    w = (1.0 + 0.1 * torch.randn(d, generator=g)).to(DEV, torch.bfloat16)
+    wgu = (torch.randn(2 * ff, d, generator=g) * 0.02).to(DEV, torch.bfloat16)
+    wdT = (torch.randn(ff, d, generator=g) * 0.02).to(DEV, torch.bfloat16)       # transposed down weight: [ff, d]
+    dy = (torch.randn(M, d, generator=g) * 0.05).to(DEV, torch.bfloat16)
+    add = (torch.randn(M, d, generator=g) * 0.05).to(DEV, torch.bfloat16)
+    h, rstd = hk.rmsnorm_fwd(x, w, eps, save_rstd=True)
+    gu, _ = hk.gemm_swiglu_fwd(h, wgu, ff)
+    wguT = hk.transpose(wgu)
+    # three-launch sequence
+    dgu_ref = hk.gemm_swiglu_bwd(dy, wdT, gu.clone(), ff)
+    dh = hk.gemm_nt(dgu_ref, wguT)
+    ref = hk.rmsnorm_bwd(dh, x, w, None, add=add, eps=eps)
+    # fused
+    gu2 = gu.clone()
+    got = hk.mlp_backward_fused(dy, wdT, gu2, wguT, x, w, rstd, ff, add=add)
+    torch.cuda.synchronize()
+    # d(gate|up): the same arithmetic in another instantiation of the kernel (the compiler contracts the fp32 expression differently when the
+    # row dot also reads dg / du): a bf16 ulp on a few elements
+    assert rel_err(gu2, dgu_ref) < 5e-4, rel_err(gu2, dgu_ref)
+    assert rel_err(got, ref) < 4e-3, rel_err(got, ref)
+    # fp32 reference of the same function from the bf16 inputs
+    xf, wf = x.float(), w.float()
+    r = torch.rsqrt((xf * xf).mean(dim=1, keepdim=True) + eps)
+    dhf = dgu_ref.float() @ wgu.float()
+    gw = dhf * wf
+    want = r * gw - xf * (r ** 3) * (gw * xf).sum(dim=1, keepdim=True) / d + add.float()
+    assert rel_err(got, want) < 6e-3 and rel_err(ref, want) < 6e-3, (rel_err(got, want), rel_err(ref, want))
