@@ -199,10 +199,27 @@ def timed_run(engine, batch, steps, warmup, world, lib, on_timed_start=None):
     import ctypes
     from lhrs_bot_amd import _lib
 
+    check = os.environ.get("LHRS_BENCH_CHECK_FINITE") == "1"   # debugging aid: synchronising finite checks after every phase of the step
+    nstep = [0]
+
+    def finite(what, *ts):
+        for t in ts:
+            if not bool(torch.isfinite(t).all()):
+                raise SystemExit(f"rank {os.environ.get('RANK', '0')}: non-finite {what} at step {nstep[0]} ({int((~torch.isfinite(t)).sum())} of {t.numel()})")
+
     def step():
         out = engine(batch)
+        if check:
+            finite("loss", out["total_loss"])
         engine.backward(out["total_loss"])
+        if check:
+            for r in getattr(engine, "reducers", {}).values():
+                r.finish()
+            finite("reduced gradient", *[st.grad for st in engine.stores])
         engine.step()
+        if check:
+            finite("master after the update", *[st.master for st in engine.stores])
+            nstep[0] += 1
         return out["total_loss"]
 
     loss = None
@@ -425,6 +442,11 @@ def main():
         n_ck = sums.numel()
         same = bool((allv[:, :n_ck] == allv[0:1, :n_ck]).all())
         if not same:
+            diag = {"loss": final_loss, "gnorm_sq": float(engine.gnorm_sq)}
+            for st in engine.stores:
+                diag[st.name] = {"master_nonfinite": int((~torch.isfinite(st.master)).sum()), "grad_nonfinite": int((~torch.isfinite(st.grad)).sum()),
+                                 **{k: int((~torch.isfinite(v)).sum()) for k, v in engine.state[st.name].items()}}
+            print(f"rank {rank} diagnostics: {diag}", file=sys.stderr, flush=True)
             raise SystemExit(f"rank {rank}: trainable masters differ across the {world} ranks after {a.steps} steps: checksums {allv[:, :n_ck].tolist()}")
         dp = {"rccl_ranks": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
               "reduce_mode": next(iter(engine.reducers.values())).mode if engine.reducers else None,

@@ -276,6 +276,9 @@ int lhrs_pooler_query_grad(const void* dt0, const void* dkv, float* dquery, int 
                            int ni1, int ni2, int dim, int accumulate, void* stream);
 int lhrs_copy_2d(void* dst, long dst_pitch_bytes, const void* src, long src_pitch_bytes, long width_bytes, long height,
                  void* stream);
+/* test aid (no reference counterpart): fills the LDS of every CU with `pattern`, so that a kernel which reads LDS it never wrote shows up
+ * as a changed result (tools/poison_check.py, tests/test_kernels_gpu.py).  0xFFFFFFFF is a NaN as fp32 and as two bf16. */
+int lhrs_debug_poison_lds(unsigned pattern, void* stream);
 
 /* ---- token side ------------------------------------------------------------------------------------- *
  * splice: TextModal.prepare_inputs_for_multimodal (lhrs/models/text_modal.py:296-526); bit-exact.

@@ -72,8 +72,33 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
+    if os.environ.get("LHRS_DEBUG_POISON_LDS") == "1":  # test aid: see lhrs_debug_poison_lds in include/lhrs_hip.h
+        lib = _PoisonProxy(lib)
     _lib = lib
     return lib
+
+
+class _PoisonProxy:
+    """LHRS_DEBUG_POISON_LDS=1: every entry point that takes a stream is preceded by a launch that fills all LDS with NaN bit patterns on
+    that stream - an operator that reads LDS it did not write then returns NaN instead of silently using a previous kernel's leftovers."""
+
+    def __init__(self, lib):
+        self._lib, self._wrapped = lib, {}
+        self._streamed = {n for n, (_, a) in parse_header().items() if a and a[-1] is ctypes.c_void_p and n != "lhrs_debug_poison_lds"}
+        self._pattern = int(os.environ.get("LHRS_DEBUG_POISON_PATTERN", "0xFFFFFFFF"), 0)
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name not in self._streamed:
+            return fn
+        if name not in self._wrapped:
+            poison, pattern = self._lib.lhrs_debug_poison_lds, self._pattern
+
+            def call(*args, _fn=fn):
+                poison(pattern, args[-1])
+                return _fn(*args)
+            self._wrapped[name] = call
+        return self._wrapped[name]
 
 
 def check(status: int, what: str) -> None:

@@ -97,3 +97,32 @@ extern "C" int lhrs_copy_2d(void* dst, long dst_pitch_bytes, const void* src, lo
   if (e != hipSuccess) LHRS_FAIL("copy_2d: %s", hipGetErrorString(e));
   return 0;
 }
+
+// ---- test aid: fill every CU's LDS with a bit pattern ---------------------------------------------------------------------------------
+// LDS is not cleared between kernels: a kernel that reads LDS it never wrote (a padded tail row, a skipped DMA) sees what the PREVIOUS kernel
+// on that CU left there - finite leftovers of our own launches on a warm box, anything at all on a fresh one.  One 160 KiB workgroup per CU
+// (nothing else fits beside it), several waves deep so that every CU is visited; tests/ and tools/poison_check.py launch it before an operator
+// and demand the same result as without it.
+namespace {
+__global__ void __launch_bounds__(256) poison_lds_kernel(unsigned pattern, int words, unsigned* sink) {
+  extern __shared__ unsigned lds_words[];
+  for (int i = threadIdx.x; i < words; i += 256) lds_words[i] = pattern;
+  __syncthreads();
+  if (sink != nullptr && lds_words[(threadIdx.x * 97) % words] != pattern) sink[0] = 1;  // keeps the stores alive
+}
+}  // namespace
+extern "C" int lhrs_debug_poison_lds(unsigned pattern, void* stream) {
+  constexpr int kBytes = 160 * 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBytes);
+    if (e != hipSuccess) LHRS_FAIL("debug_poison_lds: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  int dev = 0, cus = 256;
+  hipGetDevice(&dev);
+  hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  hipLaunchKernelGGL(poison_lds_kernel, dim3((unsigned)(4 * cus)), dim3(256), kBytes, (hipStream_t)stream, pattern, kBytes / 4, (unsigned*)nullptr);
+  LHRS_CHECK_LAUNCH("debug_poison_lds");
+  return 0;
+}
