@@ -248,7 +248,7 @@ def timed_run(engine, batch, steps, warmup, world, lib, on_timed_start=None):
     dt = time.perf_counter() - t0
     prof = (ctypes.c_double * 5)()
     _lib.check(lib.lhrs_gemm_profile_read(ctypes.addressof(prof)), "gemm_profile_read")
-    kinds = (ctypes.c_double * 15)()
+    kinds = (ctypes.c_double * 18)()
     _lib.check(lib.lhrs_gemm_profile_read_kinds(ctypes.addressof(kinds)), "gemm_profile_read_kinds")
     lib.lhrs_gemm_profile_enable(0)
     blocked = 0.0
@@ -267,6 +267,9 @@ PROFILE_STRIDE = int(os.environ.get("LHRS_GEMM_PROFILE_STRIDE", "7"))
 GEMM_KERNEL_DESC = ("gemm_nt_256s_kernel<ACT, 0, K2P, false> (256x256 tile, 16 waves): BK=64 double-buffered LDS stages via global_load_lds DMA, "
                     "v_mfma_f32_16x16x32_bf16, persistent over tiles; its launches with a fused SwiGLU / RoPE epilogue and the plain launches of the 144-row "
                     "kernel (ViT / projector products) are timed separately under `variants`")
+GEMM_VENDOR_DESC = ("hipBLASLt Custom_Cijk_Alik_Bljk_BBS_BH_..._SK3_UserArgs_MT256x256x64_MI16x16x1 (vendor assembly: 256x256x64 tile, 4 waves of 128x128, stream-K over "
+                    "256 persistent workgroups) on the PLAIN long-k products (down / o projections, the dX products, lm_head: csrc/vendor.cpp, LHRS_GEMM_VENDOR=0 turns "
+                    "it off); every product with a fused epilogue runs the hand-written gemm_nt_256s_kernel, timed separately under `variants`")
 GEMM_144_DESC = ("gemm_nt_144s_kernel<ACT, 0> (144x256 tile, 12 waves, three 50 KiB LDS stages): the plain-epilogue kernel that carries the most time at this "
                  "micro-batch; the 256-row kernel's variants are listed under `variants`")
 
@@ -275,10 +278,11 @@ def roofline_block(prof, kinds, steps, B, S, scale_layers, sclk=None, watts=None
     """`achieved` is ONE kernel's figure: the plain-epilogue 256x256 persistent kernel (kind 0, `gemm_nt_256s_kernel<ACT, 0, K2P, false>` in a rocprofv3
     kernel trace) - or, when that kernel carries less time than the plain 144-row kernel (kind 4: micro-batch 8), that one - so that its
     `avg_launch_us` can be held against the kernel's average duration in profiles/*_kernel_stats.csv; the other kinds are listed under `variants`."""
-    dom = 0 if kinds[1] >= kinds[13] else 4
+    dom = max((0, 4, 5), key=lambda k: kinds[3 * k + 1])   # among the PLAIN-epilogue kernels: the one that carries the most (sampled) time
     n_samp, ms, fl = kinds[3 * dom], kinds[3 * dom + 1], kinds[3 * dom + 2]
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    vnames = ("<ACT,0> plain, 256-row tiles", "<0,1> SwiGLU-fwd epilogue", "<0,2> SwiGLU-bwd epilogue", "<0,3> RoPE epilogue", "<ACT,0> plain, 144-row tiles (gemm_nt_144s_kernel)")
+    vnames = ("<ACT,0> plain, 256-row tiles", "<0,1> SwiGLU-fwd epilogue", "<0,2> SwiGLU-bwd epilogue", "<0,3> RoPE epilogue", "<ACT,0> plain, 144-row tiles (gemm_nt_144s_kernel)",
+              "plain long-k products in the vendor library (hipBLASLt assembly kernel, 256x256x64 tile)")
     variants = {}
     for k, nm in enumerate(vnames):
         n_k, ms_k, fl_k = kinds[3 * k], kinds[3 * k + 1], kinds[3 * k + 2]
@@ -286,14 +290,16 @@ def roofline_block(prof, kinds, steps, B, S, scale_layers, sclk=None, watts=None
             tf = fl_k / (ms_k * 1e-3) / 1e12
             variants[nm] = {"launches": int(n_k), "avg_launch_us": round(1e3 * ms_k / n_k, 2), "achieved_tflops": round(tf, 1),
                             "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
-    all_ms = sum(kinds[3 * k + 1] for k in range(5))
-    all_fl = sum(kinds[3 * k + 2] for k in range(5))
+    all_ms = sum(kinds[3 * k + 1] for k in range(6))
+    all_fl = sum(kinds[3 * k + 2] for k in range(6))
+    hand_ms = sum(kinds[3 * k + 1] for k in range(5))
+    hand_fl = sum(kinds[3 * k + 2] for k in range(5))
     # HBM-side bytes per launch of the dominant kernel: a PMC pass cannot run inside this process (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE are
     # separate profiled runs of this same command); the committed summary of that pass on this tree is quoted, with its provenance
     traffic, traffic_note = None, "not measured in this run (PMC passes are separate rocprofv3 runs)"
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r04_gemm_traffic.json")))
-        if B == 30 and scale_layers == 1.0:
+        if B == 30 and scale_layers == 1.0 and dom == 0:
             traffic = int(tj["traffic_bytes_per_launch"])
             traffic_note = ("bytes per launch of the dominant kernel from profiles/r04_gemm_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate "
                             "passes of `bench.py --steps 1 --warmup 1` at micro-batch 30 on this tree), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 and "
@@ -301,10 +307,12 @@ def roofline_block(prof, kinds, steps, B, S, scale_layers, sclk=None, watts=None
                             "every XCD streams its own copy of the operand panels); NOT measured in this process")
     except Exception:  # noqa: BLE001
         pass
-    return {"bound": "mfma", "kernel": GEMM_KERNEL_DESC if dom == 0 else GEMM_144_DESC, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+    return {"bound": "mfma", "kernel": {0: GEMM_KERNEL_DESC, 4: GEMM_144_DESC, 5: GEMM_VENDOR_DESC}[dom], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "traffic_note": traffic_note,
             "variants": variants, "all_variants_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else None,
+            "hand_written_kernels_tflops": round(hand_fl / (hand_ms * 1e-3) / 1e12, 1) if hand_ms > 0 else None,
+            "hand_written_share_of_gemm_time": round(hand_ms / all_ms, 3) if all_ms > 0 else None,
             "launches_timed": int(n_samp), "timed_every_nth_launch": PROFILE_STRIDE, "avg_launch_us": round(1e3 * ms / max(n_samp, 1), 2),
             "sclk_mhz_during_timed_region": round(sclk) if sclk else None, "package_power_w": round(watts) if watts else None,
             "frac_of_peak_at_measured_clock": round(ach / (PEAK_BF16_TFLOPS * sclk / 2400.0), 4) if sclk else None,
@@ -478,7 +486,8 @@ def main():
                        "lora": None if a.stage == 1 else ("r=8 on q,k,v,o, lora_dropout 0" if a.stage == 3 else "r=128 on all 7 linears, lora_dropout 0.05 (train mode)"),
                        "last_layer_rows": "supervised positions only (same loss and gradients; LHRS_TAIL_ROWS_ONLY=0 computes all)" if os.environ.get("LHRS_TAIL_ROWS_ONLY", "1") != "0" else "all",
                        "grad_allreduce": a.comm_dtype if world > 1 else "none",
-                       "dist_backend": (torch.distributed.get_backend() if world > 1 else None), "data_parallel": dp},
+                       "dist_backend": (torch.distributed.get_backend() if world > 1 else None), "data_parallel": dp,
+                       "plain_long_k_products": ((lib.lhrs_gemm_vendor_status() or b"").decode() or "hand-written kernels (vendor library off)")},
             "loss": round(final_loss, 4),
             "step_mfma_frac": round(sps / world * f_alg(S) / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 and a.stage == 1 else None,
             "step_mfma_frac_executed": round(sps / world * f_exec / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 and a.stage == 1 else None,

@@ -183,13 +183,24 @@ int lhrs_gemm_set_small_thresh(int n);
 int lhrs_gemm_set_min_tiles(int n);
 /* live HIP-event timing of the 16-wave 256x256 GEMM launches, on their launch stream, for bench.py's roofline leg (gemm.hip):
  * enable(n) arms n event pairs (0 = off); read() -> {launches of the plain-epilogue persistent kernels (256-row + 144-row tiles), their ms, their
- * flops, all GEMM launches, all GEMM flops}; read_kinds() -> [5][3] = {launches, ms, flops} per kind: 0 plain <ACT,0> of the 256x256 kernel (the
- * dominant kernel), 1 SwiGLU fwd, 2 SwiGLU bwd, 3 RoPE epilogue of the same kernel, 4 the plain 144-row kernel */
+ * flops, all GEMM launches, all GEMM flops}; read_kinds() -> [6][3] = {launches, ms, flops} per kind: 0 plain <ACT,0> of the 256x256 kernel,
+ * 1 SwiGLU fwd, 2 SwiGLU bwd, 3 RoPE epilogue of the same kernel, 4 the plain 144-row kernel, 5 plain products handed to the vendor library */
 int lhrs_gemm_profile_enable(int max_samples);
 /* bracket only every n-th launch of each epilogue variant (default 1): the event records themselves cost stream time (1-2 % of a step) */
 int lhrs_gemm_profile_stride(int n);
 int lhrs_gemm_profile_read(double* out5_host);
-int lhrs_gemm_profile_read_kinds(double* out15_host);
+int lhrs_gemm_profile_read_kinds(double* out18_host);
+/* plain long-k products (no bias, no activation, bf16 out, alpha 1, K >= min_k, M and N >= 1024) are offered to the vendor library first
+ * (hipBLASLt, looked up in the process at run time - csrc/vendor.cpp; same-box A/B +7 % on the stage-1 step); everything with a fused epilogue
+ * stays on the hand-written kernels.  set_vendor(0, 0) keeps every product on them (env LHRS_GEMM_VENDOR=0); vendor_takes() = 1 when
+ * lhrs_gemm_bf16_nt will offer that problem; vendor_status() names the library copy in use, or why none is ("" before the first offer);
+ * lhrs_vendor_gemm_nt is the raw call: 0 launched, 1 not taken (no library / no algorithm), -1 error. */
+int lhrs_gemm_set_vendor(int on, int min_k);
+int lhrs_gemm_vendor_takes(int M, int N, int K, int lda, int ldb, int ldc, int ldr, int has_bias, int act, int out_f32, int accumulate,
+                           float alpha);
+const char* lhrs_gemm_vendor_status(void);
+int lhrs_vendor_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual,
+                        int ldr, void* workspace, long workspace_bytes, void* stream);
 
 /* ---- LoRA gradients (peft lora.Linear backward; lhrs/models/text_modal.py:133-151) ------------------------- *
  * C[KP,N] (+)= P[M,KP]^T . Q[M,N]: dA = (s dy B)^T x and dB^T = (s x A^T)^T dy straight from token-major operands.  */

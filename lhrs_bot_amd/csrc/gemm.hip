@@ -1242,7 +1242,7 @@ struct GemmProf {
   double total_flops_all = 0; // every GEMM launch while enabled (sampled or not)
   long launches_all = 0;
   int stride = 1;             // every stride-th launch of each epilogue variant is bracketed (lhrs_gemm_profile_stride)
-  long seen[5] = {0, 0, 0, 0, 0};
+  long seen[6] = {0, 0, 0, 0, 0, 0};  // 0 plain 256-row, 1 SwiGLU fwd, 2 SwiGLU bwd, 3 RoPE, 4 plain 144-row, 5 plain products handed to the vendor library
   bool take(int kind) { return (seen[kind]++ % stride) == 0; }
 } g_prof;
 }  // namespace
@@ -1261,7 +1261,7 @@ extern "C" int lhrs_gemm_profile_enable(int max_samples) {
   }
   g_prof.on = max_samples > 0; g_prof.cap = max_samples > 0 ? max_samples : 0; g_prof.used = 0;
   g_prof.total_flops_all = 0; g_prof.launches_all = 0;
-  for (int k = 0; k < 5; ++k) g_prof.seen[k] = 0;
+  for (int k = 0; k < 6; ++k) g_prof.seen[k] = 0;
   if (g_prof.on) {
     g_prof.ev = new hipEvent_t[2 * g_prof.cap];
     g_prof.flops = new double[g_prof.cap];
@@ -1287,11 +1287,12 @@ extern "C" int lhrs_gemm_profile_read(double* out) {
   return 0;
 }
 
-// out[5][3]: per kind k - 0 plain <ACT,0> of the 16-wave 256x256 kernel (THE dominant kernel), 1 SwiGLU fwd <0,1>, 2 SwiGLU bwd <0,2>, 3 RoPE <0,3> of
-// the same kernel, 4 the plain 144-row persistent kernel (gemm_nt_144s_kernel<ACT, 0>: ViT / projector products, micro-batch 8) -:
+// out[6][3]: per kind k - 0 plain <ACT,0> of the 16-wave 256x256 kernel (THE dominant kernel), 1 SwiGLU fwd <0,1>, 2 SwiGLU bwd <0,2>, 3 RoPE <0,3> of
+// the same kernel, 4 the plain 144-row persistent kernel (gemm_nt_144s_kernel<ACT, 0>: ViT / projector products, micro-batch 8),
+// 5 the plain long-k products handed to the vendor library (vendor.cpp) -:
 // sampled launches, their summed duration (ms), their summed flops
 extern "C" int lhrs_gemm_profile_read_kinds(double* out) {
-  for (int i = 0; i < 15; ++i) out[i] = 0;
+  for (int i = 0; i < 18; ++i) out[i] = 0;
   for (int i = 0; i < g_prof.used; ++i) {
     float t = 0;
     if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) LHRS_FAIL("gemm_profile_read_kinds: event sync failed");
@@ -1478,9 +1479,49 @@ extern "C" int lhrs_gemm_bf16_nt_dropmask(const void* A, int lda, const void* B,
   return rc;
 }
 
+// ---- the plain long-k products go to the vendor library (vendor.cpp says why): 1 = on (default), 0 = every product on the kernels of this file
+extern "C" int lhrs_vendor_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
+                                   void* workspace, long workspace_bytes, void* stream);
+static int g_vendor_on = -1, g_vendor_min_k = 4096;
+static int prof_count(int M, int N, int K, int kind, hipStream_t s);
+static void prof_end(int slot, hipStream_t s);
+extern "C" int lhrs_gemm_set_vendor(int on, int min_k) {
+  g_vendor_on = on ? 1 : 0;
+  if (min_k > 0) g_vendor_min_k = min_k;
+  return 0;
+}
+static bool vendor_on() {
+  if (g_vendor_on < 0) {
+    const char* e = getenv("LHRS_GEMM_VENDOR");
+    g_vendor_on = (e == nullptr || e[0] != '0') ? 1 : 0;
+    const char* k = getenv("LHRS_GEMM_VENDOR_MIN_K");
+    if (k != nullptr && atoi(k) > 0) g_vendor_min_k = atoi(k);
+  }
+  return g_vendor_on == 1;
+}
+// 1 when lhrs_gemm_bf16_nt offers this problem to the library first (a plain epilogue on a long k-loop, operands the library can address)
+extern "C" int lhrs_gemm_vendor_takes(int M, int N, int K, int lda, int ldb, int ldc, int ldr, int has_bias, int act, int out_f32, int accumulate, float alpha) {
+  return vendor_on() && !has_bias && act == 0 && !out_f32 && !accumulate && alpha == 1.f && K >= g_vendor_min_k && M >= 1024 && N >= 1024 &&
+         lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && ldr % 8 == 0;
+}
+
 extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N,
                                  int K, const void* bias, const void* residual, int ldr, int act, int out_f32,
                                  int accumulate, float alpha, void* stream) {
+  if (lhrs_gemm_vendor_takes(M, N, K, lda, ldb, ldc, residual ? ldr : 0, bias != nullptr, act, out_f32, accumulate, alpha) &&
+      ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0) && ((size_t)C % 16 == 0) && ((size_t)residual % 16 == 0)) {
+    int dev = 0;
+    void* ws = nullptr; long ws_bytes = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && g_sk[dev].slabs != nullptr) {   // the registered workspace (lhrs_gemm_set_streamk_workspace)
+      ws = g_sk[dev].slabs; ws_bytes = g_sk[dev].units * 256L * 256 * 4;
+    }
+    const int slot = prof_count(M, N, K, 5, (hipStream_t)stream);
+    const int st = lhrs_vendor_gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, residual, ldr, ws, ws_bytes, stream);
+    if (st == 0) { prof_end(slot, (hipStream_t)stream); return 0; }
+    if (st < 0) return st;
+    if (slot >= 0) { g_prof.used--; g_prof.seen[5]--; }   // not taken: the slot goes back (it was the last one handed out)
+    if (g_prof.on) { g_prof.launches_all--; g_prof.total_flops_all -= 2.0 * M * N * K; }
+  }
   return gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, out_f32, accumulate, alpha, nullptr, 0, nullptr, 0,
                      0, stream);
 }

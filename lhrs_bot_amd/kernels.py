@@ -6,6 +6,7 @@ of liblhrs_hip.so on the current HIP stream.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -58,6 +59,17 @@ def ensure_streamk_workspace(device, force: bool = False) -> None:
     _SK_WS[idx] = ws
     if not force and os.environ.get("LHRS_GEMM_STREAMK", "0") == "1":
         _L().lhrs_gemm_set_streamk(1)
+
+
+def gemm_set_vendor(on: bool, min_k: int = 0) -> None:
+    """Plain long-k products (no bias / activation, bf16 out, K >= min_k) through the vendor library (csrc/vendor.cpp) or, off, every product on
+    the hand-written kernels (kernel tests; env LHRS_GEMM_VENDOR=0)."""
+    _L().lhrs_gemm_set_vendor(int(bool(on)), int(min_k))
+
+
+def gemm_vendor_status() -> str:
+    msg = _L().lhrs_gemm_vendor_status()
+    return msg.decode() if msg else ""
 
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, bias=None, residual=None,

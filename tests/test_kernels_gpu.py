@@ -22,7 +22,48 @@ def bf(x):
     return x.to(torch.bfloat16)
 
 
+@pytest.fixture(autouse=True)
+def _hand_written_gemm_only(request):
+    """This file checks the kernels of csrc/*.hip: the plain long-k products stay on them here (the product default offers those to the vendor
+    library first, csrc/vendor.cpp); tests named *vendor* switch it on themselves."""
+    hk.gemm_set_vendor(False)
+    yield
+    hk.gemm_set_vendor(True)
+
+
 # ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K,res", [(8190, 4096, 11008, True), (8190, 4096, 22016, False), (2184, 4096, 12288, False), (8190, 4096, 4096, True),
+                                       (3822, 32000, 4096, False), (1024, 1024, 4096, False), (8190, 4104, 4096, True)])
+def test_gemm_plain_long_k_products_in_the_vendor_library(M, N, K, res):
+    """The products lhrs_gemm_bf16_nt hands to hipBLASLt (no bias / activation, bf16 out, K >= 4096, M, N >= 1024): against fp32 and against the
+    hand-written kernel on the same operands (both round an fp32 sum to bf16 once: they may differ by re-association only), strided output and
+    residual views included; then the problems it must NOT take."""
+    from lhrs_bot_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = bf(torch.randn(M, K, generator=g)).to(DEV)
+    b = bf(torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    r_full = bf(torch.randn(M, N + 8, generator=g)).to(DEV) if res else None
+    r = r_full[:, :N] if res else None
+    out_v = torch.zeros(M, N + 16, device=DEV, dtype=torch.bfloat16)
+    hk.gemm_set_vendor(True)
+    assert lib.lhrs_gemm_vendor_takes(M, N, K, K, K, N + 16, (N + 8) if res else 0, 0, 0, 0, 0, 1.0) == 1
+    hk.gemm_nt(a, b, out=out_v[:, :N], residual=r)
+    status = hk.gemm_vendor_status()
+    assert "libhipblaslt" in status and "lacks" not in status and not status.startswith("no "), status
+    assert float(out_v[:, N:].abs().max()) == 0.0                       # nothing written beside the view
+    hk.gemm_set_vendor(False)
+    out_h = hk.gemm_nt(a, b, residual=r)
+    ref = a.float() @ b.float().t() + (r.float() if res else 0.0)
+    assert rel_err(out_v[:, :N], ref) < 4e-3 and rel_err(out_h, ref) < 4e-3
+    assert rel_err(out_v[:, :N], out_h) < 3e-3
+    hk.gemm_set_vendor(True)
+    for args in [(M, N, K, K, K, N, 0, 1, 0, 0, 0, 1.0), (M, N, K, K, K, N, 0, 0, 1, 0, 0, 1.0), (M, N, K, K, K, N, 0, 0, 0, 1, 0, 1.0),
+                 (M, N, K, K, K, N, 0, 0, 0, 0, 0, 0.5), (M, N, 1024, 1024, 1024, N, 0, 0, 0, 0, 0, 1.0), (512, N, K, K, K, N, 0, 0, 0, 0, 0, 1.0),
+                 (M, N, K, K, K, N + 4, 0, 0, 0, 0, 0, 1.0)]:
+        assert lib.lhrs_gemm_vendor_takes(*args) == 0, args
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 1024, 1024), (2184, 4096, 4096), (1000, 12288, 4096),
                                    (273, 4096, 11008), (64, 64, 64), (33, 132, 128), (1152, 1024, 4096),
                                    (4095, 4096, 128), (3000, 4104, 96), (8190, 4096, 4096), (2184, 22016, 4096),

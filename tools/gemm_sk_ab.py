@@ -1,5 +1,7 @@
 """Stream-K tail of the persistent 256x256 GEMM against whole-tile rounds, alternating inside one process on one box (us per launch).
    python tools/gemm_sk_ab.py [micro-batches ...]      default 30 32 8"""
+import os as _os
+_os.environ.setdefault("LHRS_GEMM_VENDOR", "0")   # these tools measure the hand-written kernels, not the vendor library
 import os
 import sys
 
