@@ -274,6 +274,17 @@ GEMM_144_DESC = ("gemm_nt_144s_kernel<ACT, 0> (144x256 tile, 12 waves, three 50 
                  "micro-batch; the 256-row kernel's variants are listed under `variants`")
 
 
+def plain_products_note(lib):
+    import ctypes
+    where = (lib.lhrs_gemm_vendor_status() or b"").decode()
+    st = (ctypes.c_long * 3)()
+    lib.lhrs_gemm_vendor_stats(ctypes.addressof(st))
+    if not where:
+        return "hand-written kernels (vendor library off)"
+    return (f"{where}: {st[0]} problems timed on their first call, {st[1]} went to the library's kernel, {st[2]} stayed on the hand-written kernel "
+            "(csrc/gemm.hip: lhrs_gemm_bf16_nt)")
+
+
 def roofline_block(prof, kinds, steps, B, S, scale_layers, sclk=None, watts=None):
     """`achieved` is ONE kernel's figure: the plain-epilogue 256x256 persistent kernel (kind 0, `gemm_nt_256s_kernel<ACT, 0, K2P, false>` in a rocprofv3
     kernel trace) - or, when that kernel carries less time than the plain 144-row kernel (kind 4: micro-batch 8), that one - so that its
@@ -487,7 +498,7 @@ def main():
                        "last_layer_rows": "supervised positions only (same loss and gradients; LHRS_TAIL_ROWS_ONLY=0 computes all)" if os.environ.get("LHRS_TAIL_ROWS_ONLY", "1") != "0" else "all",
                        "grad_allreduce": a.comm_dtype if world > 1 else "none",
                        "dist_backend": (torch.distributed.get_backend() if world > 1 else None), "data_parallel": dp,
-                       "plain_long_k_products": ((lib.lhrs_gemm_vendor_status() or b"").decode() or "hand-written kernels (vendor library off)")},
+                       "plain_long_k_products": plain_products_note(lib)},
             "loss": round(final_loss, 4),
             "step_mfma_frac": round(sps / world * f_alg(S) / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 and a.stage == 1 else None,
             "step_mfma_frac_executed": round(sps / world * f_exec / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 and a.stage == 1 else None,

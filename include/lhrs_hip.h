@@ -201,6 +201,13 @@ int lhrs_gemm_vendor_takes(int M, int N, int K, int lda, int ldb, int ldc, int l
 const char* lhrs_gemm_vendor_status(void);
 int lhrs_vendor_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual,
                         int ldr, void* workspace, long workspace_bytes, void* stream);
+/* the first call of lhrs_gemm_bf16_nt on such a problem decides by measurement (1 + 3 launches of every algorithm the library's heuristic offers -
+ * lhrs_vendor_gemm_tune keeps the fastest - against 1 + 3 launches of the hand-written kernel, on the caller's operands and stream, host-synchronous);
+ * the library is taken when it is more than 3 % faster.  Not on a capturing stream, not when C aliases an input, at most 96 problems per process
+ * (then: hand-written).  vendor_stats -> {problems decided, -> library, -> hand-written}; LHRS_GEMM_VENDOR_LOG=1 prints each decision to stderr. */
+int lhrs_vendor_gemm_tune(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual,
+                          int ldr, void* workspace, long workspace_bytes, int reps, float* best_us, void* stream);
+int lhrs_gemm_vendor_stats(long* out3_host);
 
 /* ---- LoRA gradients (peft lora.Linear backward; lhrs/models/text_modal.py:133-151) ------------------------- *
  * C[KP,N] (+)= P[M,KP]^T . Q[M,N]: dA = (s dy B)^T x and dB^T = (s x A^T)^T dy straight from token-major operands.  */

@@ -3,8 +3,7 @@
 // Which launches: out[M,N] (bf16) = a[M,K] . b[N,K]^T (+ residual) with no bias, no activation, alpha = 1 and a long k-loop - the decoder's
 // down / o projections, the dX products of the backward and the lm_head (HF LlamaDecoderLayer's nn.Linear calls, reached from
 // lhrs/models/text_modal.py:133-151).  Everything with a fused epilogue (SwiGLU forward / backward, RoPE, LoRA in the k-loop, bias + GELU, f32
-// accumulation) stays on the hand-written kernels of gemm.hip.  Why: same-box A/B at micro-batch 30 (tools/vendor_plain_ab.sh,
-// profiles/r04_vendor_plain_ab.txt) - 154.3 / 156.6 -> 167.0 samples/s; the library's hand-scheduled assembly kernel for these shapes (256x256x64 tile, FOUR
+// accumulation) stays on the hand-written kernels of gemm.hip.  Why: same-box A/B at micro-batch 30 (profiles/r04_vendor_ab.txt) - 154.3 / 156.6 -> 167.0 samples/s; the library's hand-scheduled assembly kernel for these shapes (256x256x64 tile, FOUR
 // waves of 128x128, stream-K over 256 persistent workgroups) runs the long-k products 14-19 % faster than gemm_nt_256s_kernel, and
 // DESIGN.md §3.1 records why the same wave shape does not survive the HIP compiler.
 //
@@ -64,12 +63,13 @@ bool resolve() {
   return true;
 }
 
+constexpr int kMaxAlgos = 8;
 struct Plan {
   hipblasLtMatmulDesc_t desc = nullptr;
   hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr, ld = nullptr;
-  hipblasLtMatmulAlgo_t algo;
-  size_t ws = 0;
-  bool ok = false;
+  hipblasLtMatmulAlgo_t algo[kMaxAlgos];
+  size_t ws[kMaxAlgos] = {};
+  int n = 0, best = 0;   // best: index the launches use - the heuristic's first answer until lhrs_vendor_gemm_tune has timed them
 };
 using Key = std::tuple<int, int, int, int, int, int, int, int, long>;  // dev, M, N, K, lda, ldb, ldc, ldr (0: no residual), workspace bytes offered
 std::map<Key, Plan> g_plans;
@@ -91,13 +91,32 @@ Plan build(hipblasLtHandle_t h, int M, int N, int K, int lda, int ldb, int ldc, 
   if (g_api.pref_create(&pref) != HIPBLAS_STATUS_SUCCESS) return p;
   const uint64_t wsz = ws_bytes;
   (void)g_api.pref_set(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsz, sizeof(wsz));
-  hipblasLtMatmulHeuristicResult_t r[1];
+  hipblasLtMatmulHeuristicResult_t r[kMaxAlgos];
   int got = 0;
-  const hipblasStatus_t st = g_api.heuristic(h, p.desc, p.la, p.lb, p.lc, p.ld, pref, 1, r, &got);
+  const hipblasStatus_t st = g_api.heuristic(h, p.desc, p.la, p.lb, p.lc, p.ld, pref, kMaxAlgos, r, &got);
   (void)g_api.pref_destroy(pref);
-  if (st != HIPBLAS_STATUS_SUCCESS || got < 1 || r[0].state != HIPBLAS_STATUS_SUCCESS || r[0].workspaceSize > ws_bytes) return p;
-  p.algo = r[0].algo; p.ws = r[0].workspaceSize; p.ok = true;
+  if (st != HIPBLAS_STATUS_SUCCESS) return p;
+  for (int i = 0; i < got && i < kMaxAlgos; ++i)
+    if (r[i].state == HIPBLAS_STATUS_SUCCESS && r[i].workspaceSize <= ws_bytes) { p.algo[p.n] = r[i].algo; p.ws[p.n] = r[i].workspaceSize; p.n++; }
   return p;
+}
+
+Plan* plan_for(int M, int N, int K, int lda, int ldb, int ldc, int ldr, bool has_res, void* workspace, long workspace_bytes, int* dev_out) {
+  if (!resolve()) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!g_handle[dev] && g_api.create(&g_handle[dev]) != HIPBLAS_STATUS_SUCCESS) { g_handle[dev] = nullptr; return nullptr; }
+  const Key key(dev, M, N, K, lda, ldb, ldc, has_res ? ldr : 0, workspace ? workspace_bytes : 0);
+  auto it = g_plans.find(key);
+  if (it == g_plans.end()) it = g_plans.emplace(key, build(g_handle[dev], M, N, K, lda, ldb, ldc, has_res ? ldr : 0, workspace ? (size_t)workspace_bytes : 0)).first;
+  *dev_out = dev;
+  return it->second.n > 0 ? &it->second : nullptr;
+}
+
+hipblasStatus_t run(int dev, const Plan& p, int i, const void* A, const void* B, void* C, const void* residual, void* workspace, hipStream_t s) {
+  const float one = 1.f, zero = 0.f;
+  return g_api.matmul(g_handle[dev], p.desc, &one, B, p.la, A, p.lb, residual ? &one : &zero, residual ? residual : C, p.lc, C, p.ld, &p.algo[i],
+                      p.ws[i] ? workspace : nullptr, p.ws[i], s);
 }
 
 }  // namespace
@@ -106,24 +125,49 @@ Plan build(hipblasLtHandle_t h, int M, int N, int K, int lda, int ldb, int ldc, 
 extern "C" int lhrs_vendor_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
                                    void* workspace, long workspace_bytes, void* stream) {
   std::lock_guard<std::mutex> lock(g_mu);
-  if (!resolve()) return 1;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 1;
-  if (!g_handle[dev] && g_api.create(&g_handle[dev]) != HIPBLAS_STATUS_SUCCESS) { g_handle[dev] = nullptr; return 1; }
-  const Key key(dev, M, N, K, lda, ldb, ldc, residual ? ldr : 0, workspace ? workspace_bytes : 0);
-  auto it = g_plans.find(key);
-  if (it == g_plans.end()) it = g_plans.emplace(key, build(g_handle[dev], M, N, K, lda, ldb, ldc, residual ? ldr : 0, workspace ? (size_t)workspace_bytes : 0)).first;
-  const Plan& p = it->second;
-  if (!p.ok) return 1;
-  const float one = 1.f, zero = 0.f;
-  const hipblasStatus_t st = g_api.matmul(g_handle[dev], p.desc, &one, B, p.la, A, p.lb, residual ? &one : &zero, residual ? residual : C, p.lc, C, p.ld,
-                                          &p.algo, p.ws ? workspace : nullptr, p.ws, (hipStream_t)stream);
+  Plan* p = plan_for(M, N, K, lda, ldb, ldc, ldr, residual != nullptr, workspace, workspace_bytes, &dev);
+  if (p == nullptr) return 1;
+  const hipblasStatus_t st = run(dev, *p, p->best, A, B, C, residual, workspace, (hipStream_t)stream);
   if (st != HIPBLAS_STATUS_SUCCESS) {
     char b[160];
     snprintf(b, sizeof(b), "vendor gemm: hipblasLtMatmul failed with status %d (M=%d N=%d K=%d)", (int)st, M, N, K);
     lhrs_set_error(b);
     return -1;
   }
+  return 0;
+}
+
+// Times every algorithm the heuristic offered for this problem on the caller's operands (1 untimed + `reps` timed launches each, HIP events on
+// `stream`, host-synchronous) and keeps the fastest for lhrs_vendor_gemm_nt; *best_us = its time per launch.  Every timing launch writes the
+// product's real result to C (A, B and the residual are only read), so C must not alias an operand or the residual (the caller checks).
+// 0 tuned, 1 not available.
+extern "C" int lhrs_vendor_gemm_tune(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
+                                     void* workspace, long workspace_bytes, int reps, float* best_us, void* stream) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  int dev = 0;
+  Plan* p = plan_for(M, N, K, lda, ldb, ldc, ldr, residual != nullptr, workspace, workspace_bytes, &dev);
+  if (p == nullptr) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1;
+  float best = 1e30f;
+  int best_i = -1;
+  for (int i = 0; i < p->n; ++i) {
+    if (run(dev, *p, i, A, B, C, residual, workspace, s) != HIPBLAS_STATUS_SUCCESS) continue;
+    (void)hipEventRecord(e0, s);
+    bool ok = true;
+    for (int r = 0; r < reps && ok; ++r) ok = run(dev, *p, i, A, B, C, residual, workspace, s) == HIPBLAS_STATUS_SUCCESS;
+    (void)hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess || !ok) continue;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
+    if (ms / reps < best) { best = ms / reps; best_i = i; }
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (best_i < 0) { p->n = 0; return 1; }
+  p->best = best_i;
+  *best_us = best * 1e3f;
   return 0;
 }
 

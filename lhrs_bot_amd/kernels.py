@@ -40,7 +40,8 @@ _SK_WS = {}
 
 def ensure_streamk_workspace(device, force: bool = False) -> None:
     """Give the library its GEMM workspace on `device` (caller-owned, 64 MiB + 4 KiB: include/lhrs_hip.h) - once per device and process;
-    the towers call this when they are built.  Two users inside the library: the split-K launch for the tail rows of a row-split product
+    the towers call this when they are built.  Three users inside the library: the vendor library's stream-K kernels on the plain long-k products
+    (csrc/vendor.cpp), the split-K launch for the tail rows of a row-split product
     with a long k-loop (always on), and the stream-K launch of the persistent kernel's last partial round, which is OFF unless
     LHRS_GEMM_STREAMK=1 (measured slower than whole rounds on MI355X: csrc/gemm.hip).  LHRS_GEMM_WORKSPACE=0: nothing is registered.
     force=True (tests, tools/gemm_sk_ab.py): register, leave the stream-K switch to the caller."""
@@ -70,6 +71,24 @@ def gemm_set_vendor(on: bool, min_k: int = 0) -> None:
 def gemm_vendor_status() -> str:
     msg = _L().lhrs_gemm_vendor_status()
     return msg.decode() if msg else ""
+
+
+def gemm_vendor_stats():
+    """(problems decided by first-call timing, of them -> the library's kernel, -> the hand-written kernel)."""
+    st = (ctypes.c_long * 3)()
+    _L().lhrs_gemm_vendor_stats(ctypes.addressof(st))
+    return int(st[0]), int(st[1]), int(st[2])
+
+
+def vendor_gemm_nt(a, b, out, residual=None) -> bool:
+    """The raw library call (tests): True when launched, False when the library has no kernel for the problem."""
+    ensure_streamk_workspace(a.device, force=True)
+    ws = _SK_WS[a.device.index if a.device.index is not None else torch.cuda.current_device()]
+    st = _L().lhrs_vendor_gemm_nt(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), a.shape[0], b.shape[0], a.shape[1],
+                                  _p(residual), residual.stride(0) if residual is not None else 0, ws.data_ptr() + 4096, ws.numel() - 4096, _stream())
+    if st < 0:
+        _lib.check(st, "vendor_gemm_nt")
+    return st == 0
 
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, bias=None, residual=None,
