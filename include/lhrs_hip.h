@@ -183,13 +183,14 @@ int lhrs_gemm_set_small_thresh(int n);
 int lhrs_gemm_set_min_tiles(int n);
 /* live HIP-event timing of the 16-wave 256x256 GEMM launches, on their launch stream, for bench.py's roofline leg (gemm.hip):
  * enable(n) arms n event pairs (0 = off); read() -> {launches of the plain-epilogue persistent kernels (256-row + 144-row tiles), their ms, their
- * flops, all GEMM launches, all GEMM flops}; read_kinds() -> [6][3] = {launches, ms, flops} per kind: 0 plain <ACT,0> of the 256x256 kernel,
- * 1 SwiGLU fwd, 2 SwiGLU bwd, 3 RoPE epilogue of the same kernel, 4 the plain 144-row kernel, 5 plain products handed to the vendor library */
+ * flops, all GEMM launches, all GEMM flops}; read_kinds() -> [7][3] = {launches, ms, flops} per kind: 0 plain <ACT,0> of the 256x256 kernel,
+ * 1 SwiGLU fwd, 2 SwiGLU bwd, 3 RoPE epilogue of the same kernel, 4 the plain 144-row kernel, 5 plain products handed to the vendor library,
+ * 6 plain products on the four-wave gemm_u4_kernel */
 int lhrs_gemm_profile_enable(int max_samples);
 /* bracket only every n-th launch of each epilogue variant (default 1): the event records themselves cost stream time (1-2 % of a step) */
 int lhrs_gemm_profile_stride(int n);
 int lhrs_gemm_profile_read(double* out5_host);
-int lhrs_gemm_profile_read_kinds(double* out18_host);
+int lhrs_gemm_profile_read_kinds(double* out21_host);
 /* plain long-k products (no bias, no activation, bf16 out, alpha 1, K >= min_k, M and N >= 1024) are offered to the vendor library first
  * (hipBLASLt, looked up in the process at run time - csrc/vendor.cpp; same-box A/B +7 % on the stage-1 step); everything with a fused epilogue
  * stays on the hand-written kernels.  set_vendor(0, 0) keeps every product on them (env LHRS_GEMM_VENDOR=0); vendor_takes() = 1 when
@@ -208,6 +209,15 @@ int lhrs_vendor_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C,
 int lhrs_vendor_gemm_tune(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual,
                           int ldr, void* workspace, long workspace_bytes, int reps, float* best_us, void* stream);
 int lhrs_gemm_vendor_stats(long* out3_host);
+/* gemm_u4_kernel (csrc/gemm_u4.hip): the hand-written four-wave kernel for the same plain long-k products - 256x256x64 tile, 128x128 per wave, AGPR
+ * accumulators, paced LDS-DMA, persistent; bit-identical to gemm_nt_256s_kernel without a residual (a residual joins the fp32 sum before the one rounding)
+ * and 5-18 % faster on these shapes.  It is the third candidate of the
+ * first-call timing (set_u4(0) / LHRS_GEMM_U4=0 removes it); u4_nt is the raw launch: 0 launched, 1 not its problem (K % 64, K < 128, alignment), -1 error;
+ * u4_problems(): how many timed problems it won.  vendor_stats()[2] counts both hand-written kernels. */
+int lhrs_gemm_set_u4(int on);
+int lhrs_gemm_u4_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
+                    void* stream);
+long lhrs_gemm_u4_problems(void);
 
 /* ---- LoRA gradients (peft lora.Linear backward; lhrs/models/text_modal.py:133-151) ------------------------- *
  * C[KP,N] (+)= P[M,KP]^T . Q[M,N]: dA = (s dy B)^T x and dB^T = (s x A^T)^T dy straight from token-major operands.  */

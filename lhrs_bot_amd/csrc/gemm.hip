@@ -1244,7 +1244,7 @@ struct GemmProf {
   double total_flops_all = 0; // every GEMM launch while enabled (sampled or not)
   long launches_all = 0;
   int stride = 1;             // every stride-th launch of each epilogue variant is bracketed (lhrs_gemm_profile_stride)
-  long seen[6] = {0, 0, 0, 0, 0, 0};  // 0 plain 256-row, 1 SwiGLU fwd, 2 SwiGLU bwd, 3 RoPE, 4 plain 144-row, 5 plain products handed to the vendor library
+  long seen[7] = {0, 0, 0, 0, 0, 0, 0};  // 0 plain 256-row, 1 SwiGLU fwd, 2 SwiGLU bwd, 3 RoPE, 4 plain 144-row, 5 plain products handed to the vendor library, 6 plain products on gemm_u4_kernel
   bool take(int kind) { return (seen[kind]++ % stride) == 0; }
 } g_prof;
 }  // namespace
@@ -1263,7 +1263,7 @@ extern "C" int lhrs_gemm_profile_enable(int max_samples) {
   }
   g_prof.on = max_samples > 0; g_prof.cap = max_samples > 0 ? max_samples : 0; g_prof.used = 0;
   g_prof.total_flops_all = 0; g_prof.launches_all = 0;
-  for (int k = 0; k < 6; ++k) g_prof.seen[k] = 0;
+  for (int k = 0; k < 7; ++k) g_prof.seen[k] = 0;
   if (g_prof.on) {
     g_prof.ev = new hipEvent_t[2 * g_prof.cap];
     g_prof.flops = new double[g_prof.cap];
@@ -1289,12 +1289,12 @@ extern "C" int lhrs_gemm_profile_read(double* out) {
   return 0;
 }
 
-// out[6][3]: per kind k - 0 plain <ACT,0> of the 16-wave 256x256 kernel (THE dominant kernel), 1 SwiGLU fwd <0,1>, 2 SwiGLU bwd <0,2>, 3 RoPE <0,3> of
+// out[7][3]: per kind k - 0 plain <ACT,0> of the 16-wave 256x256 kernel (THE dominant kernel), 1 SwiGLU fwd <0,1>, 2 SwiGLU bwd <0,2>, 3 RoPE <0,3> of
 // the same kernel, 4 the plain 144-row persistent kernel (gemm_nt_144s_kernel<ACT, 0>: ViT / projector products, micro-batch 8),
-// 5 the plain long-k products handed to the vendor library (vendor.cpp) -:
+// 5 the plain long-k products handed to the vendor library (vendor.cpp), 6 those on the four-wave gemm_u4_kernel (gemm_u4.hip) -:
 // sampled launches, their summed duration (ms), their summed flops
 extern "C" int lhrs_gemm_profile_read_kinds(double* out) {
-  for (int i = 0; i < 18; ++i) out[i] = 0;
+  for (int i = 0; i < 21; ++i) out[i] = 0;
   for (int i = 0; i < g_prof.used; ++i) {
     float t = 0;
     if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) LHRS_FAIL("gemm_profile_read_kinds: event sync failed");
@@ -1481,42 +1481,58 @@ extern "C" int lhrs_gemm_bf16_nt_dropmask(const void* A, int lda, const void* B,
   return rc;
 }
 
-// ---- the plain long-k products go to the vendor library (vendor.cpp says why): 1 = on (default), 0 = every product on the kernels of this file
+// ---- plain long-k products: three candidates, chosen per problem by measurement ---------------------------------------------------------
+// A product with a plain epilogue (no bias, no activation, bf16 out, alpha 1) on a long k-loop can run (0) gemm_nt_256s_kernel / gemm_nt_144s_kernel of this
+// file, (2) the four-wave gemm_u4_kernel (gemm_u4.hip: 128x128 per wave, paced DMA - 5-18 % faster than (0) on these shapes) or (1) the vendor library's
+// assembly kernel (vendor.cpp).  Per problem (device, M, N, K, leading dims, residual or not) the FIRST call times all three - every algorithm the library's
+// heuristic offers (lhrs_vendor_gemm_tune), 1 untimed + 3 timed launches each on the caller's operands and stream - and later calls repeat the winner.  The
+// library's first heuristic answer alone is not safe to follow: tools/gemm_vendor_ab.py has it 1.4-1.8x SLOWER than gemm_nt_256s_kernel at M = 5460
+// (K >= 11008) and at M = 2184, K = 22016.  A hand-written kernel keeps the problem unless the library is more than 3 % faster, so that two ranks rarely
+// disagree over noise; every choice is a correct bf16 product ((0) and (2) bit-identical unless a residual is added: (1) and (2) round once).  Not timed (kernel (0), nothing cached): a capturing stream, C
+// aliasing an input, more than 96 problems in one process.  lhrs_gemm_set_vendor / LHRS_GEMM_VENDOR=0 and lhrs_gemm_set_u4 / LHRS_GEMM_U4=0 remove a candidate.
 extern "C" int lhrs_vendor_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
                                    void* workspace, long workspace_bytes, void* stream);
-static int g_vendor_on = -1, g_vendor_min_k = 4096;
+extern "C" int lhrs_vendor_gemm_tune(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
+                                     void* workspace, long workspace_bytes, int reps, float* best_us, void* stream);
+extern "C" int lhrs_gemm_u4_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
+                               void* stream);
+static int g_vendor_on = -1, g_u4_on = -1, g_vendor_min_k = 4096;
 static int prof_count(int M, int N, int K, int kind, hipStream_t s);
 static void prof_end(int slot, hipStream_t s);
-extern "C" int lhrs_gemm_set_vendor(int on, int min_k) {
-  g_vendor_on = on ? 1 : 0;
-  if (min_k > 0) g_vendor_min_k = min_k;
-  return 0;
-}
-static bool vendor_on() {
+static void plain_env() {
   if (g_vendor_on < 0) {
     const char* e = getenv("LHRS_GEMM_VENDOR");
     g_vendor_on = (e == nullptr || e[0] != '0') ? 1 : 0;
     const char* k = getenv("LHRS_GEMM_VENDOR_MIN_K");
     if (k != nullptr && atoi(k) > 0) g_vendor_min_k = atoi(k);
   }
-  return g_vendor_on == 1;
+  if (g_u4_on < 0) {
+    const char* e = getenv("LHRS_GEMM_U4");
+    g_u4_on = (e == nullptr || e[0] != '0') ? 1 : 0;
+  }
 }
-// 1 when lhrs_gemm_bf16_nt offers this problem to the library first (a plain epilogue on a long k-loop, operands the library can address)
+extern "C" int lhrs_gemm_set_vendor(int on, int min_k) {
+  plain_env();
+  g_vendor_on = on ? 1 : 0;
+  if (min_k > 0) g_vendor_min_k = min_k;
+  return 0;
+}
+extern "C" int lhrs_gemm_set_u4(int on) { plain_env(); g_u4_on = on ? 1 : 0; return 0; }
+// 1 when lhrs_gemm_bf16_nt decides this problem by first-call timing (a plain epilogue on a long k-loop, operands every candidate can address)
+static int plain_timed(int M, int N, int K, int lda, int ldb, int ldc, int ldr, int has_bias, int act, int out_f32, int accumulate, float alpha) {
+  plain_env();
+  return (g_vendor_on == 1 || g_u4_on == 1) && !has_bias && act == 0 && !out_f32 && !accumulate && alpha == 1.f && K >= g_vendor_min_k && K % 64 == 0 &&
+         M >= 1024 && N >= 1024 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && ldr % 8 == 0;
+}
+// 1 when the vendor library is among the candidates for this problem
 extern "C" int lhrs_gemm_vendor_takes(int M, int N, int K, int lda, int ldb, int ldc, int ldr, int has_bias, int act, int out_f32, int accumulate, float alpha) {
-  return vendor_on() && !has_bias && act == 0 && !out_f32 && !accumulate && alpha == 1.f && K >= g_vendor_min_k && M >= 1024 && N >= 1024 &&
-         lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && ldr % 8 == 0;
+  return plain_timed(M, N, K, lda, ldb, ldc, ldr, has_bias, act, out_f32, accumulate, alpha) && g_vendor_on == 1;
 }
-
-// Per problem (device, M, N, K, leading dims, residual or not), decided ONCE by measurement on the first call: every algorithm the library's heuristic
-// offers (lhrs_vendor_gemm_tune) against the hand-written launch, 1 untimed + 3 timed launches each on the caller's operands and stream.  The
-// heuristic's first answer alone is not safe to follow: tools/gemm_vendor_ab.py has it 1.4-1.8x SLOWER than gemm_nt_256s_kernel at M = 5460 (K >= 11008)
-// and at M = 2184, K = 22016, and 11-18 % faster at M = 8190.  The library wins only by a margin (3 %), so that two ranks rarely disagree over noise;
-// either choice is a correct bf16 product.  Not tuned (hand-written kernel, nothing cached): a capturing stream, or C aliasing an input.
-extern "C" int lhrs_vendor_gemm_tune(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
-                                     void* workspace, long workspace_bytes, int reps, float* best_us, void* stream);
-static std::map<std::array<long, 9>, int> g_vendor_choice;   // -> 1 library, 0 hand-written
-static long g_vendor_stats[3] = {0, 0, 0};                   // problems decided, -> library, -> hand-written
+static std::map<std::array<long, 11>, int> g_plain_choice;   // -> 0 this file's kernels, 1 library, 2 gemm_u4_kernel
+static long g_vendor_stats[3] = {0, 0, 0};                   // problems decided, -> library, -> hand-written (either kernel)
+static long g_u4_problems = 0;                               // of the hand-written ones: -> gemm_u4_kernel
 extern "C" int lhrs_gemm_vendor_stats(long* out3) { for (int i = 0; i < 3; ++i) out3[i] = g_vendor_stats[i]; return 0; }
+extern "C" long lhrs_gemm_u4_problems() { return g_u4_problems; }
 static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* bias,
                        const void* residual, int ldr, int act, int out_f32, int accumulate, float alpha, const void* A2,
                        int lda2, const void* B2, int ldb2, int K2, void* stream);
@@ -1528,7 +1544,7 @@ static bool overlaps(const void* p, long bytes_p, const void* q, long bytes_q) {
 extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N,
                                  int K, const void* bias, const void* residual, int ldr, int act, int out_f32,
                                  int accumulate, float alpha, void* stream) {
-  if (lhrs_gemm_vendor_takes(M, N, K, lda, ldb, ldc, residual ? ldr : 0, bias != nullptr, act, out_f32, accumulate, alpha) &&
+  if (plain_timed(M, N, K, lda, ldb, ldc, residual ? ldr : 0, bias != nullptr, act, out_f32, accumulate, alpha) &&
       ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0) && ((size_t)C % 16 == 0) && ((size_t)residual % 16 == 0)) {
     int dev = 0;
     void* ws = nullptr; long ws_bytes = 0;
@@ -1536,9 +1552,9 @@ extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
     if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && g_sk[dev].slabs != nullptr) {   // the registered workspace (lhrs_gemm_set_streamk_workspace)
       ws = g_sk[dev].slabs; ws_bytes = g_sk[dev].units * 256L * 256 * 4;
     }
-    const std::array<long, 9> key = {dev, M, N, K, lda, ldb, ldc, residual ? ldr : 0, ws_bytes};
-    auto it = g_vendor_choice.find(key);
-    int choice = it == g_vendor_choice.end() ? -1 : it->second;
+    const std::array<long, 11> key = {dev, M, N, K, lda, ldb, ldc, residual ? ldr : 0, ws_bytes, g_vendor_on, g_u4_on};
+    auto it = g_plain_choice.find(key);
+    int choice = it == g_plain_choice.end() ? -1 : it->second;
     if (choice < 0) {
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
       const long cb = ((long)(M - 1) * ldc + N) * 2;
@@ -1548,28 +1564,36 @@ extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
       if (tunable && g_vendor_stats[0] < 96) {   // bounded: a caller that walks through many row counts (ragged prefill batches) stops paying for timing runs
         const bool prof_was = g_prof.on;
         g_prof.on = false;                                     // the timing launches are not part of the step
-        float t_lib = 0.f, t_hand = 1e30f;
-        const int got = lhrs_vendor_gemm_tune(A, lda, B, ldb, C, ldc, M, N, K, residual, ldr, ws, ws_bytes, 3, &t_lib, stream);
-        if (got == 0) {
-          hipEvent_t e0, e1;
-          if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-            int st = gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, nullptr, residual, ldr, 0, 0, 0, 1.f, nullptr, 0, nullptr, 0, 0, stream);
+        float t_lib = 1e30f, t_hand = 1e30f, t_u4 = 1e30f;
+        if (g_vendor_on == 1 && lhrs_vendor_gemm_tune(A, lda, B, ldb, C, ldc, M, N, K, residual, ldr, ws, ws_bytes, 3, &t_lib, stream) != 0) t_lib = 1e30f;
+        hipEvent_t e0, e1;
+        if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+          for (int cand = 0; cand < 2; ++cand) {                // 0: this file's kernels, 1: gemm_u4_kernel
+            if (cand == 1 && g_u4_on != 1) break;
+            auto run = [&]() {
+              return cand == 0 ? gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, nullptr, residual, ldr, 0, 0, 0, 1.f, nullptr, 0, nullptr, 0, 0, stream)
+                               : lhrs_gemm_u4_nt(A, lda, B, ldb, C, ldc, M, N, K, residual, ldr, stream);
+            };
+            int st = run();
             (void)hipEventRecord(e0, s);
-            for (int r = 0; r < 3 && st == 0; ++r) st = gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, nullptr, residual, ldr, 0, 0, 0, 1.f, nullptr, 0, nullptr, 0, 0, stream);
+            for (int r = 0; r < 3 && st == 0; ++r) st = run();
             (void)hipEventRecord(e1, s);
             float ms = 0.f;
-            if (st == 0 && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) t_hand = ms / 3.f * 1e3f;
-            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-            if (st != 0) { g_prof.on = prof_was; return st; }
+            if (st == 0 && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) (cand == 0 ? t_hand : t_u4) = ms / 3.f * 1e3f;
+            if (st < 0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); g_prof.on = prof_was; return st; }
           }
+          (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         }
         g_prof.on = prof_was;
-        choice = (got == 0 && t_lib < 0.97f * t_hand) ? 1 : 0;
-        g_vendor_choice[key] = choice;
-        g_vendor_stats[0]++; g_vendor_stats[choice ? 1 : 2]++;
+        const float t_own = t_u4 < t_hand ? t_u4 : t_hand;
+        choice = t_lib < 0.97f * t_own ? 1 : (t_u4 < t_hand ? 2 : 0);
+        g_plain_choice[key] = choice;
+        g_vendor_stats[0]++; g_vendor_stats[choice == 1 ? 1 : 2]++;
+        if (choice == 2) g_u4_problems++;
         if (getenv("LHRS_GEMM_VENDOR_LOG") != nullptr)
-          fprintf(stderr, "[lhrs gemm] M=%d N=%d K=%d%s: library %.1f us, hand-written %.1f us -> %s\n", M, N, K, residual ? " +residual" : "",
-                  got == 0 ? t_lib : -1.f, t_hand, choice ? "library" : "hand-written");
+          fprintf(stderr, "[lhrs gemm] M=%d N=%d K=%d%s: library %.1f us, 16-wave kernel %.1f us, 4-wave kernel %.1f us -> %s\n", M, N, K, residual ? " +residual" : "",
+                  t_lib < 1e29f ? t_lib : -1.f, t_hand < 1e29f ? t_hand : -1.f, t_u4 < 1e29f ? t_u4 : -1.f,
+                  choice == 1 ? "library" : choice == 2 ? "4-wave kernel" : "16-wave kernel");
       } else {
         choice = 0;
       }
@@ -1580,6 +1604,13 @@ extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
       if (st == 0) { prof_end(slot, s); return 0; }
       if (st < 0) return st;
       if (slot >= 0) { g_prof.used--; g_prof.seen[5]--; }   // not taken after all: the slot goes back (it was the last one handed out)
+      if (g_prof.on) { g_prof.launches_all--; g_prof.total_flops_all -= 2.0 * M * N * K; }
+    } else if (choice == 2) {
+      const int slot = prof_count(M, N, K, 6, s);
+      const int st = lhrs_gemm_u4_nt(A, lda, B, ldb, C, ldc, M, N, K, residual, ldr, stream);
+      if (st == 0) { prof_end(slot, s); return 0; }
+      if (st < 0) return st;
+      if (slot >= 0) { g_prof.used--; g_prof.seen[6]--; }
       if (g_prof.on) { g_prof.launches_all--; g_prof.total_flops_all -= 2.0 * M * N * K; }
     }
   }

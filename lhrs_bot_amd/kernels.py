@@ -68,6 +68,20 @@ def gemm_set_vendor(on: bool, min_k: int = 0) -> None:
     _L().lhrs_gemm_set_vendor(int(bool(on)), int(min_k))
 
 
+def gemm_set_u4(on: bool) -> None:
+    """The four-wave gemm_u4_kernel (csrc/gemm_u4.hip) as a candidate of the first-call timing for the plain long-k products (default on; LHRS_GEMM_U4=0)."""
+    _L().lhrs_gemm_set_u4(int(bool(on)))
+
+
+def gemm_u4_nt(a, b, out, residual=None) -> bool:
+    """The raw launch of gemm_u4_kernel (tests, tools): True when launched, False when the problem is not its kind."""
+    st = _L().lhrs_gemm_u4_nt(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), a.shape[0], b.shape[0], a.shape[1],
+                              _p(residual), residual.stride(0) if residual is not None else 0, _stream())
+    if st < 0:
+        _lib.check(st, "gemm_u4_nt")
+    return st == 0
+
+
 def gemm_vendor_status() -> str:
     msg = _L().lhrs_gemm_vendor_status()
     return msg.decode() if msg else ""
@@ -78,6 +92,10 @@ def gemm_vendor_stats():
     st = (ctypes.c_long * 3)()
     _L().lhrs_gemm_vendor_stats(ctypes.addressof(st))
     return int(st[0]), int(st[1]), int(st[2])
+
+
+def gemm_u4_problems() -> int:
+    return int(_L().lhrs_gemm_u4_problems())
 
 
 def vendor_gemm_nt(a, b, out, residual=None) -> bool:

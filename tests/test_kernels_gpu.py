@@ -27,8 +27,10 @@ def _hand_written_gemm_only(request):
     """This file checks the kernels of csrc/*.hip: the plain long-k products stay on them here (the product default offers those to the vendor
     library first, csrc/vendor.cpp); tests named *vendor* switch it on themselves."""
     hk.gemm_set_vendor(False)
+    hk.gemm_set_u4(False)
     yield
     hk.gemm_set_vendor(True)
+    hk.gemm_set_u4(True)
 
 
 # ------------------------------------------------------------------------------------------- GEMM
@@ -75,6 +77,41 @@ def test_gemm_plain_long_k_products_in_the_vendor_library(M, N, K, res):
                  (M, N, K, K, K, N, 0, 0, 0, 0, 0, 0.5), (M, N, 1024, 1024, 1024, N, 0, 0, 0, 0, 0, 1.0), (512, N, K, K, K, N, 0, 0, 0, 0, 0, 1.0),
                  (M, N, K, K, K, N + 4, 0, 0, 0, 0, 0, 1.0)]:
         assert lib.lhrs_gemm_vendor_takes(*args) == 0, args
+
+
+@pytest.mark.parametrize("M,N,K,res", [(8190, 4096, 11008, True), (8190, 4096, 22016, False), (2184, 4096, 4096, True), (1000, 1028, 128, False),
+                                       (8736, 11008, 4096, False), (300, 260, 192, True), (4095, 4104, 4096, True), (256, 256, 64 * 3, False)])
+def test_gemm_u4_four_wave_kernel_bit_identical_to_the_16_wave_kernel(M, N, K, res):
+    """gemm_u4_kernel (csrc/gemm_u4.hip: 128x128 per wave, AGPR accumulators, paced DMA, persistent over tiles): same k order and fp32 accumulation as
+    gemm_nt_256s_kernel - bit-identical on full tiles, ragged M / N edges, one to many tiles per workgroup, strided output and residual views; then the
+    first-call timing of lhrs_gemm_bf16_nt with the library off (two hand-written candidates) and the problems the raw launch must decline."""
+    g = torch.Generator(device="cpu").manual_seed(M * 3 + N + K)
+    a = bf(torch.randn(M, K, generator=g)).to(DEV)
+    b = bf(torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    r_full = bf(torch.randn(M, N + 8, generator=g)).to(DEV) if res else None
+    r = r_full[:, :N] if res else None
+    out_u = torch.zeros(M, N + 16, device=DEV, dtype=torch.bfloat16)
+    assert hk.gemm_u4_nt(a, b, out_u[:, :N], residual=r)
+    out_h = hk.gemm_nt(a, b, residual=r)                                    # fixture: library and u4 off -> gemm.hip's kernels
+    ref = a.float() @ b.float().t() + (r.float() if res else 0.0)
+    assert rel_err(out_h, ref) < 4e-3 and rel_err(out_u[:, :N], ref) < 4e-3
+    # bit-identical where the persistent 256- / 144-row kernels ran (small problems take other tiles) and no residual is added: this kernel (like the library and
+    # the split-K tail) adds the residual to the fp32 sum and rounds once, the staged epilogue of gemm_nt_256s_kernel rounds the sum first
+    big = M >= 2048 and N >= 4096 and not res
+    assert torch.equal(out_u[:, :N], out_h) if big else rel_err(out_u[:, :N], out_h) < 3e-3
+    if res:
+        assert (out_u[:, :N].float() - ref).abs().mean() <= (out_h.float() - ref).abs().mean() * 1.001
+    assert float(out_u[:, N:].abs().max()) == 0.0
+    hk.gemm_set_u4(True)
+    n0 = hk.gemm_vendor_stats()
+    out_p = hk.gemm_nt(a, b, residual=r)
+    n1 = hk.gemm_vendor_stats()
+    timed = K >= 4096 and M >= 1024 and N >= 1024 and N % 8 == 0
+    assert (n1[0] == n0[0] + 1) == (timed and n0[0] < 96) and n1[1] == n0[1]
+    assert (torch.equal(out_p, out_h) or torch.equal(out_p, out_u[:, :N])) if M >= 2048 and N >= 4096 else rel_err(out_p, ref) < 4e-3
+    assert torch.equal(hk.gemm_nt(a, b, residual=r), out_p)
+    hk.gemm_set_u4(False)
+    assert not hk.gemm_u4_nt(a[:, :96] if K > 96 else a, b[:, :96] if K > 96 else b, out_u[:, :N])            # K % 64 != 0 / K < 128: declined
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 1024, 1024), (2184, 4096, 4096), (1000, 12288, 4096),

@@ -39,6 +39,24 @@ __global__ __launch_bounds__(256, 1) void gemm_u(Args g) {
     off[j] = (unsigned)(((long)row * ld + lchunk * 8) * 2);
   }
   const int dst0 = (isA ? 0 : A_BYTES) + (wave & 1) * 16384;
+#ifdef DMA_MUBUF
+  // the DMA through the MUBUF path: buffer_load_dwordx4 ... offen lds with a raw buffer descriptor over the whole operand (the k offset of the stage in the
+  // SGPR soffset) instead of global_load_lds_dwordx4 in its saddr form
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  u32x4 rsrc;
+  {
+    const unsigned long long b = (unsigned long long)(size_t)base;
+    rsrc.x = __builtin_amdgcn_readfirstlane((unsigned)b);
+    rsrc.y = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);   // stride 0
+    rsrc.z = 0xffffffffu;                                                       // num_records: rows are clamped by hand
+    rsrc.w = 0x00020000u;
+  }
+  auto issue = [&](int kt, int buf, int j) {
+    const unsigned soff = (unsigned)kt * (BK * 2);
+    const unsigned lds_dst = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + buf * STAGE + dst0 + j * 1024;
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(off[j]), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory", "m0");
+  };
+#else
   auto issue = [&](int kt, int buf, int j) {
 #ifdef ABL_NODMA
     return;
@@ -47,6 +65,7 @@ __global__ __launch_bounds__(256, 1) void gemm_u(Args g) {
     const unsigned lds_dst = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + buf * STAGE + dst0 + j * 1024;
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off[j]), "s"(sp), "s"(lds_dst) : "memory", "m0");
   };
+#endif
   const int wm = wave >> 1, wn = wave & 1;
   const int sw = ((lane & 15) >> 1) & 7;
   const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
@@ -80,23 +99,29 @@ __global__ __launch_bounds__(256, 1) void gemm_u(Args g) {
 #define BARX __builtin_amdgcn_s_barrier(); SB
   int kt = 0;
   // steady state: stages kt+1 and kt+2 exist - no conditions inside the 128-MFMA body
-#define ISS(p) issue(kt + 2, kt & 1, p)
+  // one DMA piece = s_add on m0 behind one MFMA, the load behind the next: never more than two non-MFMA instructions between two MFMAs (one wave per SIMD issues
+  // one instruction per 4 cycles; a 16-cycle MFMA leaves three slots)
+#define M0P(p) if (p == 0) { asm volatile("s_mov_b32 m0, %0" ::"s"(lds0 + (kt & 1) * STAGE + dst0) : "m0"); } else { asm volatile("s_add_u32 m0, m0, 0x400" ::: "m0", "scc"); }
+#define GLDS(p) asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(off[p]), "s"(sp2) : "memory")
 #define RDN(dst, ad, off_) RDQ(dst, ad, off_)
   // stage kt+1 must have landed (this wave's pieces: vmcnt; everybody's: the barrier); the 16 younger pieces (stage kt+2) stay in flight
-#define WAITY asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB
+#define WAITY(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory"); __builtin_amdgcn_s_barrier(); SB
   for (; kt + 2 < nk; ++kt) {
     const unsigned so = (kt & 1) * STAGE, sn = so ^ STAGE;
     const unsigned aa1 = a0 ^ (so | 64u), ba1 = b0 ^ (so | 64u), aa0 = a0 ^ sn, ba0 = b0 ^ sn;
+    const char* sp2 = base + (long)(kt + 2) * (BK * 2);
     wait16(A0, B0);
 #include "u5_body.inc"
   }
-#undef ISS
+#undef M0P
+#undef GLDS
 #undef RDN
 #undef WAITY
   // the last two stages: nothing left to request; the last one has nothing to read ahead
-#define ISS(p)
+#define M0P(p)
+#define GLDS(p)
 #define RDN(dst, ad, off_) if (more) { RDQ(dst, ad, off_); }
-#define WAITY if (more) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } SB
+#define WAITY(n) if (more) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } SB
   for (; kt < nk; ++kt) {
     const unsigned so = (kt & 1) * STAGE, sn = so ^ STAGE;
     const bool more = kt + 1 < nk;
