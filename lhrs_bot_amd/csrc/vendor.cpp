@@ -4,8 +4,9 @@
 // down / o projections, the dX products of the backward and the lm_head (HF LlamaDecoderLayer's nn.Linear calls, reached from
 // lhrs/models/text_modal.py:133-151).  Everything with a fused epilogue (SwiGLU forward / backward, RoPE, LoRA in the k-loop, bias + GELU, f32
 // accumulation) stays on the hand-written kernels of gemm.hip.  Why: same-box A/B at micro-batch 30 (profiles/r04_vendor_ab.txt) - 154.3 / 156.6 -> 167.0 samples/s; the library's hand-scheduled assembly kernel for these shapes (256x256x64 tile, FOUR
-// waves of 128x128, stream-K over 256 persistent workgroups) runs the long-k products 14-19 % faster than gemm_nt_256s_kernel, and
-// DESIGN.md §3.1 records why the same wave shape does not survive the HIP compiler.
+// waves of 128x128, stream-K over 256 persistent workgroups) runs the long-k products 14-19 % faster than the 16-wave gemm_nt_256s_kernel.
+// gemm_u4.hip is our own kernel of that wave shape (at the library's rate on the longest k-loops, a few per cent behind on K = 4096 ... 11008); which of the
+// three runs a given problem is decided by timing them on its first call (gemm.hip: lhrs_gemm_bf16_nt).
 //
 // No link-time dependency: the entry points are looked up in the hipBLASLt that is already in the process (PyTorch loads its own copy) or, for a
 // C caller, in the first libhipblaslt.so.1 the loader finds.  When none is found, or the library has no algorithm for a problem, the caller

@@ -17,15 +17,24 @@ import re
 # kernel (ViT / projector products; the dominant one at micro-batch 8) is summarised next to it
 dom = [r for r in rows if re.search(r"gemm_nt_256s_kernel<\d, 0, (false|true)(, false)?>", r[name_key])]
 r144 = [r for r in rows if re.search(r"gemm_nt_144s_kernel<\d, 0>", r[name_key])]
+_rope = sorted(int(r["Start_Timestamp"]) for r in rows if re.search(r"gemm_nt_256s_kernel<\d, 3, ", r[name_key]))
+T0 = _rope[len(_rope) // (steps + warmup) * warmup] if len(_rope) >= steps + warmup else 0   # first RoPE-epilogue launch of the first timed step
+intimed = lambda rs: [r for r in rs if int(r["Start_Timestamp"]) >= T0]
 vend = [r for r in rows if "Cijk_" in r[name_key]]   # the vendor library's kernel on the plain long-k products (csrc/vendor.cpp)
 tot = lambda rs: sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs)
-vendor_dominant = len(vend) > 0 and tot(vend) > max(tot(dom), tot(r144))
+u4 = [r for r in rows if "gemm_u4_kernel" in r[name_key]]   # the hand-written four-wave kernel on the plain long-k products (csrc/gemm_u4.hip)
+u4_dominant = len(u4) > 0 and tot(intimed(u4)) > max(tot(intimed(dom)), tot(intimed(r144)), tot(intimed(vend)))
+vendor_dominant = (len(vend) > 0 and tot(intimed(vend)) > max(tot(intimed(dom)), tot(intimed(r144)))) or u4_dominant   # either way: the timed steps are found by time stamp, below
 hand = {"gemm_nt_256s_kernel plain launches": {"launches_total": len(dom), "avg_us": (tot(dom) / len(dom) / 1e3 if dom else None)}}
 for epi, nm in ((1, "SwiGLU-fwd"), (2, "SwiGLU-bwd"), (3, "RoPE")):
     rs = [r for r in rows if re.search(r"gemm_nt_256s_kernel<\d, %d, " % epi, r[name_key])]
     if rs:
         hand[f"gemm_nt_256s_kernel<0,{epi}> {nm} epilogue"] = {"launches_total": len(rs), "avg_us": tot(rs) / len(rs) / 1e3}
-if vendor_dominant:
+hand["gemm_u4_kernel (plain long-k products)"] = {"launches_total": len(u4), "avg_us": (tot(u4) / len(u4) / 1e3 if u4 else None)}
+vendor_share = {"launches_total": len(vend), "avg_us": (tot(vend) / len(vend) / 1e3 if vend else None)}
+if u4_dominant:
+    r144, dom = dom + r144, u4
+elif vendor_dominant:
     r144, dom = dom + r144, vend
 if not vendor_dominant and len(r144) and sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in r144) > sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in dom):
     dom, r144 = r144, dom
@@ -45,8 +54,8 @@ by_name = {}
 for r in timed:
     by_name.setdefault(r[name_key][:100], []).append(r)
 top = max(by_name, key=lambda k: tot(by_name[k])) if vendor_dominant else ""
-out = {"kernel": ((top + f" (vendor library; {len(by_name)} of its kernels were chosen by the first-call timing, this one carries {tot(by_name[top]) / max(tot(timed), 1):.0%} of their time)") if vendor_dominant else "gemm_nt_144s_kernel<ACT, 0>" if n144 else "gemm_nt_256s_kernel<ACT, 0, K2P, false>") + " (the kernel bench.py's roofline.achieved is quoted on)",
-       "hand_written_gemm_variants": hand,
+out = {"kernel": "gemm_u4_kernel (csrc/gemm_u4.hip, hand-written)" + " (the kernel bench.py's roofline.achieved is quoted on)" if u4_dominant else ((top + f" (vendor library; {len(by_name)} of its kernels were chosen by the first-call timing, this one carries {tot(by_name[top]) / max(tot(timed), 1):.0%} of their time)") if vendor_dominant else "gemm_nt_144s_kernel<ACT, 0>" if n144 else "gemm_nt_256s_kernel<ACT, 0, K2P, false>") + " (the kernel bench.py's roofline.achieved is quoted on)",
+       "hand_written_gemm_variants": hand, "vendor_library_kernels_all_launches_incl_first_call_timing": vendor_share,
        "other_plain_persistent_kernel": {"launches_total": len(r144), "avg_us_all_launches": (avg(r144) if r144 else None)},
        "timed_launches_on_144_row_tiles": n144, "timed_launches_on_256_row_tiles": len(timed) - n144,
        "command": f"rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps {steps} --warmup {warmup} --no-cpu-baseline [+ the flags of the run]",
