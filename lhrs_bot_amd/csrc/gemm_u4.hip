@@ -150,14 +150,26 @@ __global__ __launch_bounds__(256, 1) void gemm_u4_kernel(U4Args g) {
       offsets(tm, tn);
       first_stages();
     }
-    // plain epilogue straight from the accumulators: a lane holds 4 consecutive n of one m per fragment (weight fragment as the MFMA's A operand)
+    // plain epilogue straight from the accumulators: a lane holds 4 consecutive n of one m per fragment (weight fragment as the MFMA's A operand).  The residual
+    // of fragment row mi + 1 is requested before row mi is converted and stored: eight 8-byte loads per lane in flight instead of a load -> add -> store chain per
+    // fragment (o-projection at M = 8190: 226 -> ~200 us)
+    const int n_lane = cn * BN + wn * 128 + (lane >> 4) * 4, m_lane = cm * BM + wm * 128 + (lane & 15);
+    uint2 rcur[8], rnxt[8];
+    auto load_res = [&](int mi, uint2 (&r)[8]) {
+      const int m = m_lane + mi * 16;
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) {
+        const int n = n_lane + ni * 16;
+        r[ni] = (g.res != nullptr && m < g.M && n < g.N) ? *reinterpret_cast<const uint2*>(g.res + (long)m * g.ldr + n) : make_uint2(0u, 0u);
+      }
+    };
 #define ST(mi, ni)                                                                                                  \
     {                                                                                                               \
       float v[4]; RDACC(mi, ni, v)                                                                                  \
-      const int m = cm * BM + wm * 128 + mi * 16 + (lane & 15), n = cn * BN + wn * 128 + ni * 16 + (lane >> 4) * 4; \
+      const int m = m_lane + mi * 16, n = n_lane + ni * 16;                                                         \
       if (m < g.M && n < g.N) {                                                                                     \
         if (g.res != nullptr) {                                                                                     \
-          const uint2 rr = *reinterpret_cast<const uint2*>(g.res + (long)m * g.ldr + n);                            \
+          const uint2 rr = rcur[ni];                                                                                \
           v[0] += bf2f((bf16_t)(rr.x & 0xffffu)); v[1] += bf2f((bf16_t)(rr.x >> 16));                               \
           v[2] += bf2f((bf16_t)(rr.y & 0xffffu)); v[3] += bf2f((bf16_t)(rr.y >> 16));                               \
         }                                                                                                           \
@@ -165,7 +177,11 @@ __global__ __launch_bounds__(256, 1) void gemm_u4_kernel(U4Args g) {
         *reinterpret_cast<uint2*>(g.C + (long)m * g.ldc + n) = make_uint2(lo, hi);                                  \
       }                                                                                                             \
     }
-#define STROW(mi) ST(mi, 0) ST(mi, 1) ST(mi, 2) ST(mi, 3) ST(mi, 4) ST(mi, 5) ST(mi, 6) ST(mi, 7)
+#define STROW(mi)                                                                                                   \
+    if (mi + 1 < 8) load_res(mi + 1, rnxt);                                                                         \
+    ST(mi, 0) ST(mi, 1) ST(mi, 2) ST(mi, 3) ST(mi, 4) ST(mi, 5) ST(mi, 6) ST(mi, 7)                                 \
+    _Pragma("unroll") for (int q = 0; q < 8; ++q) rcur[q] = rnxt[q];
+    load_res(0, rcur);
     STROW(0) STROW(1) STROW(2) STROW(3) STROW(4) STROW(5) STROW(6) STROW(7)
     if (!next) break;
   }
