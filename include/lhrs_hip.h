@@ -218,6 +218,12 @@ int lhrs_gemm_set_u4(int on);
 int lhrs_gemm_u4_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
                     void* stream);
 long lhrs_gemm_u4_problems(void);
+/* the four-wave kernel with RoPE in its epilogue (lhrs_gemm_rope_fwd's semantics without a LoRA pair; bit-identical): u4_rope is the raw launch (0 launched,
+ * 1 not its problem); set_u4_rope(1) / LHRS_GEMM_U4_ROPE=1 makes lhrs_gemm_rope_fwd use it for M >= 1024 without a LoRA pair.  Off by default: 8 % faster back
+ * to back, no faster inside the power-capped step (csrc/gemm.hip) */
+int lhrs_gemm_set_u4_rope(int on);
+int lhrs_gemm_u4_rope(const void* X, int ldx, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const float* cos_t,
+                      const float* sin_t, int pos_mod, int pos0, int rope_cols, void* stream);
 
 /* ---- LoRA gradients (peft lora.Linear backward; lhrs/models/text_modal.py:133-151) ------------------------- *
  * C[KP,N] (+)= P[M,KP]^T . Q[M,N]: dA = (s dy B)^T x and dB^T = (s x A^T)^T dy straight from token-major operands.  */

@@ -1866,6 +1866,15 @@ extern "C" int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int
 // applied in the GEMM epilogue: columns [0, rope_cols) are heads of 128 that get rotated with the position m % pos_mod + pos0 of
 // their row, the remaining columns (v) are stored as computed.  Bit-identical to lhrs_gemm_bf16_nt(_lora) followed by lhrs_rope; that
 // pair is also the fallback when the 256-tile kernel does not apply.
+extern "C" int lhrs_gemm_u4_rope(const void* X, int ldx, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const float* cos_t, const float* sin_t,
+                                 int pos_mod, int pos0, int rope_cols, void* stream);
+static int g_u4_rope = -1;
+extern "C" int lhrs_gemm_set_u4_rope(int on) { g_u4_rope = on ? 1 : 0; return 0; }
+static bool u4_rope_on() {
+  if (g_u4_rope < 0) { const char* e = getenv("LHRS_GEMM_U4_ROPE"); g_u4_rope = (e != nullptr && e[0] == '1') ? 1 : 0; }
+  plain_env();
+  return g_u4_rope == 1 && g_u4_on == 1;   // LHRS_GEMM_U4=0 / lhrs_gemm_set_u4(0): the 16-wave kernels everywhere
+}
 extern "C" int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw, const void* A2, int lda2, const void* B2, int ldb2, int K2,
                                   void* C, int ldc, int M, int N, int K, const float* cos_t, const float* sin_t, int pos_mod, int pos0,
                                   int rope_cols, int head_dim, void* stream) {
@@ -1879,6 +1888,17 @@ extern "C" int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw
     if (gemm_launch(X, ldx, W, ldw, C, ldc, M, N, K, nullptr, nullptr, 0, 0, 0, 0, 1.f, A2, lda2, B2, ldb2, K2, stream)) return -1;
     if (rope_cols == 0) return 0;
     return lhrs_rope(C, ldc, M, rope_cols / head_dim, head_dim, cos_t, sin_t, nullptr, pos_mod, pos0, 0, stream);
+  }
+  // the four-wave kernel's RoPE variant (gemm_u4.hip), OPT-IN (LHRS_GEMM_U4_ROPE=1): same result bit for bit, 666 vs 722 us at M = 8190 and 218 vs 225 at M = 2184
+  // back to back (tools/gemm_u4_rope_ab.py) - but inside the power-capped step 634-636 vs 639 us per launch and no faster a step (156.2-156.9 vs 157.4-157.7
+  // samples/s, two same-box pairs): stall removal converts at 15-20 % there, and at K = 4096 this loop has little else to offer
+  if (K2 == 0 && u4_rope_on() && M >= 1024) {
+    const int pslot = prof_count(M, N, K, 3, (hipStream_t)stream);
+    const int st = lhrs_gemm_u4_rope(X, ldx, W, ldw, C, ldc, M, N, K, cos_t, sin_t, pos_mod, pos0, rope_cols, stream);
+    if (st == 0) { prof_end(pslot, (hipStream_t)stream); return 0; }
+    if (st < 0) return st;
+    if (pslot >= 0) { g_prof.used--; g_prof.seen[3]--; }
+    if (g_prof.on) { g_prof.launches_all--; g_prof.total_flops_all -= 2.0 * M * N * K; }
   }
   GemmArgs g; memset(&g, 0, sizeof(g));
   g.A = (const bf16_t*)X; g.B = (const bf16_t*)W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = ldw; g.ldc = ldc;

@@ -24,6 +24,7 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;
 struct U4Args {
   const bf16_t* A; const bf16_t* B; bf16_t* C; const bf16_t* res;
   int M, N, K, lda, ldb, ldc, ldr, tilesM, tilesN;
+  const float* rope_cos; const float* rope_sin; int rope_mod, rope_pos0, rope_cols;   // ROPE variant: columns [0, rope_cols) are heads of 128, tables [pos][64] f32
 };
 
 __device__ __forceinline__ void u4_tile(const U4Args& g, int t, int& tm, int& tn) {
@@ -36,6 +37,7 @@ __device__ __forceinline__ void u4_tile(const U4Args& g, int t, int& tm, int& tn
   tm = grp * GM + rem % rows; tn = rem / rows;
 }
 
+template <bool ROPE>
 __global__ __launch_bounds__(256, 1) void gemm_u4_kernel(U4Args g) {
   constexpr int BM = 256, BN = 256, BK = 64, A_BYTES = BM * BK * 2, STAGE = A_BYTES + BN * BK * 2;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
@@ -181,26 +183,71 @@ __global__ __launch_bounds__(256, 1) void gemm_u4_kernel(U4Args g) {
     if (mi + 1 < 8) load_res(mi + 1, rnxt);                                                                         \
     ST(mi, 0) ST(mi, 1) ST(mi, 2) ST(mi, 3) ST(mi, 4) ST(mi, 5) ST(mi, 6) ST(mi, 7)                                 \
     _Pragma("unroll") for (int q = 0; q < 8; ++q) rcur[q] = rnxt[q];
-    load_res(0, rcur);
-    STROW(0) STROW(1) STROW(2) STROW(3) STROW(4) STROW(5) STROW(6) STROW(7)
+    // RoPE (HF apply_rotary_pos_emb on q and k, text_modal.py:258-294 via LlamaAttention): a wave's 128 columns are one head; dim d sits in fragment ni = d / 16
+    // (d < 64) and its rotate_half partner d + 64 in fragment ni + 4 of the SAME lane - no exchange.  Both are rounded to bf16 first, exactly as the
+    // unfused pair lhrs_gemm_bf16_nt + lhrs_rope sees them (bit-identical: tests/test_kernels_gpu.py)
+#define ROPE_ST(mi, ni, nj)                                                                                         \
+    {                                                                                                               \
+      float v1[4], v2[4]; RDACC(mi, ni, v1) RDACC(mi, nj, v2)                                                       \
+      const int m = m_lane + mi * 16, n = n_lane + ni * 16;                                                         \
+      if (m < g.M) {                                                                                                \
+        const int pos = m % g.rope_mod + g.rope_pos0, d = ni * 16 + (lane >> 4) * 4;                                \
+        const float4 c4 = *reinterpret_cast<const float4*>(g.rope_cos + (long)pos * 64 + d);                        \
+        const float4 s4 = *reinterpret_cast<const float4*>(g.rope_sin + (long)pos * 64 + d);                        \
+        const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w};                             \
+        float o1[4], o2[4];                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) rope_pair(bf2f(f2bf(v1[i])), bf2f(f2bf(v2[i])), cv[i], sv[i], o1[i], o2[i]); \
+        *reinterpret_cast<uint2*>(g.C + (long)m * g.ldc + n) =                                                      \
+            make_uint2((unsigned)f2bf(o1[0]) | ((unsigned)f2bf(o1[1]) << 16), (unsigned)f2bf(o1[2]) | ((unsigned)f2bf(o1[3]) << 16)); \
+        *reinterpret_cast<uint2*>(g.C + (long)m * g.ldc + n + 64) =                                                 \
+            make_uint2((unsigned)f2bf(o2[0]) | ((unsigned)f2bf(o2[1]) << 16), (unsigned)f2bf(o2[2]) | ((unsigned)f2bf(o2[3]) << 16)); \
+      }                                                                                                             \
+    }
+#define ROPE_ROW(mi) ROPE_ST(mi, 0, 4) ROPE_ST(mi, 1, 5) ROPE_ST(mi, 2, 6) ROPE_ST(mi, 3, 7)
+    if (ROPE && cn * BN < g.rope_cols) {   // tile-uniform (rope_cols % 256 == 0)
+      ROPE_ROW(0) ROPE_ROW(1) ROPE_ROW(2) ROPE_ROW(3) ROPE_ROW(4) ROPE_ROW(5) ROPE_ROW(6) ROPE_ROW(7)
+    } else {
+      load_res(0, rcur);
+      STROW(0) STROW(1) STROW(2) STROW(3) STROW(4) STROW(5) STROW(6) STROW(7)
+    }
     if (!next) break;
   }
 }
 }  // namespace
 
-// 0 launched; 1 not this kernel's problem (the caller takes gemm.hip's kernels); -1 error.  Plain epilogue only: bf16 out, optional bf16 residual.
-extern "C" int lhrs_gemm_u4_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
-                               void* stream) {
-  if (M <= 0 || N <= 0 || K < 128 || K % 64 != 0 || N % 4 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 4 != 0 || (residual != nullptr && ldr % 4 != 0) ||
-      lda < K || ldb < K || ldc < N || ((size_t)A | (size_t)B) % 16 != 0 || ((size_t)C | (size_t)residual) % 8 != 0 ||
-      (long)M * lda * 2 >= (1L << 32) || (long)N * ldb * 2 >= (1L << 32))   // 32-bit lane offsets into an operand
-    return 1;
-  U4Args g{(const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, (const bf16_t*)residual, M, N, K, lda, ldb, ldc, ldr, (M + 255) / 256, (N + 255) / 256};
+static bool u4_addressable(const void* A, int lda, const void* B, int ldb, const void* C, int ldc, int M, int N, int K) {
+  return M > 0 && N > 0 && K >= 128 && K % 64 == 0 && N % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && lda >= K && ldb >= K && ldc >= N &&
+         ((size_t)A | (size_t)B) % 16 == 0 && (size_t)C % 8 == 0 && (long)M * lda * 2 < (1L << 32) && (long)N * ldb * 2 < (1L << 32);   // 32-bit lane offsets
+}
+static dim3 u4_grid(const U4Args& g) {
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const int tiles = g.tilesM * g.tilesN;
-  hipLaunchKernelGGL(gemm_u4_kernel, dim3(tiles < cus ? tiles : cus), dim3(256), 0, (hipStream_t)stream, g);
+  return dim3(tiles < cus ? tiles : cus);
+}
+
+// 0 launched; 1 not this kernel's problem (the caller takes gemm.hip's kernels); -1 error.  Plain epilogue only: bf16 out, optional bf16 residual.
+extern "C" int lhrs_gemm_u4_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
+                               void* stream) {
+  if (!u4_addressable(A, lda, B, ldb, C, ldc, M, N, K) || (residual != nullptr && (ldr % 4 != 0 || (size_t)residual % 8 != 0))) return 1;
+  U4Args g{(const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, (const bf16_t*)residual, M, N, K, lda, ldb, ldc, ldr, (M + 255) / 256, (N + 255) / 256,
+           nullptr, nullptr, 1, 0, 0};
+  hipLaunchKernelGGL(gemm_u4_kernel<false>, u4_grid(g), dim3(256), 0, (hipStream_t)stream, g);
   LHRS_CHECK_LAUNCH("gemm_u4_nt");
+  return 0;
+}
+
+// q|k|v projection with RoPE in the epilogue (the semantics of lhrs_gemm_rope_fwd without a LoRA pair): columns [0, rope_cols) are heads of 128 rotated with
+// the position m % pos_mod + pos0 of their row, the rest stored as computed.  0 launched; 1 not this kernel's problem.
+extern "C" int lhrs_gemm_u4_rope(const void* X, int ldx, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const float* cos_t, const float* sin_t,
+                                 int pos_mod, int pos0, int rope_cols, void* stream) {
+  if (!u4_addressable(X, ldx, W, ldw, C, ldc, M, N, K) || rope_cols % 256 != 0 || rope_cols > N || pos_mod <= 0 || cos_t == nullptr || sin_t == nullptr ||
+      ((size_t)cos_t | (size_t)sin_t) % 16 != 0)
+    return 1;
+  U4Args g{(const bf16_t*)X, (const bf16_t*)W, (bf16_t*)C, nullptr, M, N, K, ldx, ldw, ldc, 0, (M + 255) / 256, (N + 255) / 256,
+           cos_t, sin_t, pos_mod, pos0, rope_cols};
+  hipLaunchKernelGGL(gemm_u4_kernel<true>, u4_grid(g), dim3(256), 0, (hipStream_t)stream, g);
+  LHRS_CHECK_LAUNCH("gemm_u4_rope");
   return 0;
 }

@@ -595,6 +595,15 @@ def test_gemm_fused_rope_bit_identical_to_unfused(M, S, pos0, lora):
     fr = torch.outer(torch.arange(512).float(), inv)
     cos, sin = fr.cos().to(DEV).contiguous(), fr.sin().to(DEV).contiguous()
     got = hk.gemm_rope_fwd(x, w, cos, sin, pos_mod=S, pos0=pos0, rope_cols=2 * d, head_dim=hd, a2=a2, b2=b2)
+    if not lora and M >= 1024:   # the four-wave kernel's RoPE variant (csrc/gemm_u4.hip: partners d / d + 64 in one lane; opt-in, LHRS_GEMM_U4_ROPE=1)
+        from lhrs_bot_amd import _lib
+        raw = torch.zeros_like(got)
+        assert _lib.load().lhrs_gemm_u4_rope(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), raw.data_ptr(), raw.stride(0), M, 3 * d, d, cos.data_ptr(),
+                                             sin.data_ptr(), S, pos0, 2 * d, torch.cuda.current_stream().cuda_stream) == 0
+        assert torch.equal(raw, got)
+        hk.gemm_set_u4(True); _lib.load().lhrs_gemm_set_u4_rope(1)          # opt-in route through lhrs_gemm_rope_fwd
+        assert torch.equal(hk.gemm_rope_fwd(x, w, cos, sin, pos_mod=S, pos0=pos0, rope_cols=2 * d, head_dim=hd), got)
+        hk.gemm_set_u4(False); _lib.load().lhrs_gemm_set_u4_rope(0)
     ref = hk.gemm_nt_lora(x, w, a2, b2) if lora else hk.gemm_nt(x, w)
     plain = ref.clone()
     hk.rope_(ref, M, 2 * d // hd, hd, cos, sin, pos_mod=S, pos0=pos0)
