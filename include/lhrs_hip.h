@@ -191,7 +191,8 @@ int lhrs_gemm_profile_enable(int max_samples);
 int lhrs_gemm_profile_stride(int n);
 int lhrs_gemm_profile_read(double* out5_host);
 int lhrs_gemm_profile_read_kinds(double* out21_host);
-/* plain long-k products (no bias, no activation, bf16 out, alpha 1, K >= min_k, M and N >= 1024) are offered to the vendor library first
+/* plain long-k products (the decoder's nn.Linear calls without a fused epilogue: lhrs/models/text_modal.py:133-151, 258-294; no bias, no activation, bf16 out, alpha 1,
+ * K >= min_k, M and N >= 1024) are decided by a first-call timing in which the vendor library is one candidate
  * (hipBLASLt, looked up in the process at run time - csrc/vendor.cpp; same-box A/B +7 % on the stage-1 step); everything with a fused epilogue
  * stays on the hand-written kernels.  set_vendor(0, 0) keeps every product on them (env LHRS_GEMM_VENDOR=0); vendor_takes() = 1 when
  * lhrs_gemm_bf16_nt will offer that problem; vendor_status() names the library copy in use, or why none is ("" before the first offer);
@@ -209,7 +210,8 @@ int lhrs_vendor_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C,
 int lhrs_vendor_gemm_tune(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual,
                           int ldr, void* workspace, long workspace_bytes, int reps, float* best_us, void* stream);
 int lhrs_gemm_vendor_stats(long* out3_host);
-/* gemm_u4_kernel (csrc/gemm_u4.hip): the hand-written four-wave kernel for the same plain long-k products - 256x256x64 tile, 128x128 per wave, AGPR
+/* gemm_u4_kernel (csrc/gemm_u4.hip): the hand-written four-wave kernel for the same plain long-k products (the nn.Linear calls of HF LlamaDecoderLayer / lm_head with
+ * no fused epilogue, reached from lhrs/models/text_modal.py:133-151, 258-294) - 256x256x64 tile, 128x128 per wave, AGPR
  * accumulators, paced LDS-DMA, persistent; bit-identical to gemm_nt_256s_kernel without a residual (a residual joins the fp32 sum before the one rounding)
  * and 5-18 % faster on these shapes.  It is the third candidate of the
  * first-call timing (set_u4(0) / LHRS_GEMM_U4=0 removes it); u4_nt is the raw launch: 0 launched, 1 not its problem (K % 64, K < 128, alignment), -1 error;
