@@ -267,37 +267,28 @@ PROFILE_STRIDE = int(os.environ.get("LHRS_GEMM_PROFILE_STRIDE", "7"))
 GEMM_KERNEL_DESC = ("gemm_nt_256s_kernel<ACT, 0, K2P, false> (256x256 tile, 16 waves): BK=64 double-buffered LDS stages via global_load_lds DMA, "
                     "v_mfma_f32_16x16x32_bf16, persistent over tiles; its launches with a fused SwiGLU / RoPE epilogue and the plain launches of the 144-row "
                     "kernel (ViT / projector products) are timed separately under `variants`")
-GEMM_VENDOR_DESC = ("hipBLASLt Custom_Cijk_Alik_Bljk_BBS_BH_..._SK3_UserArgs_MT256x256x64_MI16x16x1 (vendor assembly: 256x256x64 tile, 4 waves of 128x128, stream-K over "
-                    "256 persistent workgroups) on the PLAIN long-k products (down / o projections, the dX products, lm_head: csrc/vendor.cpp, LHRS_GEMM_VENDOR=0 turns "
-                    "it off); every product with a fused epilogue runs the hand-written gemm_nt_256s_kernel, timed separately under `variants`")
 GEMM_U4_DESC = ("gemm_u4_kernel (csrc/gemm_u4.hip; hand-written): 256x256x64 tile, FOUR waves of 128x128, accumulators in named AGPRs, two 64 KiB LDS stages via paced "
-                "global_load_lds DMA (one piece per 6 MFMAs), v_mfma_f32_16x16x32_bf16, persistent - on the PLAIN long-k products it wins in the first-call timing; the "
-                "fused-epilogue launches of gemm_nt_256s_kernel and the vendor library's share are under `variants`")
+                "global_load_lds DMA (one piece per 6 MFMAs), v_mfma_f32_16x16x32_bf16, persistent - every PLAIN long-k product whose tiles fill the chip (a shape rule in "
+                "lhrs_gemm_bf16_nt: no timing, no vendor library); the fused-epilogue launches are timed separately under `variants`")
 GEMM_144_DESC = ("gemm_nt_144s_kernel<ACT, 0> (144x256 tile, 12 waves, three 50 KiB LDS stages): the plain-epilogue kernel that carries the most time at this "
                  "micro-batch; the 256-row kernel's variants are listed under `variants`")
 
 
 def plain_products_note(lib):
-    import ctypes
-    where = (lib.lhrs_gemm_vendor_status() or b"").decode()
-    st = (ctypes.c_long * 3)()
-    lib.lhrs_gemm_vendor_stats(ctypes.addressof(st))
-    if not where and st[0] == 0:
-        return "hand-written kernels (vendor library off)"
-    u4 = int(lib.lhrs_gemm_u4_problems())
-    return (f"{where or 'vendor library off'}: {st[0]} problems timed on their first call, {st[1]} went to the library's kernel, {u4} to the hand-written 4-wave "
-            f"gemm_u4_kernel, {st[2] - u4} stayed on the 16-wave kernels (csrc/gemm.hip: lhrs_gemm_bf16_nt)")
+    return ("hand-written only: a plain long-k product (no bias / activation, bf16 out, K >= 4096, M and N >= 1024) whose 256x256 tiles fill >= 80 % of one round "
+            "of the CUs runs the four-wave gemm_u4_kernel, every other product the 16-wave / 144-row / small-tile kernels of csrc/gemm.hip - a pure shape rule "
+            "(lhrs_gemm_u4_takes): no first-call timing, no vendor library in the process path, bit-reproducible run to run and rank to rank")
 
 
 def roofline_block(prof, kinds, steps, B, S, scale_layers, sclk=None, watts=None):
     """`achieved` is ONE kernel's figure: the plain-epilogue 256x256 persistent kernel (kind 0, `gemm_nt_256s_kernel<ACT, 0, K2P, false>` in a rocprofv3
     kernel trace) - or, when that kernel carries less time than the plain 144-row kernel (kind 4: micro-batch 8), that one - so that its
     `avg_launch_us` can be held against the kernel's average duration in profiles/*_kernel_stats.csv; the other kinds are listed under `variants`."""
-    dom = max((0, 4, 5, 6), key=lambda k: kinds[3 * k + 1])   # among the PLAIN-epilogue kernels: the one that carries the most (sampled) time
+    dom = max((0, 4, 6), key=lambda k: kinds[3 * k + 1])   # among the PLAIN-epilogue kernels: the one that carries the most (sampled) time
     n_samp, ms, fl = kinds[3 * dom], kinds[3 * dom + 1], kinds[3 * dom + 2]
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     vnames = ("<ACT,0> plain, 256-row tiles", "<0,1> SwiGLU-fwd epilogue", "<0,2> SwiGLU-bwd epilogue", "<0,3> RoPE epilogue", "<ACT,0> plain, 144-row tiles (gemm_nt_144s_kernel)",
-              "plain long-k products in the vendor library (hipBLASLt assembly kernel, 256x256x64 tile)",
+              "(unused)",
               "plain long-k products on gemm_u4_kernel (4 waves of 128x128, hand-written)")
     variants = {}
     for k, nm in enumerate(vnames):
@@ -308,8 +299,7 @@ def roofline_block(prof, kinds, steps, B, S, scale_layers, sclk=None, watts=None
                             "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
     all_ms = sum(kinds[3 * k + 1] for k in range(7))
     all_fl = sum(kinds[3 * k + 2] for k in range(7))
-    hand_ms = sum(kinds[3 * k + 1] for k in range(7) if k != 5)
-    hand_fl = sum(kinds[3 * k + 2] for k in range(7) if k != 5)
+    hand_ms, hand_fl = all_ms, all_fl   # every GEMM launch is one of this library's kernels (round 4 had a vendor-library candidate: kind 5, gone)
     # HBM-side bytes per launch of the dominant kernel: a PMC pass cannot run inside this process (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE are
     # separate profiled runs of this same command); the committed summary of that pass on this tree is quoted, with its provenance
     traffic, traffic_note = None, "not measured in this run (PMC passes are separate rocprofv3 runs)"
@@ -323,7 +313,7 @@ def roofline_block(prof, kinds, steps, B, S, scale_layers, sclk=None, watts=None
                             "every XCD streams its own copy of the operand panels); NOT measured in this process")
     except Exception:  # noqa: BLE001
         pass
-    return {"bound": "mfma", "kernel": {0: GEMM_KERNEL_DESC, 4: GEMM_144_DESC, 5: GEMM_VENDOR_DESC, 6: GEMM_U4_DESC}[dom], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+    return {"bound": "mfma", "kernel": {0: GEMM_KERNEL_DESC, 4: GEMM_144_DESC, 6: GEMM_U4_DESC}[dom], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "traffic_note": traffic_note,
             "variants": variants, "all_variants_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else None,

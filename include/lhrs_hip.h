@@ -92,20 +92,6 @@ int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int ldw, const
                          int K2, void* gu, int ld_gu, void* act, int ld_act, int M, int ff, int K, void* stream);
 int lhrs_gemm_swiglu_bwd(const void* dY, int ldy, const void* WdT, int ldw, const void* A2, int lda2, const void* B2, int ldb2,
                          int K2, const void* gu, void* dgu, int ld_gu, void* dact_scratch, int M, int ff, int K, void* stream);
-/* ---- RMSNorm backward inside the dX GEMM (no pass of its own over HBM; HF LlamaRMSNorm in front of LlamaMLP, text_modal.py:281-292) ----
- * The backward of h = w o (x * rstd) needs c = sum_j dh_j w_j x_j over the whole row of dh = d(gate|up) . W_gu; since c = (1 / rstd) *
- * <d(gate|up), gate|up>, the fused d-down + SwiGLU' launch can emit it: lhrs_gemm_swiglu_bwd_rowdot = lhrs_gemm_swiglu_bwd that also writes
- * row_dot [4 * ff / 256][M] fp32 partial sums; lhrs_rowsum_partials folds them into s [M] in a fixed order; lhrs_gemm_rmsnorm_bwd computes
- * out = rstd * (w o (dY . WT^T)) - x * (rstd^2 * s / N) + add in the epilogue of the dX GEMM (dY [M, K], WT [N, K] = transposed weight copy,
- * x / add / out [M, N], w [N] bf16, rstd / s [M] fp32; add may be NULL).  Only where lhrs_gemm_rmsnorm_bwd_fusable(M, d, ff) == 1 (both
- * products whole rounds of the 256-row persistent kernel); elsewhere callers keep lhrs_gemm_swiglu_bwd -> lhrs_gemm_bf16_nt -> lhrs_rmsnorm_bwd.
- * Same function up to rounding: dh is used as the unfused path stores it (bf16), s comes from the stored bf16 d(gate|up) and gate|up. */
-int lhrs_gemm_rmsnorm_bwd_fusable(int M, int d, int ff);
-int lhrs_gemm_swiglu_bwd_rowdot(const void* dY, int ldy, const void* WdT, int ldw, const void* gu, void* dgu, int ld_gu, float* row_dot,
-                                int M, int ff, int K, void* stream);
-int lhrs_rowsum_partials(const float* part, float* out, int P, int M, void* stream);
-int lhrs_gemm_rmsnorm_bwd(const void* dY, int ldy, const void* WT, int ldw, const void* x, int ldx, const void* w, const float* rstd,
-                          const float* s_row, const void* add, int ld_add, void* out, int ldo, int M, int N, int K, void* stream);
 /* qkv projection with the RoPE of its q / k heads in the GEMM epilogue (HF LlamaAttention.forward: apply_rotary_pos_emb on
  * q_proj / k_proj outputs, rotate_half convention; text_modal.py:258-294): C[M, N] = X.W^T (+ A2.B2^T); the heads of width
  * head_dim in columns [0, rope_cols) are rotated with position m %% pos_mod + pos0 of their row (cos / sin fp32 [pos][head_dim/2]),
@@ -119,8 +105,7 @@ int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw, const voi
 int lhrs_dropout_bf16(const void* x, long ldx, void* out, long ldo, long rows, int cols, float p, unsigned seed, void* stream);
 int lhrs_gemm_bf16_nt_dropmask(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                                const void* residual, int ldr, float alpha, float p, unsigned seed, void* stream);
-/* 256x256-tile kernel choice (tuning / A-B tests): 0 never, 2 default (16-wave BK=64 two-buffer kernel when K % 64 == 0, else the BK=32
- * ring), 4 always the BK=32 ring */
+/* persistent big-tile kernels (tuning / A-B tests): 0 never (small tiles only), non-zero = default */
 int lhrs_gemm_set_policy(int allow_256);
 /* kernel A/B tests only: 0 disables the tail-row rule (a product whose last round of 256x256 tiles would be nearly empty is cut into
  * whole tile rows for the 16-wave kernel + the remaining rows for the small-tile kernel); default 1 */
@@ -134,25 +119,13 @@ int lhrs_gemm_set_persistent(int on);
  * is 16 x 16 = 256 tiles of 144 x 256 instead of 144 tiles of 256 x 256 -, 2 = 144 rows wherever the kernel applies (A/B tests).  Results
  * are bit-identical between the two tile heights. */
 int lhrs_gemm_set_bm144(int mode);
-/* ---- stream-K for the last, partial round of the persistent 256x256 kernel (no reference counterpart: the reference's GEMMs are torch /
- * hipBLASLt calls reached from lhrs/models/text_modal.py:258-294; this removes the wave-quantisation loss of OUR tile walk) ---------------
- * T tiles on P CUs cost ceil(T / P) rounds; with a workspace registered the T % P tiles of the last round are cut along k into P contiguous
- * ranges of 64-k stages (one per CU), partial fp32 accumulators travel through the workspace, the CU that holds a tile's first stage adds
- * them in a fixed order and runs the (fused) epilogue.  Deterministic; differs from the unsplit kernel by fp32 re-association only.
- * The workspace is CALLER-OWNED device memory of lhrs_gemm_streamk_workspace_bytes() bytes, 256-B aligned, registered per device; every
- * GEMM launch that may use it must be ordered on one stream.  ws = NULL unregisters.  A second user of the same workspace, always on while
- * it is registered: the tail rows of a row-split product (M = 8736: 8192 rows on 256-row tiles + 544 rows) with K >= 8192 are computed
- * split-K (f32 slabs per K slice, summed in a fixed order together with the residual) instead of by 160 small tiles walking all of K.
- * lhrs_gemm_set_streamk(0 | 1): default 0 - measured slower than whole rounds at every shape of the path on MI355X (the k-ranges lose the L2
- * sharing of operand panels between the tiles of an XCD, and the slab exchange is exposed; numbers in csrc/gemm.hip and DESIGN.md §3.1). */
-long lhrs_gemm_streamk_workspace_bytes(void);
-int lhrs_gemm_set_streamk_workspace(void* ws, long bytes);
-int lhrs_gemm_set_streamk(int on);
-/* host replay of the decomposition (tests; launches nothing): T tiles of nk stages, nk2 of them from the second operand pair; returns -1
- * when stream-K does not apply, else out[0..2] = {tiles of the whole rounds, stream-K tiles, units} and, for unit >= 0, out[3..9] = {first
- * tile of the unit's range, first stage there, stages in that tile, stages in the next tile, first item is a partial, partials added to the
- * first / second item}.  assume_ws != 0: plan as if a workspace were registered (CPU tests). */
-int lhrs_gemm_streamk_plan(long T, int nk, int nk2, int assume_ws, int unit, int* out);
+/* ---- the GEMM workspace (no reference counterpart: the reference's GEMMs are torch calls reached from lhrs/models/text_modal.py:258-294) ----
+ * CALLER-OWNED device memory of lhrs_gemm_workspace_bytes() bytes, 256-B aligned, registered per device; every GEMM launch that may use it must
+ * be ordered on one stream.  ws = NULL unregisters.  One user, on while it is registered: the tail rows of a row-split product (M = 8736:
+ * 8192 rows on 256-row tiles + 544 rows) with K >= 8192 are computed split-K (f32 slabs per K slice, summed in a fixed order together with
+ * the residual) instead of by 160 small tiles walking all of K. */
+long lhrs_gemm_workspace_bytes(void);
+int lhrs_gemm_set_workspace(void* ws, long bytes);
 /* ---- LLM.int8() base (the reference's `bits: 8`: lhrs/models/text_modal.py:91-131 -> bitsandbytes MatMul8bitLt, 0.41 series) --------------
  * weights once: lhrs_quant_int8_rows -> int8 rows + factor absmax / 127 per row; lhrs_dequant_int8_rows -> the 16-bit weight CB * factor that
  * the backward (dx = dy . dequant(W)) and generate() use.  Per product: lhrs_int8_prepare scans x for outlier columns (any |x| >= thr = 6.0),
@@ -184,42 +157,24 @@ int lhrs_gemm_set_min_tiles(int n);
 /* live HIP-event timing of the 16-wave 256x256 GEMM launches, on their launch stream, for bench.py's roofline leg (gemm.hip):
  * enable(n) arms n event pairs (0 = off); read() -> {launches of the plain-epilogue persistent kernels (256-row + 144-row tiles), their ms, their
  * flops, all GEMM launches, all GEMM flops}; read_kinds() -> [7][3] = {launches, ms, flops} per kind: 0 plain <ACT,0> of the 256x256 kernel,
- * 1 SwiGLU fwd, 2 SwiGLU bwd, 3 RoPE epilogue of the same kernel, 4 the plain 144-row kernel, 5 plain products handed to the vendor library,
+ * 1 SwiGLU fwd, 2 SwiGLU bwd, 3 RoPE epilogue (16-wave or four-wave kernel, whichever the shape rule took), 4 the plain 144-row kernel, 5 unused,
  * 6 plain products on the four-wave gemm_u4_kernel */
 int lhrs_gemm_profile_enable(int max_samples);
 /* bracket only every n-th launch of each epilogue variant (default 1): the event records themselves cost stream time (1-2 % of a step) */
 int lhrs_gemm_profile_stride(int n);
 int lhrs_gemm_profile_read(double* out5_host);
 int lhrs_gemm_profile_read_kinds(double* out21_host);
-/* plain long-k products (the decoder's nn.Linear calls without a fused epilogue: lhrs/models/text_modal.py:133-151, 258-294; no bias, no activation, bf16 out, alpha 1,
- * K >= min_k, M and N >= 1024) are decided by a first-call timing in which the vendor library is one candidate
- * (hipBLASLt, looked up in the process at run time - csrc/vendor.cpp; same-box A/B +7 % on the stage-1 step); everything with a fused epilogue
- * stays on the hand-written kernels.  set_vendor(0, 0) keeps every product on them (env LHRS_GEMM_VENDOR=0); vendor_takes() = 1 when
- * lhrs_gemm_bf16_nt will offer that problem; vendor_status() names the library copy in use, or why none is ("" before the first offer);
- * lhrs_vendor_gemm_nt is the raw call: 0 launched, 1 not taken (no library / no algorithm), -1 error. */
-int lhrs_gemm_set_vendor(int on, int min_k);
-int lhrs_gemm_vendor_takes(int M, int N, int K, int lda, int ldb, int ldc, int ldr, int has_bias, int act, int out_f32, int accumulate,
-                           float alpha);
-const char* lhrs_gemm_vendor_status(void);
-int lhrs_vendor_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual,
-                        int ldr, void* workspace, long workspace_bytes, void* stream);
-/* the first call of lhrs_gemm_bf16_nt on such a problem decides by measurement (1 + 3 launches of every algorithm the library's heuristic offers -
- * lhrs_vendor_gemm_tune keeps the fastest - against 1 + 3 launches of the hand-written kernel, on the caller's operands and stream, host-synchronous);
- * the library is taken when it is more than 3 % faster.  Not on a capturing stream, not when C aliases an input, at most 96 problems per process
- * (then: hand-written).  vendor_stats -> {problems decided, -> library, -> hand-written}; LHRS_GEMM_VENDOR_LOG=1 prints each decision to stderr. */
-int lhrs_vendor_gemm_tune(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual,
-                          int ldr, void* workspace, long workspace_bytes, int reps, float* best_us, void* stream);
-int lhrs_gemm_vendor_stats(long* out3_host);
-/* gemm_u4_kernel (csrc/gemm_u4.hip): the hand-written four-wave kernel for the same plain long-k products (the nn.Linear calls of HF LlamaDecoderLayer / lm_head with
- * no fused epilogue, reached from lhrs/models/text_modal.py:133-151, 258-294) - 256x256x64 tile, 128x128 per wave, AGPR
- * accumulators, paced LDS-DMA, persistent; bit-identical to gemm_nt_256s_kernel without a residual (a residual joins the fp32 sum before the one rounding)
- * and 5-18 % faster on these shapes.  It is the third candidate of the
- * first-call timing (set_u4(0) / LHRS_GEMM_U4=0 removes it); u4_nt is the raw launch: 0 launched, 1 not its problem (K % 64, K < 128, alignment), -1 error;
- * u4_problems(): how many timed problems it won.  vendor_stats()[2] counts both hand-written kernels. */
+/* gemm_u4_kernel (csrc/gemm_u4.hip): the hand-written four-wave kernel for the plain long-k products (the nn.Linear calls of HF LlamaDecoderLayer / lm_head with
+ * no fused epilogue, reached from lhrs/models/text_modal.py:133-151, 258-294: no bias, no activation, bf16 out, alpha 1, K >= 4096, M and N >= 1024) -
+ * 256x256x64 tile, 128x128 per wave, AGPR accumulators, paced LDS-DMA, persistent; bit-identical to gemm_nt_256s_kernel without a residual (a residual joins
+ * the fp32 sum before the one rounding) and 5-18 % faster on these shapes.  lhrs_gemm_bf16_nt takes it by a SHAPE rule (its 256x256 tiles fill >= 80 % of one
+ * round of the CUs): u4_takes() is that rule, a pure function of its arguments - no timing, no cache: runs are bit-reproducible and every data-parallel rank
+ * runs the same kernels.  set_u4(0) / LHRS_GEMM_U4=0: the 16-wave kernels everywhere (kernel A/B tests).  u4_nt is the raw launch: 0 launched, 1 not its
+ * problem (K % 64, K < 128, alignment), -1 error. */
 int lhrs_gemm_set_u4(int on);
+int lhrs_gemm_u4_takes(int M, int N, int K, int lda, int ldb, int ldc, int ldr, int has_bias, int act, int out_f32, int accumulate, float alpha);
 int lhrs_gemm_u4_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
                     void* stream);
-long lhrs_gemm_u4_problems(void);
 /* the four-wave kernel with RoPE in its epilogue (lhrs_gemm_rope_fwd's semantics without a LoRA pair; bit-identical): u4_rope is the raw launch (0 launched,
  * 1 not its problem); set_u4_rope(1) / LHRS_GEMM_U4_ROPE=1 makes lhrs_gemm_rope_fwd use it for M >= 1024 without a LoRA pair.  Off by default: 8 % faster back
  * to back, no faster inside the power-capped step (csrc/gemm.hip) */
@@ -431,13 +386,11 @@ int lhrs_image_preprocess(const unsigned char* img, int H, int W, long row_strid
  * lhrs_llama_layer_backward: d loss / d x_out -> d loss / d x (activation gradients only: the weights are frozen), what engine.backward
  *   (lhrs/CustomTrainer/hook/deepspeed_hook.py:6-9) does inside one decoder layer.  *_wT = transposed weight copies; gu is overwritten
  *   with d(gate|up); scratch dh, d_o [B*S, d], dqkv [B*S, 3d], delta f32 [B, heads, LT], dact [B*S, ff] (NULL allowed when
- *   lhrs_gemm_swiglu_fusable() == 1); dx_in [B*S, d].  Optional (NULL = off): rstd2 f32 [B*S] as the forward saved it + scratch rowdot_part
- *   f32 [4 * ff / 256][B*S] and rowdot_sum f32 [B*S]: where lhrs_gemm_rmsnorm_bwd_fusable says so, the second norm's backward then rides in the
- *   d-gate|up GEMM's epilogue instead of being a pass of its own.
+ *   lhrs_gemm_swiglu_fusable() == 1); dx_in [B*S, d].
  * Both compose the operator entry points above in the order lhrs_bot_amd/text.py uses (bit-identical results); caller-owned buffers. */
 int lhrs_llama_layer_forward(const void* x, const void* ln1_w, const void* qkv_w, const void* o_w, const void* ln2_w, const void* gu_w,
                              const void* down_w, const float* cos_t, const float* sin_t, const int* desc, int B, int S, int LT, int d,
-                             int heads, int ff, float eps, void* h, void* qkv, void* o, float* lse, void* x_mid, float* rstd2, void* gu,
+                             int heads, int ff, float eps, void* h, void* qkv, void* o, float* lse, void* x_mid, void* gu,
                              void* act, void* x_out, void* stream);
 /* one pre-LN encoder layer of the frozen CLIP ViT IN PLACE on x [B * n, d] (HF CLIPEncoderLayer, reached from VisionModal.encode,
  * lhrs/models/rgb_vision_modal.py:166-179): LN -> qkv (+bias) -> attention (no mask) -> out_proj (+bias, +x) -> LN -> fc1 (+bias, quick_gelu)
@@ -450,7 +403,7 @@ int lhrs_llama_layer_backward(const void* dx_out, const void* x_in, const void* 
                               void* gu, const void* ln1_w, const void* ln2_w, const void* qkv_wT, const void* o_wT, const void* gu_wT,
                               const void* down_wT, const float* cos_t, const float* sin_t, const int* desc, int B, int S, int LT, int d,
                               int heads, int ff, float eps, void* dh, void* d_o, void* dqkv, float* delta, void* dact, void* dx_in,
-                              const float* rstd2, float* rowdot_part, float* rowdot_sum, void* stream);
+                              void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@
 //     filled by direct-to-LDS DMA (global_load_lds_dwordx4, no VGPR round trip), one barrier per stage, PERSISTENT over tiles (one workgroup
 //     per CU; the next tile's first stage is fetched under the epilogue), fused epilogues: bias / activation / residual / dropout mask
 //     (EPI 0), SwiGLU forward / backward (EPI 1 / 2), RoPE (EPI 3).
-//   * gemm_nt_256p_kernel - K % 64 != 0 fallback of the above (BK = 32, 4-deep ring, 8 waves).
+//   * gemm_u4_kernel (gemm_u4.hip) - the four-wave 256x256x64 kernel for the plain long-k products.
 //   * gemm_nt_kernel<WM, WN> - 128x128 / 64x128 / 64x64 tiles, 4 waves, for the small products of the ViT and the projector.
 //   * e4m3 siblings (gemm_fp8_256_kernel, gemm_fp8_small_kernel) for the 8-bit frozen base of stages 2/3.
 // Common to all:
@@ -52,13 +52,7 @@ struct GemmArgs {
   //   epi 1: B = [gate; up] weight [2*ff, K]; tile tn holds gate AND up of columns [tn*128, +128) (wave wn: 32 gate + 32 up);
   //          C = gate|up [M, 2*ff] in the usual layout, aux_out = silu(gate) * up [M, ff]
   //   epi 2: A.B^T = d_act [M, ff]; aux = gate|up [M, 2*ff]; C = d(gate|up) [M, 2*ff] (may alias aux)
-  //   epi 5: epi 2, and row_dot[(tn * 4 + wn) * M + m] = sum over the wave's 64 columns of d(gate|up) * gate|up (fp32) - the partial sums of
-  //          the row dot product <d(gate|up), gate|up> that the RMSNorm backward behind the NEXT product needs (epi 4)
-  //   epi 4: RMSNorm backward in the epilogue (HF LlamaRMSNorm, no recompute): A.B^T = dh = d loss / d (normalised row) [M, N], N = the whole
-  //          normalised width; C = rstd * (w o dh) - x * (rstd^2 * s / N) + add with x = aux [M, ld_aux], add = res [M, ldr] (may be null),
-  //          w = bias [N], rstd = sa [M], s = sb [M] = sum_j dh_j w_j x_j * rstd (= <d(gate|up), gate|up> of the linear the norm feeds)
   int epi, ff;
-  float* row_dot;
   const bf16_t* aux;
   bf16_t* aux_out;
   long ld_aux;
@@ -78,16 +72,6 @@ struct GemmArgs {
   // 8-bit kernels: bf16 columns of the second pair whose count is only known on the device (LLM.int8 outlier columns; a multiple of 64),
   // appended behind the K2 host-known ones (nullptr = none)
   const int* k2_dev;
-  // persistent 16-wave kernel: the tiles one launch walks are the raster positions [0, ntiles) (ntiles = tilesM * tilesN unless a stream-K
-  // launch takes the positions behind them)
-  int ntiles;
-  // stream-K launch (gemm_nt_256s_kernel<..., SK = true>): the raster positions [sk_tile0, sk_tile0 + sk_tiles) - the tiles of the last,
-  // partial round of the CUs - are cut along k into sk_units contiguous ranges of stages, one per workgroup; a workgroup whose range starts
-  // inside a tile writes its fp32 accumulators to slab `unit` of sk_ws and raises sk_flags[unit]; the workgroup that holds the tile's stage
-  // 0 adds the slabs of the others and runs the epilogue (the caller owns sk_ws / sk_flags; the flags are zero between launches)
-  int sk_tile0, sk_tiles, sk_units;
-  float* sk_ws;
-  int* sk_flags;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -271,247 +255,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 
 
 // ------------------------------------------------------------------------------------------------
-// 256x256 tile, 8 waves (2 x 4), BK = 32 stages in a 4-deep LDS ring (128 KiB), DMA two stages ahead; the ds_read of the NEXT k-step is in
-// flight while the MFMAs of the current k-step issue, so LDS latency never sits in front of the matrix pipe.
-// Fragment reads are inline asm (hipcc would otherwise place an lgkmcnt(0) right before every consumer, i.e.
-// behind the reads just issued); every wait is an explicit lgkmcnt(0) placed BEFORE the next batch of reads, so
-// it only ever covers reads issued one 8-MFMA block (>= 256 cycles) earlier.
-//   per iteration i (stage i+1 is published by the barrier):
-//     vmcnt(4) ; barrier ; DMA(stage i+3) ; wait ; read k0(i+1)->set0 ; 8 MFMA set1=k1(i) ; wait ; read k1(i+1)->set1 ;
-//     8 MFMA set0
-//   WAR on LDS: buffer (i+3)&3 held stage i-1, whose last reads (k1) completed before MFMA k1(i-1) issued, which every
-//   wave did before reaching this iteration's barrier.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lds_read6(bf16x8 (&a)[4], bf16x8 (&b)[2], unsigned a_addr, unsigned b_addr) {
-  asm volatile(
-      "ds_read_b128 %0, %6\n\t"
-      "ds_read_b128 %1, %6 offset:2048\n\t"
-      "ds_read_b128 %2, %7\n\t"
-      "ds_read_b128 %3, %7 offset:2048\n\t"
-      "ds_read_b128 %4, %7 offset:4096\n\t"
-      "ds_read_b128 %5, %7 offset:6144"
-      : "=&v"(b[0]), "=&v"(b[1]), "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3])
-      : "v"(b_addr), "v"(a_addr));
-}
-__device__ __forceinline__ void lds_wait6(bf16x8 (&a)[4], bf16x8 (&b)[2]) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-#define LDS_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
-
-template <int ACT>
-__global__ __launch_bounds__(512, 2) void gemm_nt_256p_kernel(GemmArgs g) {
-  constexpr int BM = 256, BN = 256, BK = 32, NS = 4;
-  constexpr int A_BYTES = BM * BK * 2, STAGE = A_BYTES + BN * BK * 2;
-  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
-
-  int tm, tn;
-  tile_coords(g, tm, tn);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  const int lrow = lane >> 2;
-  const int lchunk = (lane & 3) ^ ((lane >> 4) & 3);
-  const bf16_t* src[4];
-  int dst_off[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int idx = wave * 4 + j;
-    if (idx < 16) {
-      const int row = min(tm * BM + idx * 16 + lrow, g.M - 1);
-      src[j] = g.A + (long)row * g.lda + lchunk * 8;
-      dst_off[j] = idx * 1024;
-    } else {
-      const int row = min(tn * BN + (idx - 16) * 16 + lrow, g.N - 1);
-      src[j] = g.B + (long)row * g.ldb + lchunk * 8;
-      dst_off[j] = A_BYTES + (idx - 16) * 1024;
-    }
-  }
-  const bf16_t* src2[4];
-  const int nk1 = g.K / BK;
-  if (g.K2 > 0) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int idx = wave * 4 + j;
-      if (idx < 16) src2[j] = g.A2 + (long)min(tm * BM + idx * 16 + lrow, g.M - 1) * g.lda2 + lchunk * 8;
-      else src2[j] = g.B2 + (long)min(tn * BN + (idx - 16) * 16 + lrow, g.N - 1) * g.ldb2 + lchunk * 8;
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) src2[j] = src[j];
-  }
-  auto issue1 = [&](int kt, int j) {
-    const bf16_t* p = kt < nk1 ? src[j] + (long)kt * BK : src2[j] + (long)(kt - nk1) * BK;
-    __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(smem + ((unsigned)kt % NS) * STAGE + dst_off[j]), 16, 0, 0);
-  };
-
-  const int wm = wave >> 2, wn = wave & 3;
-  const int fr = lane & 31, fh = lane >> 5;
-  const int sw = (lane >> 2) & 3;
-  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
-  const unsigned a_base = lds0 + (wm * 128 + fr) * 64;
-  const unsigned b_base = lds0 + A_BYTES + (wn * 64 + fr) * 64;
-  const unsigned koff0 = ((0 * 2 + fh) ^ sw) * 16, koff1 = ((1 * 2 + fh) ^ sw) * 16;
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  bf16x8 a0[4], b0[2], a1[4], b1[2];  // set0 = k-step 0 fragments, set1 = k-step 1 fragments
-#define MF(A_, B_, mi, ni) \
-  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B_[ni], A_[mi], acc[mi][ni], 0, 0, 0); __builtin_amdgcn_sched_barrier(0);
-#define MFMA8(A_, B_) \
-  MF(A_, B_, 0, 0) MF(A_, B_, 0, 1) MF(A_, B_, 1, 0) MF(A_, B_, 1, 1) MF(A_, B_, 2, 0) MF(A_, B_, 2, 1) MF(A_, B_, 3, 0) MF(A_, B_, 3, 1)
-
-  const int nk = (g.K + g.K2) / BK;  // >= 3 (host guarantees)
-#pragma unroll
-  for (int s = 0; s < NS - 2; ++s)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) issue1(s, j);
-  // NOT a counted vmcnt(4 / 8): the LDS-DMA pieces of one wave do not retire in issue order (round 3: a counted wait on the older of two
-  // stages in flight produced wrong tiles in gemm_nt_144s_kernel, 10 of 12 repetitions).  This fallback kernel therefore waits for everything
-  // it has issued; its ring still spreads the issue, but a stage has one stage time to land, like in the two-buffer kernels
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-#pragma unroll
-  for (int j = 0; j < 4; ++j) issue1(NS - 2, j);
-  lds_read6(a0, b0, a_base + koff0, b_base + koff0);
-  lds_read6(a1, b1, a_base + koff1, b_base + koff1);
-  asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(b0[0]), "+v"(b0[1]), "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]));
-  __builtin_amdgcn_sched_barrier(0);
-  MFMA8(a0, b0)
-
-  // One iteration = [publish stage kt+1] + 16 MFMAs (k1 of stage kt, k0 of stage kt+1); behind every MFMA sits one filler:
-  // a ds_read of the next k-step's fragments or one DMA piece of stage kt+3.
-  auto body = [&](auto dma_c, auto vm_c, int kt) {
-    constexpr bool DMA = decltype(dma_c)::value;
-    constexpr int VM = decltype(vm_c)::value;  // DMA pieces that may still be in flight: the stages after kt+1
-    (void)VM;  // see the prologue: counted waits on LDS-DMA are not safe
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const unsigned so = ((unsigned)(kt + 1) % NS) * STAGE;
-    const unsigned aa0 = a_base + so + koff0, ba0 = b_base + so + koff0;
-    const unsigned aa1 = a_base + so + koff1, ba1 = b_base + so + koff1;
-    lds_wait6(a1, b1);
-    MF(a1, b1, 0, 0) LDS_RD(b0[0], ba0, 0);    __builtin_amdgcn_sched_barrier(0);
-    MF(a1, b1, 0, 1) LDS_RD(b0[1], ba0, 2048); __builtin_amdgcn_sched_barrier(0);
-    MF(a1, b1, 1, 0) LDS_RD(a0[0], aa0, 0);    __builtin_amdgcn_sched_barrier(0);
-    MF(a1, b1, 1, 1) LDS_RD(a0[1], aa0, 2048); __builtin_amdgcn_sched_barrier(0);
-    MF(a1, b1, 2, 0) LDS_RD(a0[2], aa0, 4096); __builtin_amdgcn_sched_barrier(0);
-    MF(a1, b1, 2, 1) LDS_RD(a0[3], aa0, 6144); __builtin_amdgcn_sched_barrier(0);
-    MF(a1, b1, 3, 0) if constexpr (DMA) issue1(kt + NS - 1, 0); __builtin_amdgcn_sched_barrier(0);
-    MF(a1, b1, 3, 1) if constexpr (DMA) issue1(kt + NS - 1, 1); __builtin_amdgcn_sched_barrier(0);
-    lds_wait6(a0, b0);
-    MF(a0, b0, 0, 0) LDS_RD(b1[0], ba1, 0);    __builtin_amdgcn_sched_barrier(0);
-    MF(a0, b0, 0, 1) LDS_RD(b1[1], ba1, 2048); __builtin_amdgcn_sched_barrier(0);
-    MF(a0, b0, 1, 0) LDS_RD(a1[0], aa1, 0);    __builtin_amdgcn_sched_barrier(0);
-    MF(a0, b0, 1, 1) LDS_RD(a1[1], aa1, 2048); __builtin_amdgcn_sched_barrier(0);
-    MF(a0, b0, 2, 0) LDS_RD(a1[2], aa1, 4096); __builtin_amdgcn_sched_barrier(0);
-    MF(a0, b0, 2, 1) LDS_RD(a1[3], aa1, 6144); __builtin_amdgcn_sched_barrier(0);
-    MF(a0, b0, 3, 0) if constexpr (DMA) issue1(kt + NS - 1, 2); __builtin_amdgcn_sched_barrier(0);
-    MF(a0, b0, 3, 1) if constexpr (DMA) issue1(kt + NS - 1, 3); __builtin_amdgcn_sched_barrier(0);
-  };
-  using T_ = std::integral_constant<bool, true>;
-  using F_ = std::integral_constant<bool, false>;
-  using V8 = std::integral_constant<int, 8>;
-  using V4 = std::integral_constant<int, 4>;
-  using V0 = std::integral_constant<int, 0>;
-  if constexpr (NS == 4) {
-    for (int kt = 0; kt < nk - 3; ++kt) body(T_{}, V4{}, kt);  // steady state: DMA NS-1 stages ahead, vmcnt never 0
-    body(F_{}, V4{}, nk - 3);                                  // stage nk-1 is already in flight
-  } else {
-    for (int kt = 0; kt < nk - 4; ++kt) body(T_{}, V8{}, kt);
-    body(F_{}, V8{}, nk - 4);
-    body(F_{}, V4{}, nk - 3);
-  }
-  body(F_{}, V0{}, nk - 2);
-  lds_wait6(a1, b1);
-  MFMA8(a1, b1)
-#undef MFMA8
-#undef MF
-
-  if (g.out_f32) {
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int m = tm * BM + wm * 128 + mi * 32 + fr;
-      if (m >= g.M) continue;
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4;
-          if (n >= g.N) continue;
-          store4<ACT>(g, m, n, f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]});
-        }
-    }
-    return;
-  }
-  // ---- bf16 epilogue through LDS: each wave transposes its own 128 x 64 sub-tile in a private 16 KiB region of the
-  // (now idle) ring so that global stores are 16 B per lane, 128 contiguous bytes per row (full cache lines).
-  //   stage value = bf16(act(alpha*acc + bias));  final = bf16(stage + residual)  (the reference's rounding order)
-  __builtin_amdgcn_s_barrier();  // every wave is done reading the last stages
-  char* reg = smem + wave * 16384;
-  {
-    float bias_v[2][4][4];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = min(tn * BN + wn * 64 + ni * 32 + q * 8 + fh * 4, g.N - 4);
-        uint2 bb = make_uint2(0, 0);
-        if (g.bias) bb = *reinterpret_cast<const uint2*>(g.bias + n);
-        bias_v[ni][q][0] = bflo(bb.x); bias_v[ni][q][1] = bfhi(bb.x); bias_v[ni][q][2] = bflo(bb.y); bias_v[ni][q][3] = bfhi(bb.y);
-      }
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int row = mi * 32 + fr;
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            v[i] = acc[mi][ni][4 * q + i] * g.alpha + bias_v[ni][q][i];
-            if (ACT) v[i] = apply_act(v[i], ACT);
-          }
-          const int u = ni * 8 + q * 2 + fh;  // 8-byte unit inside the 128-B row
-          *reinterpret_cast<uint2*>(reg + row * 128 + ((u ^ ((row & 7) << 1)) << 3)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-        }
-    }
-  }
-  // a wave reads back only what it wrote itself: its own LDS writes are visible to it once lgkmcnt drains
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  {
-    const int rsub = lane >> 3, c = lane & 7;
-    const int n = tn * BN + wn * 64 + c * 8;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = i * 8 + rsub;
-      const int m = tm * BM + wm * 128 + row;
-      uint4 val = *reinterpret_cast<const uint4*>(reg + row * 128 + ((c ^ (row & 7)) << 4));
-      if (m < g.M && n < g.N) {
-        if (g.res) {
-          const uint4 r = *reinterpret_cast<const uint4*>(g.res + (long)m * g.ldr + n);
-          val.x = pack2bf(bflo(val.x) + bflo(r.x), bfhi(val.x) + bfhi(r.x));
-          val.y = pack2bf(bflo(val.y) + bflo(r.y), bfhi(val.y) + bfhi(r.y));
-          val.z = pack2bf(bflo(val.z) + bflo(r.z), bfhi(val.z) + bfhi(r.z));
-          val.w = pack2bf(bflo(val.w) + bflo(r.w), bfhi(val.w) + bfhi(r.w));
-        }
-        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n) = val;
-      }
-    }
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------------
 // The 16-wave 256x256 kernel (4x4 waves of 64x64, 128 VGPRs -> 4 waves per SIMD: while one wave sits in a DMA issue or at the barrier three
 // others feed the SIMD's MFMA pipe).  MFMA shape: v_mfma_f32_16x16x32_bf16, not the 32x32x16 this kernel used through round 2's first half
 // (gemm_nt_256r_kernel, in the history).  Per FLOP the 16x16x32 instruction moves half the accumulator data (4 accumulator VGPRs per 16 KFLOP
@@ -530,27 +273,15 @@ __device__ __forceinline__ void lds_wait8(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// SK = true: the stream-K launch for the tiles of the last, partial round (GemmArgs::sk_*): a workgroup computes a contiguous range of
-// k-stages that covers the end of one tile and / or the start of the next one instead of whole tiles.  Same main loop: a work item is the
-// stages [S0, S0 + nkl) of a tile (SK = false: S0 = 0, nkl = all of them - the compiler folds both).
-constexpr int SK_MINSEG = 4;   // no item shorter than this many stages (the pipeline needs 2); cut points closer to a tile edge snap to it
-// cut point `uu` of `units` over the sk_tiles * nk stages of the tail tiles (host + device: lhrs_gemm_streamk_plan replays it for the tests)
-__host__ __device__ __forceinline__ int sk_cut(int uu, int sk_tiles, int nk, int units) {
-  int x = (int)((long)uu * ((long)sk_tiles * nk) / units);
-  const int r = x % nk;
-  if (r < SK_MINSEG) x -= r;
-  else if (r > nk - SK_MINSEG) x += nk - r;
-  return x;
-}
-template <int ACT, int EPI, bool K2P, bool SK = false>
+template <int ACT, int EPI, bool K2P>
 __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
   constexpr int BM = 256, BN = 256, BK = 64;
   constexpr int A_BYTES = BM * BK * 2, STAGE = A_BYTES + BN * BK * 2;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
-  const int ntiles = g.ntiles;
+  const int ntiles = g.tilesM * g.tilesN;
   int t = blockIdx.x;
-  if (!SK && t >= ntiles) return;
+  if (t >= ntiles) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -617,33 +348,14 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
   const unsigned a0 = lds0 + (wm * 64 + (lane & 15)) * 128 + (((lane >> 4)) ^ sw) * 16;
   const unsigned b0 = lds0 + A_BYTES + (wn * 64 + (lane & 15)) * 128 + (((lane >> 4)) ^ sw) * 16;
 
-  int S0 = 0, nkl = nk;   // the current work item: stages [S0, S0 + nkl) of its tile
-  // stream-K: unit u of sk_units owns the stages [bnd(u), bnd(u + 1)) of the sk_tiles * nk stages of the tail tiles (cut points within
-  // SK_MINSEG stages of a tile edge snap to it).  Its range is the end of tile sk_i0 (from stage S0: a PARTIAL unless S0 == 0) and / or the
-  // first sk_n1 stages of tile sk_i0 + 1; the unit that holds a tile's stage 0 finishes the tile (adds the others' partials, epilogue)
-  int sk_u = 0, sk_i0 = 0, sk_n1 = 0, sk_seg = 0;
-  auto sk_bnd = [&](int uu) { return sk_cut(uu, g.sk_tiles, nk, g.sk_units); };
+  const int nkl = nk;   // stages per tile
   int tm, tn;
-  if constexpr (SK) {
-    const int U = g.sk_units;
-    sk_u = blockIdx.x;
-    if ((U & 7) == 0) sk_u = (sk_u & 7) * (U >> 3) + (sk_u >> 3);   // neighbouring units (they exchange partials) on one XCD
-    const int b0 = sk_bnd(sk_u), b1 = sk_bnd(sk_u + 1);
-    if (b1 <= b0) return;
-    sk_i0 = b0 / nk;
-    S0 = b0 - sk_i0 * nk;
-    const int e0 = min(b1, (sk_i0 + 1) * nk);
-    nkl = e0 - b0;
-    sk_n1 = b1 - e0;
-    tile_coords_raster(g, g.sk_tile0 + sk_i0, tm, tn);
-  } else {
-    tile_coords_lin(g, t, ntiles, tm, tn);
-  }
+  tile_coords_lin(g, t, ntiles, tm, tn);
   unsigned off1[4];
   dma_rows(tm, tn, off1);
   int pb = 0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) issue1(off1, S0, 0, j);   // (a stream-K item never starts inside the second operand pair: host rule)
+  for (int j = 0; j < 4; ++j) issue1(off1, 0, 0, j);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   bf16x8 A[4], B[4];
@@ -653,7 +365,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
 
   for (;;) {
     const int tnext = t + (int)gridDim.x;
-    const bool has_next = SK ? (sk_seg == 0 && sk_n1 > 0) : (tnext < ntiles);  // workgroup-uniform
+    const bool has_next = tnext < ntiles;  // workgroup-uniform
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -664,8 +376,8 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (!K2P || S0 + 1 < nk1) issue1(off1, S0 + 1, pb ^ 1, j);
-      else issue2(tm, tn, S0 + 1 - nk1, pb ^ 1, j);
+      if (!K2P || 1 < nk1) issue1(off1, 1, pb ^ 1, j);
+      else issue2(tm, tn, 1 - nk1, pb ^ 1, j);
     }
     {
       const unsigned aa = a0 ^ (unsigned)(pb * STAGE), ba = b0 ^ (unsigned)(pb * STAGE);
@@ -682,20 +394,19 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
       { const unsigned aa = a0 ^ (so | 64u), ba = b0 ^ (so | 64u); S_BLOCK0(aa, ba) }                           \
       { const unsigned aa = a0 ^ sn, ba = b0 ^ sn; S_BLOCK1(aa, ba) }                                           \
     }
-    // local stage s fetches the item's stage s + 2 = stage S0 + s + 2 of the tile: from the first pair while that is < nk1
-    const int nA = K2P ? min(nkl - 2, nk1 - 2 - S0) : nkl - 2;
-#define ISS(j) issue1(off1, S0 + s + 2, (s + pb) & 1, j);
+    // stage s fetches stage s + 2 of the tile: from the first pair while that is < nk1
+    const int nA = K2P ? min(nkl - 2, nk1 - 2) : nkl - 2;
+#define ISS(j) issue1(off1, s + 2, (s + pb) & 1, j);
     for (int s = 0; s < nA; ++s) STAGE_S(s)   // !K2P: every stage but the last two
 #undef ISS
     if (K2P) {  // the stages whose DMA slot fetches the second pair
-#define ISS(j) issue2(tm, tn, S0 + s + 2 - nk1, (s + pb) & 1, j);
+#define ISS(j) issue2(tm, tn, s + 2 - nk1, (s + pb) & 1, j);
       for (int s = max(nA, 0); s < nkl - 2; ++s) STAGE_S(s)
 #undef ISS
     }
     int ntm = 0, ntn = 0;
     if (has_next) {  // this tile's DMA rows are not needed any more (its last stage is in flight): the offsets become the next tile's
-      if constexpr (SK) tile_coords_raster(g, g.sk_tile0 + sk_i0 + 1, ntm, ntn);
-      else tile_coords_lin(g, tnext, ntiles, ntm, ntn);
+      tile_coords_lin(g, tnext, ntiles, ntm, ntn);
       dma_rows(ntm, ntn, off1);
     }
     // stage nkl - 2: the buffer its barrier frees takes the first stage of the NEXT item (always a tile's stage 0)
@@ -709,60 +420,13 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
       S_BLOCK1_FINAL(0, 0)
     }
 
-    bool sk_partial = false;
-    if constexpr (SK) {
-      // slab layout: [unit][wave][mi][ni][lane] float4 - exactly this lane's accumulator registers, 1 KiB per wave instruction
-      if (S0 != 0) {
-        // PARTIAL of a tile another unit finishes: accumulators -> slab sk_u, then publish (agent-scope release behind every wave's
-        // drained stores, then the flag: cdna_hip_programming.md §6 Guideline 16)
-        sk_partial = true;
-        float4* dst = reinterpret_cast<float4*>(g.sk_ws + (size_t)sk_u * (BM * BN)) + wave * 1024 + lane;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni)
-            dst[(mi * 4 + ni) * 64] = make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __hip_atomic_store(g.sk_flags + sk_u, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      } else if (nkl != nk) {
-        // this unit holds the tile's stage 0 but not all of it: add the partials of the units that hold the rest (units sk_u + 1 ... whose
-        // cut point lies inside this tile), in unit order (a fixed summation order: deterministic results)
-        const int tile_end = (sk_i0 + sk_seg + 1) * nk;
-        if (tid == 0) {
-          for (int p = sk_u + 1; p < g.sk_units && sk_bnd(p) < tile_end; ++p) {
-            if (sk_bnd(p + 1) <= sk_bnd(p)) continue;   // an empty unit writes nothing
-            while (__hip_atomic_load(g.sk_flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
-            __hip_atomic_store(g.sk_flags + p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // flags are zero again when the launch ends
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-        for (int p = sk_u + 1; p < g.sk_units && sk_bnd(p) < tile_end; ++p) {
-          if (sk_bnd(p + 1) <= sk_bnd(p)) continue;
-          const float4* src = reinterpret_cast<const float4*>(g.sk_ws + (size_t)p * (BM * BN)) + wave * 1024 + lane;
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-              const float4 v = src[(mi * 4 + ni) * 64];
-              acc[mi][ni][0] += v.x; acc[mi][ni][1] += v.y; acc[mi][ni][2] += v.z; acc[mi][ni][3] += v.w;
-            }
-        }
-      }
-    }
     // accumulator element acc[mi][ni][i]: m = wm*64 + mi*16 + fr, n = wn*64 + ni*16 + fg*4 + i.
     // Everything the epilogue derives from the lane id is derived from an opaque copy made HERE, per tile: otherwise those values are
     // loop-invariant across tiles, get hoisted in front of the tile loop and sit in (or spill from) registers all through the main loop
     int le = lane;
     asm volatile("" : "+v"(le));
     const int fr = le & 15, fg = le >> 4;
-    if (sk_partial) {
-    } else if (g.out_f32) {
+    if (g.out_f32) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
         const int m = tm * BM + wm * 64 + mi * 16 + fr;
@@ -782,13 +446,13 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
       const int n = EPI == 1   ? (c < 4 ? 0 : g.ff) + tn * 128 + wn * 32 + (c & 3) * 8
                     : rope_tile ? tn * BN + (wn >> 1) * 128 + (c < 4 ? 0 : 64) + (wn & 1) * 32 + (c & 3) * 8
                                 : tn * BN + wn * 64 + c * 8;
-      constexpr bool SWB = EPI == 2 || EPI == 5;   // SwiGLU-backward epilogue (5: + row dot partials)
+      constexpr bool SWB = EPI == 2;   // SwiGLU-backward epilogue
       const int nlim = SWB ? g.ff : g.N;
       const bool col_ok = n < nlim;
 #pragma unroll
       for (int ps = 0; ps < 2; ++ps) {
         uint4 pre_a[4], pre_b[4];
-        if (SWB || EPI == 4 || (EPI == 0 && g.res)) {
+        if (SWB || (EPI == 0 && g.res)) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int m = tm * BM + wm * 64 + ps * 32 + i * 8 + rsub;
@@ -797,9 +461,6 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
               if (SWB) {
                 pre_a[i] = *reinterpret_cast<const uint4*>(g.aux + (long)m * g.ld_aux + n);
                 pre_b[i] = *reinterpret_cast<const uint4*>(g.aux + (long)m * g.ld_aux + g.ff + n);
-              } else if (EPI == 4) {
-                pre_a[i] = *reinterpret_cast<const uint4*>(g.aux + (long)m * g.ld_aux + n);                        // x
-                if (g.res) pre_b[i] = *reinterpret_cast<const uint4*>(g.res + (long)m * g.ldr + n);              // add
               } else {
                 pre_a[i] = *reinterpret_cast<const uint4*>(g.res + (long)m * g.ldr + n);
               }
@@ -854,7 +515,6 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
           const int r32 = i * 8 + rsub;
           const int m = tm * BM + wm * 64 + ps * 32 + r32;
           uint4 val = *reinterpret_cast<const uint4*>(reg + r32 * 128 + ((c ^ (r32 & 7)) << 4));
-          float rowp = 0.f;   // EPI 5: this lane's 8 columns of <d(gate|up), gate|up> of row m
           if (SWB && m < g.M && col_ok) {
             const uint4 gq = pre_a[i], uq = pre_b[i];
             float d[8], gg[8], uu[8], dg[8], du[8];
@@ -864,29 +524,13 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
               const float sg = 1.f / (1.f + __expf(-gg[e]));
               du[e] = d[e] * gg[e] * sg;
               dg[e] = d[e] * uu[e] * sg * (1.f + gg[e] * (1.f - sg));
-              if (EPI == 5) rowp += bf2f(f2bf(dg[e])) * gg[e] + bf2f(f2bf(du[e])) * uu[e];   // on the values as they are stored
             }
             bf16_t* out = reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n;
             *reinterpret_cast<uint4*>(out) = pack8(dg);
             *reinterpret_cast<uint4*>(out + g.ff) = pack8(du);
           }
-          if (EPI == 5) {   // the 8 lanes c = 0..7 of a row hold its 64 columns of this wave: fold them, lane c == 0 stores the partial
-            rowp += __shfl_xor(rowp, 1, 64); rowp += __shfl_xor(rowp, 2, 64); rowp += __shfl_xor(rowp, 4, 64);
-            if (c == 0 && m < g.M) g.row_dot[(long)(tn * 4 + wn) * g.M + m] = rowp;
-          }
           if (SWB) continue;
           if (m < g.M && col_ok) {
-            if (EPI == 4) {
-              // dx = rstd * (w o dh) - x * (rstd^2 * s / N) + add, fp32, one rounding (dh as the unfused path sees it: rounded to bf16)
-              float dh[8], xv[8], av[8], wv[8], o8[8];
-              unpack8(val, dh); unpack8(pre_a[i], xv); unpack8(pre_b[i], av);
-              unpack8(*reinterpret_cast<const uint4*>(g.bias + n), wv);
-              const float r = g.sa[m], coef = r * r * g.sb[m] / (float)g.N;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) o8[e] = r * (wv[e] * dh[e]) - xv[e] * coef + av[e];
-              *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n) = pack8(o8);
-              continue;
-            }
             if (EPI == 0 && g.res) {
               const uint4 r = pre_a[i];
               val.x = pack2bf(bflo(val.x) + bflo(r.x), bfhi(val.x) + bfhi(r.x));
@@ -931,7 +575,6 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
     if (g.out_f32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     t = tnext; tm = ntm; tn = ntn;
     pb = (pb + nkl) & 1;
-    if constexpr (SK) { sk_seg = 1; S0 = 0; nkl = sk_n1; }
   }
 #undef MF
 #undef SB
@@ -1323,109 +966,33 @@ static int num_cus() {
 }
 static dim3 grid_256s(long tiles) { return dim3((unsigned)(g_gemm_persist ? (tiles < num_cus() ? tiles : num_cus()) : tiles)); }
 
-// ---- stream-K for the last, partial round of the persistent 16-wave kernel -------------------------------------------------------------
-// T tiles on P CUs run as ceil(T / P) rounds and a nearly empty last round costs a full one (M = 8190, N = 11008: 1376 tiles = 5.375 rounds
-// -> 6; M = 8736, N = 4096: 560 = 2.19 -> 3; M = 2184, N = 4096: 144 = 0.56 -> 1).  With a workspace registered the floor(T / P) full rounds
-// run as before and the T % P tiles behind them go to a second launch of the same kernel (SK = true) that cuts their k-loops into P
-// contiguous ranges of stages, one per CU: the tail then costs (T % P) / P of a round plus the exchange of the fp32 partials.  The
-// workspace belongs to the caller (P slabs of 256 x 256 floats behind 4 KiB of flags = 64 MiB + 4 KiB); launches that use it must be
-// ordered on ONE stream.  Summation order is fixed by the shape alone: results are deterministic, and differ from the unsplit kernel's
-// only by fp32 re-association inside the split tiles.
-static struct { float* slabs; int* flags; long units; } g_sk[16];
-// MEASURED (round 4, tools/gemm_sk_ab.py, one box, us per launch whole rounds / stream-K): M = 8190: d-down + SwiGLU' (5.375 rounds) 672 / 691-802,
-// gate|up + SwiGLU (10.75) 1121-1153 / 1198-1341, lm_head 773-791 / 799-873; M = 8736 (2.19 rounds): o 239 / 285; M = 2184 (0.56 rounds): o 69
-// (144-row tiles) / 126, down 171 / 268.  SLOWER everywhere, for two reasons that belong to this chip, not to the code: (1) the 32 tiles an XCD
-// walks concurrently share 8 A and 4 B panels through its L2 only while they sit at the SAME k; ranges that start at different stages of
-// their tiles stream every panel from the Infinity Cache on their own (2.8 us per stage instead of 1.5); (2) a 256 KiB fp32 slab costs
-// 10-30 us to publish (store-issue-bound, then the L2 write-back of the release) and the unit that needs it finishes at the same moment
-// as the unit that writes it, so the exchange is exposed.  Therefore OFF by default; kept, with its tests, as the correct starting point for an
-// XCD-lockstep variant (units = groups of 16-32 CUs on 16-32 tiles at one k): DESIGN.md §3.1.
-static int g_gemm_streamk = 0;   // lhrs_gemm_set_streamk
-extern "C" int lhrs_gemm_set_streamk(int on) { g_gemm_streamk = on; return 0; }
-extern "C" long lhrs_gemm_streamk_workspace_bytes() { return 4096 + (long)num_cus() * 256 * 256 * 4; }
-// ws == nullptr: forget the workspace of the current device (stream-K off)
-extern "C" int lhrs_gemm_set_streamk_workspace(void* ws, long bytes) {
+// ---- the GEMM workspace -------------------------------------------------------------------------------------------------------------------
+// Caller-owned device memory, registered per device (lhrs_gemm_set_workspace; 64 MiB + 4 KiB for 256 CUs).  One user: the tail rows of a
+// row-split product with a long k-loop are computed split-K through f32 slabs in it (gemm_launch below).  Launches that use it must be ordered on
+// ONE stream per device.  (Round 4 also ran a stream-K tail of the persistent kernel through it: built, correct, slower at every shape of the path -
+// profiles/r04_streamk_ab.txt, DESIGN.md 3.1 - and removed in round 5.)
+static struct { float* slabs; long units; } g_sk[16];
+extern "C" long lhrs_gemm_workspace_bytes() { return 4096 + (long)num_cus() * 256 * 256 * 4; }
+// ws == nullptr: forget the workspace of the current device
+extern "C" int lhrs_gemm_set_workspace(void* ws, long bytes) {
   int dev = 0;
-  LHRS_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "streamk_workspace: device %d", dev);
-  if (ws == nullptr) { g_sk[dev].slabs = nullptr; g_sk[dev].flags = nullptr; g_sk[dev].units = 0; return 0; }
-  LHRS_REQUIRE(bytes >= lhrs_gemm_streamk_workspace_bytes() && ((size_t)ws & 255) == 0, "streamk_workspace: %ld bytes (need %ld, 256-B aligned)", bytes,
-               lhrs_gemm_streamk_workspace_bytes());
-  LHRS_REQUIRE(hipMemset(ws, 0, 4096) == hipSuccess, "streamk_workspace: cannot clear the flags");
-  g_sk[dev].flags = (int*)ws; g_sk[dev].slabs = (float*)((char*)ws + 4096); g_sk[dev].units = num_cus();
+  LHRS_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "gemm_set_workspace: device %d", dev);
+  if (ws == nullptr) { g_sk[dev].slabs = nullptr; g_sk[dev].units = 0; return 0; }
+  LHRS_REQUIRE(bytes >= lhrs_gemm_workspace_bytes() && ((size_t)ws & 255) == 0, "gemm_set_workspace: %ld bytes (need %ld, 256-B aligned)", bytes,
+               lhrs_gemm_workspace_bytes());
+  g_sk[dev].slabs = (float*)((char*)ws + 4096); g_sk[dev].units = num_cus();
   return 0;
 }
-// rounds of the P CUs (in units of one full 256x256 tile's k-loop of nk stages) that T tiles cost on the 16-wave kernel, and whether the
-// tail goes to the stream-K launch.  Fixed costs of that launch: a kernel boundary, one prologue per range, the slab round trip ~ 8 stages
-static double rounds_256(long T, int nk, int nk2, bool drop, bool* use_sk) {
+// rounds of the P CUs that T tiles of the persistent kernels cost
+static double rounds_256(long T) {
   const long P = num_cus();
-  int dev = 0;
-  const long tail = T % P;
-  bool sk = g_gemm_streamk && g_gemm_persist && tail != 0 && !drop && nk2 < 4 && nk >= 16 && P <= 1020 &&
-            hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && g_sk[dev].slabs != nullptr && g_sk[dev].units >= P;
-  const double cost_sk = (double)(T / P) + (double)tail / P + 8.0 / nk;
-  if (sk && cost_sk > (double)(T / P) + 0.92) sk = false;
-  if (use_sk) *use_sk = sk;
-  return sk ? cost_sk : (double)((T + P - 1) / P);
-}
-static int sk_units_for(long sk_tiles, int nk) {
-  const long W = sk_tiles * nk, P = num_cus();
-  const long u = W / 10 < P ? W / 10 : P;          // >= 10 stages per range on average (>= SK_MINSEG after snapping)
-  return (int)(u < 1 ? 1 : u);
-}
-// The stream-K decomposition as the kernels compute it, replayed on the host (tests; no launch).  T tiles of nk stages (nk2 of them from the
-// second operand pair), workspace assumed registered when `assume_ws`.  out[0] = tiles of the whole rounds, out[1] = stream-K tiles, out[2] =
-// units.  unit >= 0: out[3] = first tile of the unit's range (relative to out[0]), out[4] = its first stage there, out[5] = stages in that
-// tile, out[6] = stages in the next tile, out[7] = 1 if the first item is a PARTIAL (another unit finishes the tile), out[8] / out[9] = partials
-// the unit adds to its first / second item.  Returns 0, or -1 when stream-K does not apply.
-extern "C" int lhrs_gemm_streamk_plan(long T, int nk, int nk2, int assume_ws, int unit, int* out) {
-  const long P = num_cus(), tail = T % P;
-  bool sk = tail != 0 && nk2 < 4 && nk >= 16 && (double)tail / P + 8.0 / nk <= 0.92;
-  if (!assume_ws) (void)rounds_256(T, nk, nk2, false, &sk);
-  if (!sk) return -1;
-  const int units = sk_units_for(tail, nk), st = (int)tail;
-  out[0] = (int)(T - tail); out[1] = st; out[2] = units;
-  if (unit < 0) return 0;
-  const int b0 = sk_cut(unit, st, nk, units), b1 = sk_cut(unit + 1, st, nk, units);
-  for (int i = 3; i < 10; ++i) out[i] = 0;
-  if (b1 <= b0) return 0;
-  const int i0 = b0 / nk, S0 = b0 - i0 * nk, e0 = b1 < (i0 + 1) * nk ? b1 : (i0 + 1) * nk;
-  out[3] = i0; out[4] = S0; out[5] = e0 - b0; out[6] = b1 - e0; out[7] = S0 != 0;
-  for (int seg = 0; seg < 2; ++seg) {
-    const int n = seg == 0 ? out[5] : out[6], s0 = seg == 0 ? S0 : 0;
-    if (n == 0 || s0 != 0 || n == nk) continue;
-    const int tile_end = (i0 + seg + 1) * nk;
-    for (int p = unit + 1; p < units && sk_cut(p, st, nk, units) < tile_end; ++p)
-      if (sk_cut(p + 1, st, nk, units) > sk_cut(p, st, nk, units)) out[8 + seg]++;
-  }
-  return 0;
+  return (double)((T + P - 1) / P);
 }
 template <int ACT, int EPI>
 static void launch_256s(GemmArgs& g, hipStream_t s) {
-  const long T = (long)g.tilesM * g.tilesN, P = num_cus();
-  const int nk = (g.K + g.K2) / 64;
-  bool sk = false;
-  if (EPI < 4) (void)rounds_256(T, nk, g.K2 / 64, g.drop_thresh != 0, &sk);
-  g.ntiles = (int)T; g.sk_tile0 = 0; g.sk_tiles = 0; g.sk_units = 0; g.sk_ws = nullptr; g.sk_flags = nullptr;
-  if (sk) g.ntiles = (int)(T / P * P);
-  if constexpr (EPI >= 4) {   // the RMSNorm-backward epilogues: whole rounds, no second operand pair (their launchers guarantee both)
-    hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT, EPI, false, false>), grid_256s(g.ntiles), dim3(1024), 0, s, g);
-    return;
-  }
-  if (g.ntiles > 0) {
-    const dim3 grid = grid_256s(g.ntiles);
-    if (g.K2 > 0) hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT, EPI, true, false>), grid, dim3(1024), 0, s, g);
-    else hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT, EPI, false, false>), grid, dim3(1024), 0, s, g);
-  }
-  if (sk) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    g.sk_tile0 = g.ntiles; g.sk_tiles = (int)(T - g.ntiles);
-    g.sk_units = sk_units_for(g.sk_tiles, nk);
-    g.sk_ws = g_sk[dev].slabs; g.sk_flags = g_sk[dev].flags;
-    const dim3 grid((unsigned)g.sk_units);
-    if (g.K2 > 0) hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT, EPI, true, true>), grid, dim3(1024), 0, s, g);
-    else hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT, EPI, false, true>), grid, dim3(1024), 0, s, g);
-  }
+  const dim3 grid = grid_256s((long)g.tilesM * g.tilesN);
+  if (g.K2 > 0) hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT, EPI, true>), grid, dim3(1024), 0, s, g);
+  else hipLaunchKernelGGL((gemm_nt_256s_kernel<ACT, EPI, false>), grid, dim3(1024), 0, s, g);
 }
 // the 16-wave kernel; a second operand pair (K2 > 0: the fused LoRA product) is a template parameter of it
 #define LAUNCH_256(ACT_, EPI_, grid_, s_, g_) launch_256s<ACT_, EPI_>(g_, s_)
@@ -1448,7 +1015,7 @@ static bool pick_144(int M, long tiles_n, int K, int K2, bool drop) {
     // 1.15 nk + 5): M = 7710: qkv 86.6 -> 68.1 us, o 30.2 -> 25.9; M = 27360: 264.7 -> 214.4, 88.5 -> 69.7; fc1 (496 tiles = 2 rounds) stays
     return (double)((t144 + P - 1) / P) * (1.15 * nk + 5.0) < (double)((t256 + P - 1) / P) * (1.5 * nk + 20.0);
   }
-  return (double)((t144 + P - 1) / P) * g_gemm_bm144_cost < rounds_256(t256, nk, 0, drop, nullptr);
+  return (double)((t144 + P - 1) / P) * g_gemm_bm144_cost < rounds_256(t256);
 }
 // fewest 64x128 tiles for which the 64x128 small-tile kernel is taken over the 64x64 one (A/B: lhrs_gemm_set_small_thresh)
 static int g_gemm_small_thresh = 256;
@@ -1456,9 +1023,8 @@ extern "C" int lhrs_gemm_set_small_thresh(int n) { g_gemm_small_thresh = n; retu
 static int g_gemm_min256 = 128;  // fewest 256x256 tiles (half a round of the 256 CUs) for which the big-tile kernels are chosen: 2184 x 4096 (144
                                  // tiles, the reference's micro-batch 8) runs 20 % faster there than on 576 small tiles; A/B: lhrs_gemm_set_min_tiles
 extern "C" int lhrs_gemm_set_min_tiles(int n) { g_gemm_min256 = n; return 0; }
-// tile policy switch for A/B measurements: 0 = never a 256x256 kernel, 2 = default (16-wave BK=64 kernel when K % 64 == 0, else the BK=32
-// ring kernel), 4 = always the BK=32 ring kernel
-extern "C" int lhrs_gemm_set_policy(int allow_256) { g_gemm_allow_256 = allow_256; return 0; }
+// tile policy switch for A/B measurements: 0 = never a 256x256 / 144x256 persistent kernel (small tiles only), 2 = default
+extern "C" int lhrs_gemm_set_policy(int allow_256) { g_gemm_allow_256 = allow_256 ? 2 : 0; return 0; }
 
 // C ABI ------------------------------------------------------------------------------------------
 static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* bias,
@@ -1481,138 +1047,51 @@ extern "C" int lhrs_gemm_bf16_nt_dropmask(const void* A, int lda, const void* B,
   return rc;
 }
 
-// ---- plain long-k products: three candidates, chosen per problem by measurement ---------------------------------------------------------
-// A product with a plain epilogue (no bias, no activation, bf16 out, alpha 1) on a long k-loop can run (0) gemm_nt_256s_kernel / gemm_nt_144s_kernel of this
-// file, (2) the four-wave gemm_u4_kernel (gemm_u4.hip: 128x128 per wave, paced DMA - 5-18 % faster than (0) on these shapes) or (1) the vendor library's
-// assembly kernel (vendor.cpp).  Per problem (device, M, N, K, leading dims, residual or not) the FIRST call times all three - every algorithm the library's
-// heuristic offers (lhrs_vendor_gemm_tune), 1 untimed + 3 timed launches each on the caller's operands and stream - and later calls repeat the winner.  The
-// library's first heuristic answer alone is not safe to follow: tools/gemm_vendor_ab.py has it 1.4-1.8x SLOWER than gemm_nt_256s_kernel at M = 5460
-// (K >= 11008) and at M = 2184, K = 22016.  A hand-written kernel keeps the problem unless the library is more than 3 % faster, so that two ranks rarely
-// disagree over noise; every choice is a correct bf16 product ((0) and (2) bit-identical unless a residual is added: (1) and (2) round once).  Not timed (kernel (0), nothing cached): a capturing stream, C
-// aliasing an input, more than 96 problems in one process.  lhrs_gemm_set_vendor / LHRS_GEMM_VENDOR=0 and lhrs_gemm_set_u4 / LHRS_GEMM_U4=0 remove a candidate.
-extern "C" int lhrs_vendor_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
-                                   void* workspace, long workspace_bytes, void* stream);
-extern "C" int lhrs_vendor_gemm_tune(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
-                                     void* workspace, long workspace_bytes, int reps, float* best_us, void* stream);
+// ---- plain long-k products: the four-wave kernel by a shape rule ------------------------------------------------------------------------
+// A product with a plain epilogue (no bias, no activation, bf16 out, alpha 1; optional bf16 residual) on a long k-loop runs the four-wave
+// gemm_u4_kernel (gemm_u4.hip: 128x128 per wave, paced DMA - 5-18 % faster than the 16-wave kernel on these shapes) whenever its 256x256 tiles
+// fill at least ~80 % of one round of the CUs; everything else takes this file's kernels (gemm_launch).  The rule is a function of the SHAPE only -
+// no timing, no cache, no state: a run is bit-reproducible, every data-parallel rank runs the same kernels, ragged row counts (padded batches,
+// the supervised rows of lm_head) cost nothing, and a capturing stream sees the same kernels as an eager one.  Where the threshold comes from
+// (profiles/r04_plain_first_call_timing.txt, us, 16-wave / four-wave): M = 8190, N = 4096 (512 tiles): K = 4096 204.8 / 196.0, 12288 584.4 / 525.0,
+// 22016 1135.8 / 976.6; M = 3840, N = 4096 (240 tiles): K = 4096 100.9 / 96.8, 22016 560.8 / 476.7; M = 3840, N = 32000: 776.0 / 766.7;
+// M = 4320, N = 1024 (68 tiles): 58.4 / 76.0 - the four-wave kernel has one tile height, so a launch that cannot fill the chip stays on the 144-row /
+// small-tile kernels (M = 2184, N = 4096, the reference's micro-batch 8: 144 tiles).  lhrs_gemm_set_u4(0) / LHRS_GEMM_U4=0: the 16-wave kernels everywhere (kernel A/B tests).
 extern "C" int lhrs_gemm_u4_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
                                void* stream);
-static int g_vendor_on = -1, g_u4_on = -1, g_vendor_min_k = 4096;
+static int g_u4_on = -1;
 static int prof_count(int M, int N, int K, int kind, hipStream_t s);
 static void prof_end(int slot, hipStream_t s);
 static void plain_env() {
-  if (g_vendor_on < 0) {
-    const char* e = getenv("LHRS_GEMM_VENDOR");
-    g_vendor_on = (e == nullptr || e[0] != '0') ? 1 : 0;
-    const char* k = getenv("LHRS_GEMM_VENDOR_MIN_K");
-    if (k != nullptr && atoi(k) > 0) g_vendor_min_k = atoi(k);
-  }
   if (g_u4_on < 0) {
     const char* e = getenv("LHRS_GEMM_U4");
     g_u4_on = (e == nullptr || e[0] != '0') ? 1 : 0;
   }
 }
-extern "C" int lhrs_gemm_set_vendor(int on, int min_k) {
-  plain_env();
-  g_vendor_on = on ? 1 : 0;
-  if (min_k > 0) g_vendor_min_k = min_k;
-  return 0;
-}
 extern "C" int lhrs_gemm_set_u4(int on) { plain_env(); g_u4_on = on ? 1 : 0; return 0; }
-// 1 when lhrs_gemm_bf16_nt decides this problem by first-call timing (a plain epilogue on a long k-loop, operands every candidate can address)
-static int plain_timed(int M, int N, int K, int lda, int ldb, int ldc, int ldr, int has_bias, int act, int out_f32, int accumulate, float alpha) {
+// 1 when lhrs_gemm_bf16_nt runs this problem on gemm_u4_kernel (pure function of the arguments and of lhrs_gemm_set_u4)
+extern "C" int lhrs_gemm_u4_takes(int M, int N, int K, int lda, int ldb, int ldc, int ldr, int has_bias, int act, int out_f32, int accumulate, float alpha) {
   plain_env();
-  return (g_vendor_on == 1 || g_u4_on == 1) && !has_bias && act == 0 && !out_f32 && !accumulate && alpha == 1.f && K >= g_vendor_min_k && K % 64 == 0 &&
-         M >= 1024 && N >= 1024 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && ldr % 8 == 0;
+  const long tiles = (long)cdiv(M, 256) * cdiv(N, 256);
+  return g_u4_on == 1 && !has_bias && act == 0 && !out_f32 && !accumulate && alpha == 1.f && K >= 4096 && K % 64 == 0 && M >= 1024 && N >= 1024 &&
+         5 * tiles >= 4L * num_cus() && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && ldr % 8 == 0;
 }
-// 1 when the vendor library is among the candidates for this problem
-extern "C" int lhrs_gemm_vendor_takes(int M, int N, int K, int lda, int ldb, int ldc, int ldr, int has_bias, int act, int out_f32, int accumulate, float alpha) {
-  return plain_timed(M, N, K, lda, ldb, ldc, ldr, has_bias, act, out_f32, accumulate, alpha) && g_vendor_on == 1;
-}
-static std::map<std::array<long, 11>, int> g_plain_choice;   // -> 0 this file's kernels, 1 library, 2 gemm_u4_kernel
-static long g_vendor_stats[3] = {0, 0, 0};                   // problems decided, -> library, -> hand-written (either kernel)
-static long g_u4_problems = 0;                               // of the hand-written ones: -> gemm_u4_kernel
-extern "C" int lhrs_gemm_vendor_stats(long* out3) { for (int i = 0; i < 3; ++i) out3[i] = g_vendor_stats[i]; return 0; }
-extern "C" long lhrs_gemm_u4_problems() { return g_u4_problems; }
 static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* bias,
                        const void* residual, int ldr, int act, int out_f32, int accumulate, float alpha, const void* A2,
                        int lda2, const void* B2, int ldb2, int K2, void* stream);
-static bool overlaps(const void* p, long bytes_p, const void* q, long bytes_q) {
-  const char* a = (const char*)p; const char* b = (const char*)q;
-  return q != nullptr && a < b + bytes_q && b < a + bytes_p;
-}
 
 extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N,
                                  int K, const void* bias, const void* residual, int ldr, int act, int out_f32,
                                  int accumulate, float alpha, void* stream) {
-  if (plain_timed(M, N, K, lda, ldb, ldc, residual ? ldr : 0, bias != nullptr, act, out_f32, accumulate, alpha) &&
+  if (lhrs_gemm_u4_takes(M, N, K, lda, ldb, ldc, residual ? ldr : 0, bias != nullptr, act, out_f32, accumulate, alpha) &&
       ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0) && ((size_t)C % 16 == 0) && ((size_t)residual % 16 == 0)) {
-    int dev = 0;
-    void* ws = nullptr; long ws_bytes = 0;
     hipStream_t s = (hipStream_t)stream;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && g_sk[dev].slabs != nullptr) {   // the registered workspace (lhrs_gemm_set_streamk_workspace)
-      ws = g_sk[dev].slabs; ws_bytes = g_sk[dev].units * 256L * 256 * 4;
-    }
-    const std::array<long, 11> key = {dev, M, N, K, lda, ldb, ldc, residual ? ldr : 0, ws_bytes, g_vendor_on, g_u4_on};
-    auto it = g_plain_choice.find(key);
-    int choice = it == g_plain_choice.end() ? -1 : it->second;
-    if (choice < 0) {
-      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-      const long cb = ((long)(M - 1) * ldc + N) * 2;
-      const bool tunable = hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone &&
-                           !overlaps(C, cb, A, ((long)(M - 1) * lda + K) * 2) && !overlaps(C, cb, B, ((long)(N - 1) * ldb + K) * 2) &&
-                           !overlaps(C, cb, residual, ((long)(M - 1) * ldr + N) * 2);
-      if (tunable && g_vendor_stats[0] < 96) {   // bounded: a caller that walks through many row counts (ragged prefill batches) stops paying for timing runs
-        const bool prof_was = g_prof.on;
-        g_prof.on = false;                                     // the timing launches are not part of the step
-        float t_lib = 1e30f, t_hand = 1e30f, t_u4 = 1e30f;
-        if (g_vendor_on == 1 && lhrs_vendor_gemm_tune(A, lda, B, ldb, C, ldc, M, N, K, residual, ldr, ws, ws_bytes, 3, &t_lib, stream) != 0) t_lib = 1e30f;
-        hipEvent_t e0, e1;
-        if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-          for (int cand = 0; cand < 2; ++cand) {                // 0: this file's kernels, 1: gemm_u4_kernel
-            if (cand == 1 && g_u4_on != 1) break;
-            auto run = [&]() {
-              return cand == 0 ? gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, nullptr, residual, ldr, 0, 0, 0, 1.f, nullptr, 0, nullptr, 0, 0, stream)
-                               : lhrs_gemm_u4_nt(A, lda, B, ldb, C, ldc, M, N, K, residual, ldr, stream);
-            };
-            int st = run();
-            (void)hipEventRecord(e0, s);
-            for (int r = 0; r < 3 && st == 0; ++r) st = run();
-            (void)hipEventRecord(e1, s);
-            float ms = 0.f;
-            if (st == 0 && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) (cand == 0 ? t_hand : t_u4) = ms / 3.f * 1e3f;
-            if (st < 0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); g_prof.on = prof_was; return st; }
-          }
-          (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-        }
-        g_prof.on = prof_was;
-        const float t_own = t_u4 < t_hand ? t_u4 : t_hand;
-        choice = t_lib < 0.97f * t_own ? 1 : (t_u4 < t_hand ? 2 : 0);
-        g_plain_choice[key] = choice;
-        g_vendor_stats[0]++; g_vendor_stats[choice == 1 ? 1 : 2]++;
-        if (choice == 2) g_u4_problems++;
-        if (getenv("LHRS_GEMM_VENDOR_LOG") != nullptr)
-          fprintf(stderr, "[lhrs gemm] M=%d N=%d K=%d%s: library %.1f us, 16-wave kernel %.1f us, 4-wave kernel %.1f us -> %s\n", M, N, K, residual ? " +residual" : "",
-                  t_lib < 1e29f ? t_lib : -1.f, t_hand < 1e29f ? t_hand : -1.f, t_u4 < 1e29f ? t_u4 : -1.f,
-                  choice == 1 ? "library" : choice == 2 ? "4-wave kernel" : "16-wave kernel");
-      } else {
-        choice = 0;
-      }
-    }
-    if (choice == 1) {
-      const int slot = prof_count(M, N, K, 5, s);
-      const int st = lhrs_vendor_gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, residual, ldr, ws, ws_bytes, stream);
-      if (st == 0) { prof_end(slot, s); return 0; }
-      if (st < 0) return st;
-      if (slot >= 0) { g_prof.used--; g_prof.seen[5]--; }   // not taken after all: the slot goes back (it was the last one handed out)
-      if (g_prof.on) { g_prof.launches_all--; g_prof.total_flops_all -= 2.0 * M * N * K; }
-    } else if (choice == 2) {
-      const int slot = prof_count(M, N, K, 6, s);
-      const int st = lhrs_gemm_u4_nt(A, lda, B, ldb, C, ldc, M, N, K, residual, ldr, stream);
-      if (st == 0) { prof_end(slot, s); return 0; }
-      if (st < 0) return st;
-      if (slot >= 0) { g_prof.used--; g_prof.seen[6]--; }
-      if (g_prof.on) { g_prof.launches_all--; g_prof.total_flops_all -= 2.0 * M * N * K; }
-    }
+    const int slot = prof_count(M, N, K, 6, s);
+    const int st = lhrs_gemm_u4_nt(A, lda, B, ldb, C, ldc, M, N, K, residual, ldr, stream);
+    if (st == 0) { prof_end(slot, s); return 0; }
+    if (st < 0) return st;
+    if (slot >= 0) { g_prof.used--; g_prof.seen[6]--; }   // not its problem after all (addressing limits): the slot goes back (it was the last one handed out)
+    if (g_prof.on) { g_prof.launches_all--; g_prof.total_flops_all -= 2.0 * M * N * K; }
   }
   return gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, out_f32, accumulate, alpha, nullptr, 0, nullptr, 0,
                      0, stream);
@@ -1633,7 +1112,7 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
                        const void* residual, int ldr, int act, int out_f32, int accumulate, float alpha, const void* A2,
                        int lda2, const void* B2, int ldb2, int K2, void* stream) {
   LHRS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
-  LHRS_REQUIRE(K % 32 == 0, "gemm: K=%d must be a multiple of 32 (zero-pad the reduction dim)", K);
+  LHRS_REQUIRE(K % 64 == 0, "gemm: K=%d must be a multiple of 64 (zero-pad the reduction dim)", K);
   LHRS_REQUIRE(N % 4 == 0, "gemm: N=%d must be a multiple of 4", N);
   LHRS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "gemm: lda=%d ldb=%d must be multiples of 8 (16-B rows)", lda, ldb);
   LHRS_REQUIRE(ldc % 4 == 0 && (residual == nullptr || ldr % 4 == 0), "gemm: ldc/ldr must be multiples of 4");
@@ -1665,25 +1144,23 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   } while (0)
   const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
   const bool al16 = out_f32 || (N % 8 == 0 && ldc % 8 == 0 && (residual == nullptr || ldr % 8 == 0));  // 16-B epilogue rows
-  bool use256 = g_gemm_allow_256 && t256 >= g_gemm_min256 && K >= 96 && K % 32 == 0 && al16;  // ring prologue needs >= 3 stages
+  bool use256 = g_gemm_allow_256 && t256 >= g_gemm_min256 && K >= 128 && al16;  // the persistent kernels' pipeline needs >= 2 stages
   // just under the big-tile threshold but nearly a full round of 144-row tiles (ViT o / fc2 at micro-batch 30: 124 tiles of 256 rows, 216 of
   // 144): the persistent 144-row kernel beats the small tiles (30.2 -> 25.9, 75.1 -> 68.4 us; tools/gemm_vit_sweep.py)
   if (!use256 && g_gemm_allow_256 == 2 && g_gemm_bm144 == 1 && al16 && !out_f32 && K % 64 == 0 && K >= 192 && K2 == 0 && !g.drop_thresh &&
       t256 >= g_gemm_min256 / 2 && (long)cdiv(M, 144) * cdiv(N, 256) >= 200 && (long)cdiv(M, 144) * cdiv(N, 256) <= num_cus())
     use256 = true;
-  if (g.drop_thresh && !(g_gemm_allow_256 == 2 && K % 64 == 0 && K >= 128)) use256 = false;  // the mask lives in the 16-wave kernel and in store4
   if (K2 > 0 && !use256) {  // small problems: base GEMM, then the rank-K2 update accumulated on top of it
     if (gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, out_f32, accumulate, alpha, nullptr, 0, nullptr, 0, 0, stream))
       return -1;
     return gemm_launch(A2, lda2, B2, ldb2, C, ldc, M, N, K2, nullptr, out_f32 ? nullptr : C, ldc, 0, out_f32, out_f32 ? 1 : 0, alpha,
                        nullptr, 0, nullptr, 0, 0, stream);
   }
-  LHRS_REQUIRE(use256 || K % 64 == 0, "gemm: K=%d must be a multiple of 64 for this problem size (zero-pad the reduction dim)", K);
   // Tail rows: T = tilesM * tilesN 256x256 tiles run as ceil(T / 256) rounds of the 256 CUs, and a nearly empty last round costs as
   // much as a full one (M = 8736, N = 4096: 560 tiles = 2.19 rounds -> 3).  When the tile rows that spill over the last full round
   // are cheaper as a separate small-tile launch (~2.5x the time per FLOP, but no idle CUs), the row range is cut there: whole
   // 256-row tile rows for the 16-wave kernel, the remaining rows for the 64x128 / 128x128 kernel.  Disjoint rows of C, no partials.
-  const bool s_kernel = use256 && g_gemm_allow_256 == 2 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128;
+  const bool s_kernel = use256;
   const bool bm144 = s_kernel && !out_f32 && pick_144(M, cdiv(N, 256), K, K2, g.drop_thresh != 0);
   if (s_kernel && !bm144 && t_split_ok && g_gemm_tail_split && !g.drop_thresh) {
     const int tm = cdiv(M, 256), tn = cdiv(N, 256);
@@ -1693,7 +1170,7 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
       const long t_main = (long)tm_main * tn, t_tail = T - t_main;
       const double split_cost = (double)((t_main + 255) / 256) + 2.5 * (double)t_tail / 256.0 + 0.05;
       (void)rounds;
-      if (split_cost < rounds_256(T, (K + K2) / 64, K2 / 64, false, nullptr)) {
+      if (split_cost < rounds_256(T)) {
         const int M_main = tm_main * 256, M_tail = M - M_main;
         const long esz = out_f32 ? 4 : 2;
         t_split_ok = false;
@@ -1733,7 +1210,7 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   int slot = -1;
   if (g_prof.on) {
     g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * (K + K2);
-    const bool dominant = use256 && g_gemm_allow_256 == 2 && K % 64 == 0 && K2 % 64 == 0 && K + K2 >= 128;
+    const bool dominant = s_kernel;
     const int pkind = bm144 ? 4 : 0;
     if (dominant && g_prof.used < g_prof.cap && g_prof.take(pkind)) {  // time the launches rocprof lists as gemm_nt_256s_kernel<ACT, 0 ...> (kind 0) / gemm_nt_144s_kernel<ACT, 0> (kind 4)
       slot = g_prof.used++;
@@ -1744,7 +1221,6 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
   }
   if (use256) {
     g.tilesM = cdiv(M, 256); g.tilesN = cdiv(N, 256);
-    const dim3 grid(g.tilesM * g.tilesN), blk(512);
     if (bm144) {
       g.tilesM = cdiv(M, 144);
       const dim3 grid12 = grid_256s((long)g.tilesM * g.tilesN);
@@ -1754,20 +1230,13 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
         case 2: LAUNCH_144(2, 0, grid12, s, g); break;
         default: LAUNCH_144(3, 0, grid12, s, g); break;
       }
-    } else if (s_kernel) {
+    } else {
       const dim3 grid16 = grid_256s((long)g.tilesM * g.tilesN);
       switch (act) {
         case 0: LAUNCH_256(0, 0, grid16, s, g); break;
         case 1: LAUNCH_256(1, 0, grid16, s, g); break;
         case 2: LAUNCH_256(2, 0, grid16, s, g); break;
         default: LAUNCH_256(3, 0, grid16, s, g); break;
-      }
-    } else {
-      switch (act) {
-        case 0: hipLaunchKernelGGL((gemm_nt_256p_kernel<0>), grid, blk, 0, s, g); break;
-        case 1: hipLaunchKernelGGL((gemm_nt_256p_kernel<1>), grid, blk, 0, s, g); break;
-        case 2: hipLaunchKernelGGL((gemm_nt_256p_kernel<2>), grid, blk, 0, s, g); break;
-        default: hipLaunchKernelGGL((gemm_nt_256p_kernel<3>), grid, blk, 0, s, g); break;
       }
     }
   } else if (big) LAUNCH_TILE(4, 4);
@@ -1936,101 +1405,6 @@ extern "C" int lhrs_gemm_swiglu_bwd(const void* dY, int ldy, const void* WdT, in
   LHRS_CHECK_LAUNCH("gemm_swiglu_bwd");
   return 0;
 }
-
-// ---- RMSNorm backward without its own pass over HBM (round 4) ------------------------------------------------------------------------
-// HF LlamaRMSNorm in front of the MLP: h = w o (x * rstd), gate|up = h W_gu^T.  Its backward needs c = sum_j dh_j w_j x_j over the WHOLE row
-// of dh = d(gate|up) W_gu - a full-row reduction that a tiled GEMM epilogue does not have.  But c = (1 / rstd) <d(gate|up), gate|up> (write
-// h_j = w_j x_j rstd and pull W_gu through the sum), and both factors sit in the SwiGLU-backward epilogue one launch earlier:
-//   lhrs_gemm_swiglu_bwd_rowdot : the fused d-down + SwiGLU' launch, which also writes the 4 * ff/256 per-wave-column partial sums per row
-//   lhrs_rowsum_partials        : s[m] = sum of the partials (fixed order: deterministic)
-//   lhrs_gemm_rmsnorm_bwd       : dx = rstd * (w o (dgu W_gu)) - x * (rstd^2 s / d) + add in the epilogue of the dX GEMM
-// instead of GEMM -> [dh to HBM] -> rmsnorm_bwd (4 row passes, 43 us at M = 8190).  Only where both products are whole rounds of the 256-row
-// persistent kernel (lhrs_gemm_rmsnorm_bwd_fusable); everywhere else the callers keep the three-launch sequence.
-// MEASURED (round 4, micro-batch 30, rocprofv3): the SwiGLU' launch grows 642 -> 678 us with the row dot, the d-gate|up launch 1118 -> 1133 us with
-// the norm epilogue, + the partial sum: +51 us of EXPOSED epilogue per layer for the 43 us rmsnorm_bwd pass it removes - the step is 0.4 ms
-// SLOWER (2.3 ms with the first, latency-bound version of the partial-sum kernel).  In this persistent kernel every wave runs the epilogue at
-// the same time, nothing overlaps it, and it moves bytes less efficiently than a dedicated bandwidth kernel at 6.2 TB/s.  The callers therefore
-// use it only on request (LHRS_FUSE_NORM_BWD=1); correct and tested (test_rmsnorm_backward_inside_the_dx_gemm_*).
-namespace {
-__global__ __launch_bounds__(512) void rowsum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int P, int M) {
-  // block = 64 rows x 8 slices of the partial index: slice y adds partials y, y + 8, ... (coalesced over the rows), then slice 0 adds the eight slice
-  // sums in slice order - a fixed summation order (deterministic), 8 loads in flight per row instead of a chain of P dependent ones
-  __shared__ float red[8][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int m = blockIdx.x * 64 + tx;
-  float acc = 0.f;
-  if (m < M)
-    for (int p = ty; p < P; p += 8) acc += part[(long)p * M + m];
-  red[ty][tx] = acc;
-  __syncthreads();
-  if (ty == 0 && m < M) {
-    float t = red[0][tx];
-#pragma unroll
-    for (int y = 1; y < 8; ++y) t += red[y][tx];
-    out[m] = t;
-  }
-}
-}  // namespace
-extern "C" int lhrs_gemm_rmsnorm_bwd_fusable(int M, int d, int ff) {
-  const long P = num_cus();
-  if (g_gemm_allow_256 != 2 || !g_gemm_persist || d % 256 != 0 || ff % 256 != 0) return 0;
-  const long t_down = (long)cdiv(M, 256) * (ff / 256), t_gu = (long)cdiv(M, 256) * (d / 256);
-  if (!swiglu_fusable(t_down, ff, d, 0, d, d) || pick_144(M, ff / 256, d, 0, false)) return 0;                 // d-down + SwiGLU': one fused 256-row launch
-  if (t_gu < g_gemm_min256 || t_gu % P != 0 || pick_144(M, d / 256, 2 * ff, 0, false)) return 0;               // d-gate|up: whole rounds of the 256-row kernel
-  return 1;
-}
-extern "C" int lhrs_gemm_swiglu_bwd_rowdot(const void* dY, int ldy, const void* WdT, int ldw, const void* gu, void* dgu, int ld_gu, float* row_dot,
-                                           int M, int ff, int K, void* stream) {
-  LHRS_REQUIRE(M > 0 && ff > 0 && K > 0 && ff % 256 == 0 && ld_gu >= 2 * ff && ld_gu % 8 == 0 && row_dot != nullptr, "gemm_swiglu_bwd_rowdot: M=%d ff=%d K=%d", M, ff, K);
-  LHRS_REQUIRE(swiglu_fusable((long)cdiv(M, 256) * (ff / 256), ff, K, 0, ldy, ldw) && !pick_144(M, ff / 256, K, 0, false),
-               "gemm_swiglu_bwd_rowdot: not a single fused 256-row launch for M=%d ff=%d K=%d (ask lhrs_gemm_rmsnorm_bwd_fusable first)", M, ff, K);
-  GemmArgs g; memset(&g, 0, sizeof(g));
-  g.A = (const bf16_t*)dY; g.B = (const bf16_t*)WdT; g.C = dgu; g.M = M; g.N = ff; g.K = K; g.lda = ldy; g.ldb = ldw; g.ldc = ld_gu;
-  g.alpha = 1.f; g.epi = 5; g.ff = ff; g.aux = (const bf16_t*)gu; g.ld_aux = ld_gu; g.row_dot = row_dot; g.drop_scale = 1.f;
-  g.tilesM = cdiv(M, 256); g.tilesN = ff / 256;
-  hipStream_t s = (hipStream_t)stream;
-  const int pslot = prof_count(M, ff, K, 2, s);
-  LAUNCH_256(0, 5, 0, s, g);
-  prof_end(pslot, s);
-  LHRS_CHECK_LAUNCH("gemm_swiglu_bwd_rowdot");
-  return 0;
-}
-// s[m] = sum_{p < P} part[p * M + m]
-extern "C" int lhrs_rowsum_partials(const float* part, float* out, int P, int M, void* stream) {
-  LHRS_REQUIRE(part && out && P > 0 && M > 0, "rowsum_partials: P=%d M=%d", P, M);
-  hipLaunchKernelGGL(rowsum_partials_kernel, dim3(cdiv(M, 64)), dim3(512), 0, (hipStream_t)stream, part, out, P, M);
-  LHRS_CHECK_LAUNCH("rowsum_partials");
-  return 0;
-}
-// out[M, N] = rstd o (w o (dY . WT^T)) - x o (rstd^2 s / N) + add;  dY [M, K], WT [N, K] (the transposed weight copy), x / add / out [M, N]
-extern "C" int lhrs_gemm_rmsnorm_bwd(const void* dY, int ldy, const void* WT, int ldw, const void* x, int ldx, const void* w, const float* rstd,
-                                     const float* s_row, const void* add, int ld_add, void* out, int ldo, int M, int N, int K, void* stream) {
-  LHRS_REQUIRE(M > 0 && N > 0 && K >= 128 && K % 64 == 0 && N % 256 == 0 && ldy % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 &&
-               (add == nullptr || ld_add % 8 == 0) && x && w && rstd && s_row, "gemm_rmsnorm_bwd: M=%d N=%d K=%d", M, N, K);
-  const long T = (long)cdiv(M, 256) * (N / 256);
-  LHRS_REQUIRE(g_gemm_allow_256 == 2 && g_gemm_persist && T >= g_gemm_min256 && T % num_cus() == 0 && !pick_144(M, N / 256, K, 0, false),
-               "gemm_rmsnorm_bwd: M=%d N=%d is not whole rounds of the 256-row kernel (ask lhrs_gemm_rmsnorm_bwd_fusable first)", M, N);
-  GemmArgs g; memset(&g, 0, sizeof(g));
-  g.A = (const bf16_t*)dY; g.B = (const bf16_t*)WT; g.C = out; g.M = M; g.N = N; g.K = K; g.lda = ldy; g.ldb = ldw; g.ldc = ldo;
-  g.alpha = 1.f; g.epi = 4; g.aux = (const bf16_t*)x; g.ld_aux = ldx; g.res = (const bf16_t*)add; g.ldr = ld_add; g.bias = (const bf16_t*)w;
-  g.sa = rstd; g.sb = s_row; g.drop_scale = 1.f;
-  g.tilesM = cdiv(M, 256); g.tilesN = N / 256;
-  hipStream_t s = (hipStream_t)stream;
-  int slot = -1;
-  if (g_prof.on) {
-    g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M * N * K;
-    if (g_prof.used < g_prof.cap && g_prof.take(0)) {   // counted with the plain launches of the 256-row kernel: it is that kernel with a heavier epilogue
-      slot = g_prof.used++;
-      g_prof.flops[slot] = 2.0 * M * N * K; g_prof.kind[slot] = 0;
-      (void)hipEventRecord(g_prof.ev[2 * slot], s);
-    }
-  }
-  LAUNCH_256(0, 4, 0, s, g);
-  if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], s);
-  LHRS_CHECK_LAUNCH("gemm_rmsnorm_bwd");
-  return 0;
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // Small-tile sibling of gemm_fp8_256_kernel (64x128 tile, 4 waves, the 2-stage DMA skeleton of gemm_nt_kernel; a stage row is 128 e4m3

@@ -24,10 +24,10 @@ extern "C" void lhrs_set_error(const char* msg);
   } while (0)
 
 // x [M = B * S, d] bf16 -> x_out [M, d]; saved for the backward: qkv [M, 3d] (q, k rotated), o [M, d], lse [B, heads, LT] f32, x_mid [M, d],
-// rstd2 [M] f32 (1 / rms of x_mid's rows; optional), gu [M, 2 ff].  h [M, d] and act [M, ff] are scratch.  desc: int32 [B][8] attention records (lhrs_attn_fwd).  LT = S rounded up to 64.
+// gu [M, 2 ff].  h [M, d] and act [M, ff] are scratch.  desc: int32 [B][8] attention records (lhrs_attn_fwd).  LT = S rounded up to 64.
 extern "C" int lhrs_llama_layer_forward(const void* x, const void* ln1_w, const void* qkv_w, const void* o_w, const void* ln2_w, const void* gu_w,
                                         const void* down_w, const float* cos_t, const float* sin_t, const int* desc, int B, int S, int LT, int d,
-                                        int heads, int ff, float eps, void* h, void* qkv, void* o, float* lse, void* x_mid, float* rstd2, void* gu,
+                                        int heads, int ff, float eps, void* h, void* qkv, void* o, float* lse, void* x_mid, void* gu,
                                         void* act, void* x_out, void* stream) {
   LAYER_REQUIRE(B > 0 && S > 0 && d > 0 && heads > 0 && d % heads == 0 && ff > 0 && LT >= S, "llama_layer_forward: B=%d S=%d d=%d heads=%d ff=%d LT=%d",
                 B, S, d, heads, ff, LT);
@@ -39,7 +39,7 @@ extern "C" int lhrs_llama_layer_forward(const void* x, const void* ln1_w, const 
   TRY(lhrs_gemm_rope_fwd(h, d, qkv_w, d, nullptr, 0, nullptr, 0, 0, qkv, 3 * d, M, 3 * d, d, cos_t, sin_t, S, 0, 2 * d, hd, stream));
   TRY(lhrs_attn_fwd(q, 3 * d, q + (long)d * 2, 3 * d, q + (long)2 * d * 2, 3 * d, o, d, lse, desc, B, heads, hd, S, S, LT, 1, 1.0f / sqrtf((float)hd), stream));
   TRY(lhrs_gemm_bf16_nt(o, d, o_w, d, x_mid, d, M, d, d, nullptr, x, d, 0, 0, 0, 1.0f, stream));
-  TRY(lhrs_rmsnorm_fwd(x_mid, d, ln2_w, h, d, rstd2, M, d, eps, stream));   // rstd2 [M] (may be NULL): lets the backward fold this norm into the d-gate|up GEMM
+  TRY(lhrs_rmsnorm_fwd(x_mid, d, ln2_w, h, d, nullptr, M, d, eps, stream));
   TRY(lhrs_gemm_swiglu_fwd(h, d, gu_w, d, nullptr, 0, nullptr, 0, 0, gu, 2 * ff, act, ff, M, ff, d, stream));
   TRY(lhrs_gemm_bf16_nt(act, ff, down_w, ff, x_out, d, M, d, ff, nullptr, x_mid, d, 0, 0, 0, 1.0f, stream));
   return 0;
@@ -48,12 +48,12 @@ extern "C" int lhrs_llama_layer_forward(const void* x, const void* ln1_w, const 
 // dx_out = d loss / d x_out [M, d] -> dx_in = d loss / d x [M, d] through the frozen layer (weights get no gradient: activation gradients only).
 // *_wT: the transposed weight copies ([in, out] of the forward weight, i.e. the dX products are NT GEMMs as well).  gu is OVERWRITTEN with
 // d(gate|up).  Scratch: dh [M, d], dh1 [M, d], d_o [M, d], dqkv [M, 3d], delta [B, heads, LT] f32, dact [M, ff] (may be NULL when
-// lhrs_gemm_swiglu_fusable says the fused kernel runs).  rstd2 (saved by the forward) + rowdot_part / rowdot_sum scratch: optional, see below.
+// lhrs_gemm_swiglu_fusable says the fused kernel runs).
 extern "C" int lhrs_llama_layer_backward(const void* dx_out, const void* x_in, const void* x_mid, const void* qkv, const void* o, const float* lse,
                                          void* gu, const void* ln1_w, const void* ln2_w, const void* qkv_wT, const void* o_wT, const void* gu_wT,
                                          const void* down_wT, const float* cos_t, const float* sin_t, const int* desc, int B, int S, int LT, int d,
                                          int heads, int ff, float eps, void* dh, void* d_o, void* dqkv, float* delta, void* dact, void* dx_in,
-                                         const float* rstd2, float* rowdot_part, float* rowdot_sum, void* stream) {
+                                         void* stream) {
   LAYER_REQUIRE(B > 0 && S > 0 && d > 0 && heads > 0 && d % heads == 0 && ff > 0 && LT >= S, "llama_layer_backward: B=%d S=%d d=%d heads=%d ff=%d LT=%d",
                 B, S, d, heads, ff, LT);
   LAYER_REQUIRE(dx_out && x_in && x_mid && qkv && o && lse && gu && ln1_w && ln2_w && qkv_wT && o_wT && gu_wT && down_wT && cos_t && sin_t && desc &&
@@ -62,17 +62,9 @@ extern "C" int lhrs_llama_layer_backward(const void* dx_out, const void* x_in, c
   const char* q = (const char*)qkv;
   char* dq = (char*)dqkv;
   // MLP: d(gate|up) = swiglu'(gu) * (dx_out . W_down) over gu;  dh = d(gate|up) . W_gu;  dx_mid = RMSNorm'(dh; x_mid) + dx_out  (over dh)
-  // With rstd2 and the two row-dot buffers (rowdot_part [4 * ff / 256][M], rowdot_sum [M] f32) and both products whole rounds of the 256-row
-  // GEMM, the norm's backward rides in the d-gate|up GEMM's epilogue (lhrs_gemm_rmsnorm_bwd) instead of being a pass of its own
-  if (rstd2 && rowdot_part && rowdot_sum && lhrs_gemm_rmsnorm_bwd_fusable(M, d, ff)) {
-    TRY(lhrs_gemm_swiglu_bwd_rowdot(dx_out, d, down_wT, d, gu, gu, 2 * ff, rowdot_part, M, ff, d, stream));
-    TRY(lhrs_rowsum_partials(rowdot_part, rowdot_sum, 4 * (ff / 256), M, stream));
-    TRY(lhrs_gemm_rmsnorm_bwd(gu, 2 * ff, gu_wT, 2 * ff, x_mid, d, ln2_w, rstd2, rowdot_sum, dx_out, d, dh, d, M, d, 2 * ff, stream));
-  } else {
-    TRY(lhrs_gemm_swiglu_bwd(dx_out, d, down_wT, d, nullptr, 0, nullptr, 0, 0, gu, gu, 2 * ff, dact, M, ff, d, stream));
-    TRY(lhrs_gemm_bf16_nt(gu, 2 * ff, gu_wT, 2 * ff, dh, d, M, d, 2 * ff, nullptr, nullptr, 0, 0, 0, 0, 1.0f, stream));
-    TRY(lhrs_rmsnorm_bwd(dh, x_mid, ln2_w, nullptr, dx_out, dh, M, d, eps, stream));
-  }
+  TRY(lhrs_gemm_swiglu_bwd(dx_out, d, down_wT, d, nullptr, 0, nullptr, 0, 0, gu, gu, 2 * ff, dact, M, ff, d, stream));
+  TRY(lhrs_gemm_bf16_nt(gu, 2 * ff, gu_wT, 2 * ff, dh, d, M, d, 2 * ff, nullptr, nullptr, 0, 0, 0, 0, 1.0f, stream));
+  TRY(lhrs_rmsnorm_bwd(dh, x_mid, ln2_w, nullptr, dx_out, dh, M, d, eps, stream));
   // attention: d_o = dx_mid . W_o;  (dq, dk, dv) with delta = rowsum(d_o * o) and the inverse RoPE inside;  dh1 = dqkv . W_qkv;
   // dx_in = RMSNorm'(dh1; x_in) + dx_mid
   TRY(lhrs_gemm_bf16_nt(dh, d, o_wT, d, d_o, d, M, d, d, nullptr, nullptr, 0, 0, 0, 0, 1.0f, stream));

@@ -35,42 +35,37 @@ def _req(t: torch.Tensor, dtype, name: str):
 
 
 # --------------------------------------------------------------------------------------------- GEMM
-_SK_WS = {}
+_GEMM_WS = {}
 
 
-def ensure_streamk_workspace(device, force: bool = False) -> None:
+def ensure_gemm_workspace(device) -> None:
     """Give the library its GEMM workspace on `device` (caller-owned, 64 MiB + 4 KiB: include/lhrs_hip.h) - once per device and process;
-    the towers call this when they are built.  Three users inside the library: the vendor library's stream-K kernels on the plain long-k products
-    (csrc/vendor.cpp), the split-K launch for the tail rows of a row-split product
-    with a long k-loop (always on), and the stream-K launch of the persistent kernel's last partial round, which is OFF unless
-    LHRS_GEMM_STREAMK=1 (measured slower than whole rounds on MI355X: csrc/gemm.hip).  LHRS_GEMM_WORKSPACE=0: nothing is registered.
-    force=True (tests, tools/gemm_sk_ab.py): register, leave the stream-K switch to the caller."""
-    import os
+    the towers call this when they are built.  One user inside the library: the split-K launch for the tail rows of a row-split product
+    with a long k-loop.  LHRS_GEMM_WORKSPACE=0: nothing is registered (those tail rows then run whole-K small tiles)."""
     dev = torch.device(device)
-    if dev.type != "cuda" or (not force and os.environ.get("LHRS_GEMM_WORKSPACE", "1") == "0"):
+    if dev.type != "cuda" or os.environ.get("LHRS_GEMM_WORKSPACE", "1") == "0":
         return
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    if idx in _SK_WS:
+    if idx in _GEMM_WS:
         return
     with torch.cuda.device(idx):
-        n = int(_L().lhrs_gemm_streamk_workspace_bytes())
+        n = int(_L().lhrs_gemm_workspace_bytes())
         ws = torch.empty(n, device=f"cuda:{idx}", dtype=torch.uint8)
         torch.cuda.synchronize()
-        _lib.check(_L().lhrs_gemm_set_streamk_workspace(ws.data_ptr(), n), "gemm_set_streamk_workspace")
-    _SK_WS[idx] = ws
-    if not force and os.environ.get("LHRS_GEMM_STREAMK", "0") == "1":
-        _L().lhrs_gemm_set_streamk(1)
-
-
-def gemm_set_vendor(on: bool, min_k: int = 0) -> None:
-    """Plain long-k products (no bias / activation, bf16 out, K >= min_k) through the vendor library (csrc/vendor.cpp) or, off, every product on
-    the hand-written kernels (kernel tests; env LHRS_GEMM_VENDOR=0)."""
-    _L().lhrs_gemm_set_vendor(int(bool(on)), int(min_k))
+        _lib.check(_L().lhrs_gemm_set_workspace(ws.data_ptr(), n), "gemm_set_workspace")
+    _GEMM_WS[idx] = ws
 
 
 def gemm_set_u4(on: bool) -> None:
-    """The four-wave gemm_u4_kernel (csrc/gemm_u4.hip) as a candidate of the first-call timing for the plain long-k products (default on; LHRS_GEMM_U4=0)."""
+    """The four-wave gemm_u4_kernel (csrc/gemm_u4.hip) for the plain long-k products and the fused-epilogue products it covers (default on; LHRS_GEMM_U4=0:
+    the 16-wave kernels everywhere - kernel A/B tests)."""
     _L().lhrs_gemm_set_u4(int(bool(on)))
+
+
+def gemm_u4_takes(M, N, K, lda=None, ldb=None, ldc=None, ldr=0, has_bias=False, act=0, out_f32=False, accumulate=False, alpha=1.0) -> bool:
+    """The shape rule of lhrs_gemm_bf16_nt: True when that problem runs on gemm_u4_kernel (a pure function of the arguments)."""
+    return bool(_L().lhrs_gemm_u4_takes(int(M), int(N), int(K), int(K if lda is None else lda), int(K if ldb is None else ldb), int(N if ldc is None else ldc),
+                                        int(ldr), int(has_bias), int(act), int(out_f32), int(accumulate), float(alpha)))
 
 
 def gemm_u4_nt(a, b, out, residual=None) -> bool:
@@ -79,33 +74,6 @@ def gemm_u4_nt(a, b, out, residual=None) -> bool:
                               _p(residual), residual.stride(0) if residual is not None else 0, _stream())
     if st < 0:
         _lib.check(st, "gemm_u4_nt")
-    return st == 0
-
-
-def gemm_vendor_status() -> str:
-    msg = _L().lhrs_gemm_vendor_status()
-    return msg.decode() if msg else ""
-
-
-def gemm_vendor_stats():
-    """(problems decided by first-call timing, of them -> the library's kernel, -> the hand-written kernel)."""
-    st = (ctypes.c_long * 3)()
-    _L().lhrs_gemm_vendor_stats(ctypes.addressof(st))
-    return int(st[0]), int(st[1]), int(st[2])
-
-
-def gemm_u4_problems() -> int:
-    return int(_L().lhrs_gemm_u4_problems())
-
-
-def vendor_gemm_nt(a, b, out, residual=None) -> bool:
-    """The raw library call (tests): True when launched, False when the library has no kernel for the problem."""
-    ensure_streamk_workspace(a.device, force=True)
-    ws = _SK_WS[a.device.index if a.device.index is not None else torch.cuda.current_device()]
-    st = _L().lhrs_vendor_gemm_nt(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), a.shape[0], b.shape[0], a.shape[1],
-                                  _p(residual), residual.stride(0) if residual is not None else 0, ws.data_ptr() + 4096, ws.numel() - 4096, _stream())
-    if st < 0:
-        _lib.check(st, "vendor_gemm_nt")
     return st == 0
 
 
@@ -185,33 +153,6 @@ def gemm_swiglu_bwd(dy, w_down_t, gu, ff, a2=None, b2=None, out=None):
                                 _stream())
     _lib.check(st, "gemm_swiglu_bwd")
     return dgu
-
-
-def mlp_norm_bwd_fusable(M: int, d: int, ff: int) -> bool:
-    """True when the RMSNorm backward in front of the MLP is to ride in the epilogue of the d-gate|up GEMM: the library can
-    (lhrs_gemm_rmsnorm_bwd_fusable) AND LHRS_FUSE_NORM_BWD=1 asks for it - it is OFF by default: measured 0.4 ms per step SLOWER than the
-    rmsnorm_bwd pass it removes (the epilogue of the persistent GEMM is exposed time; csrc/gemm.hip)."""
-    import os
-    return os.environ.get("LHRS_FUSE_NORM_BWD", "0") == "1" and bool(_L().lhrs_gemm_rmsnorm_bwd_fusable(int(M), int(d), int(ff)))
-
-
-def mlp_backward_fused(dy, w_down_t, gu, w_gu_t, x_mid, ln_w, rstd, ff, add=None):
-    """The MLP half of a frozen decoder layer's backward with the RMSNorm backward inside the dX GEMM (no rmsnorm_bwd pass):
-    dgu (over gu) = swiglu'(gu) * (dy @ w_down_t^T) + per-row partial sums of <dgu, gu>; s = their sum; returns
-    rstd * (ln_w o (dgu @ w_gu_t^T)) - x_mid * (rstd^2 s / d) + add   [M, d].  Requires mlp_norm_bwd_fusable(M, d, ff)."""
-    M, d = dy.shape
-    L = _L()
-    P = 4 * (ff // 256)
-    part = torch.empty((P, M), device=dy.device, dtype=torch.float32)
-    s_row = torch.empty(M, device=dy.device, dtype=torch.float32)
-    _lib.check(L.lhrs_gemm_swiglu_bwd_rowdot(dy.data_ptr(), dy.stride(0), w_down_t.data_ptr(), w_down_t.stride(0), gu.data_ptr(), gu.data_ptr(),
-                                             gu.stride(0), part.data_ptr(), M, ff, d, _stream()), "gemm_swiglu_bwd_rowdot")
-    _lib.check(L.lhrs_rowsum_partials(part.data_ptr(), s_row.data_ptr(), P, M, _stream()), "rowsum_partials")
-    out = torch.empty((M, d), device=dy.device, dtype=torch.bfloat16)
-    _lib.check(L.lhrs_gemm_rmsnorm_bwd(gu.data_ptr(), gu.stride(0), w_gu_t.data_ptr(), w_gu_t.stride(0), x_mid.data_ptr(), x_mid.stride(0),
-                                       ln_w.data_ptr(), rstd.data_ptr(), s_row.data_ptr(), _p(add), add.stride(0) if add is not None else 0,
-                                       out.data_ptr(), out.stride(0), M, d, 2 * ff, _stream()), "gemm_rmsnorm_bwd")
-    return out
 
 
 def gemm_fp8_nt(a8, sa, b8, sb, out=None, *, residual=None, alpha=1.0, a2=None, b2=None):
@@ -498,16 +439,15 @@ def llama_layer_forward(x, L, cos_t, sin_t, desc, B, S, LT, heads, ff, eps, h_sc
     o = torch.empty((M, d), device=dev, dtype=bf)
     lse = torch.empty((B, heads, LT), device=dev, dtype=torch.float32)
     x_mid = torch.empty((M, d), device=dev, dtype=bf)
-    rstd2 = torch.empty(M, device=dev, dtype=torch.float32)
     gu = torch.empty((M, 2 * ff), device=dev, dtype=bf)
     act = torch.empty((M, ff), device=dev, dtype=bf)
     x_out = torch.empty((M, d), device=dev, dtype=bf)
     st = _L().lhrs_llama_layer_forward(x.data_ptr(), L["ln1_w"].data_ptr(), L["qkv_w"].data_ptr(), L["o_w"].data_ptr(), L["ln2_w"].data_ptr(),
                                        L["gu_w"].data_ptr(), L["down_w"].data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), desc.data_ptr(), B, S, LT, d,
                                        heads, ff, float(eps), h_scratch.data_ptr(), qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), x_mid.data_ptr(),
-                                       rstd2.data_ptr(), gu.data_ptr(), act.data_ptr(), x_out.data_ptr(), _stream())
+                                       gu.data_ptr(), act.data_ptr(), x_out.data_ptr(), _stream())
     _lib.check(st, "llama_layer_forward")
-    return x_out, dict(x_in=x, qkv=qkv, o=o, o_full=o, lse=lse, x_mid=x_mid, gu=gu, rstd2=rstd2)
+    return x_out, dict(x_in=x, qkv=qkv, o=o, o_full=o, lse=lse, x_mid=x_mid, gu=gu)
 
 
 def vit_layer_forward(x, L, desc, B, n, LT, heads, ff, h, qkv, o, f):
@@ -530,14 +470,11 @@ def llama_layer_backward(dx_out, s, L, cos_t, sin_t, desc, B, S, LT, heads, ff, 
     dx_in = torch.empty((M, d), device=dev, dtype=bf)
     lib = _L()
     dact = None if lib.lhrs_gemm_swiglu_fusable(M, ff, d, d, 0) else torch.empty((M, ff), device=dev, dtype=bf)
-    fuse = s.get("rstd2") is not None and mlp_norm_bwd_fusable(M, d, ff)
-    part = torch.empty((4 * (ff // 256), M), device=dev, dtype=torch.float32) if fuse else None
-    srow = torch.empty(M, device=dev, dtype=torch.float32) if fuse else None
     st = lib.lhrs_llama_layer_backward(dx_out.data_ptr(), s["x_in"].data_ptr(), s["x_mid"].data_ptr(), s["qkv"].data_ptr(), s["o_full"].data_ptr(),
                                        s["lse"].data_ptr(), s["gu"].data_ptr(), L["ln1_w"].data_ptr(), L["ln2_w"].data_ptr(), L["qkv_wT"].data_ptr(),
                                        L["o_wT"].data_ptr(), L["gu_wT"].data_ptr(), L["down_wT"].data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(),
                                        desc.data_ptr(), B, S, LT, d, heads, ff, float(eps), dh.data_ptr(), d_o.data_ptr(), dqkv.data_ptr(),
-                                       delta.data_ptr(), _p(dact), dx_in.data_ptr(), _p(s.get("rstd2")) if fuse else None, _p(part), _p(srow), _stream())
+                                       delta.data_ptr(), _p(dact), dx_in.data_ptr(), _stream())
     _lib.check(st, "llama_layer_backward")
     return dx_in, dh          # (d loss / d x, d loss / d x_mid)
 

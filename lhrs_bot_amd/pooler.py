@@ -33,7 +33,7 @@ class AttnPooler:
         assert encoder_hidden_size == hidden_size, "in_proj is None in every shipped config (common_arch.py:112-115)"
         assert num_query == sum(STAGE_NUM)
         self.device = torch.device(device)
-        hk.ensure_streamk_workspace(self.device)
+        hk.ensure_gemm_workspace(self.device)
         self.nq, self.nl, self.heads, self.d, self.out_dim = num_query, num_layers, num_attention_heads, hidden_size, output_size
         d, od = hidden_size, output_size
         # (name, shape, no_decay) in a fixed order; names follow the reference state_dict (checkpoint row f-1)

@@ -203,7 +203,7 @@ class TextModal:
     def __init__(self, config=None, device="cuda", layers=32, dim=4096, ff=11008, heads=32, vocab=32000, eps=1e-5,
                  rope_theta=10000.0, max_pos=4096):  # LLaMA-2 max_position_embeddings; S reaches model_max_length 2048 + 143 image tokens
         self.device = torch.device(device)
-        hk.ensure_streamk_workspace(self.device)   # the persistent GEMM's stream-K tail needs a caller-owned workspace
+        hk.ensure_gemm_workspace(self.device)
         self.nl, self.d, self.ff, self.heads, self.vocab, self.eps = layers, dim, ff, heads, vocab, float(eps)
         self.hd = dim // heads
         self.tokenizer = SyntheticTokenizer()
@@ -496,9 +496,7 @@ class TextModal:
         if self.base8:
             h, hq = hk.rmsnorm_fwd_q(x_mid, L["ln2_w"], self.eps, want_bf16=lo is not None and "gu" in lo.groups)
         else:
-            h, rstd2 = hk.rmsnorm_fwd(x_mid, L["ln2_w"], self.eps, save_rstd=True, out=h if tail is None else None)
-            if rec is not None:
-                rec["rstd2"] = rstd2     # lets the backward fold this norm's gradient into the d-gate|up GEMM (kernels.mlp_backward_fused)
+            h = hk.rmsnorm_fwd(x_mid, L["ln2_w"], self.eps, out=h if tail is None else None)
         gu, act, actq = self._gu_fwd(li, h, L["gu_w"], rec, q8=self._q8(L, "gu_w"), xq=hq, i8=self._i8(L, "gu_w"))
         x_out = self._lin(li, "down", act, L["down_w"], residual=x_mid, save=rec, q8=self._q8(L, "down_w"), xq=actq, i8=self._i8(L, "down_w"))
         if save is not None:
@@ -1109,21 +1107,17 @@ class TextModal:
                 continue
             gu, qkv = s["gu"], s["qkv"]
             dmq = None
-            if lo is None and not self.base8 and not self.base_int8 and "rstd2" in s and hk.mlp_norm_bwd_fusable(dx.shape[0], d, ff):
-                # frozen bf16 base, both MLP products whole rounds of the 256-row GEMM: RMSNorm backward inside the d-gate|up GEMM's epilogue
-                dx_mid = hk.mlp_backward_fused(dx, L["down_wT"], gu, L["gu_wT"], s["x_mid"], L["ln2_w"], s["rstd2"], ff, add=dx)
+            act = hk.swiglu_fwd(gu, ff) if lo is not None and "down" in lo.groups else None      # x of the down projection
+            dgu = self._down_bwd(li, dx, L["down_wT"], gu, act, s.get("T_down"), q8=self._q8(L, "down_wT"), dyq=dxq, drop=self._drop(s, "down"))
+            dguq = None
+            if self.base8:
+                dgu, dguq = dgu
+            h2 = hk.rmsnorm_fwd(s["x_mid"], L["ln2_w"], self.eps) if lo is not None and "gu" in lo.groups else None
+            dh = self._lin_bwd(li, "gu", dgu, L["gu_wT"], h2, s.get("T_gu"), q8=self._q8(L, "gu_wT"), dyq=dguq, drop=self._drop(s, "gu"))
+            if self.base8:
+                dx_mid, dmq = hk.rmsnorm_bwd_q(dh, s["x_mid"], L["ln2_w"], None, add=dx, eps=self.eps, out=dh)
             else:
-                act = hk.swiglu_fwd(gu, ff) if lo is not None and "down" in lo.groups else None      # x of the down projection
-                dgu = self._down_bwd(li, dx, L["down_wT"], gu, act, s.get("T_down"), q8=self._q8(L, "down_wT"), dyq=dxq, drop=self._drop(s, "down"))
-                dguq = None
-                if self.base8:
-                    dgu, dguq = dgu
-                h2 = hk.rmsnorm_fwd(s["x_mid"], L["ln2_w"], self.eps) if lo is not None and "gu" in lo.groups else None
-                dh = self._lin_bwd(li, "gu", dgu, L["gu_wT"], h2, s.get("T_gu"), q8=self._q8(L, "gu_wT"), dyq=dguq, drop=self._drop(s, "gu"))
-                if self.base8:
-                    dx_mid, dmq = hk.rmsnorm_bwd_q(dh, s["x_mid"], L["ln2_w"], None, add=dx, eps=self.eps, out=dh)
-                else:
-                    dx_mid = hk.rmsnorm_bwd(dh, s["x_mid"], L["ln2_w"], None, add=dx, eps=self.eps, out=dh)
+                dx_mid = hk.rmsnorm_bwd(dh, s["x_mid"], L["ln2_w"], None, add=dx, eps=self.eps, out=dh)
             do = self._lin_bwd(li, "o", dx_mid, L["o_wT"], s["o"], s.get("T_o"), q8=self._q8(L, "o_wT"), dyq=dmq, drop=self._drop(s, "o"))
             adesc, max_q = desc, S
             if tl is not None:

@@ -20,7 +20,7 @@ class VisionModal:
 
     def __init__(self, config=None, device="cuda", layers=24, dim=1024, ff=4096, heads=16, patch=14, img=224):
         self.device = torch.device(device)
-        hk.ensure_streamk_workspace(self.device)
+        hk.ensure_gemm_workspace(self.device)
         self.layers_n, self.dim, self.ff, self.heads, self.patch, self.img = layers, dim, ff, heads, patch, img
         self.n_patch = (img // patch) ** 2
         self.kp = (3 * patch * patch + 63) // 64 * 64  # im2col K padded to the GEMM's K % 64 rule (588 -> 640)

@@ -423,35 +423,3 @@ def test_module_level_layer_entry_points_equal_the_operator_path(monkeypatch):
     assert torch.equal(res["1"][0], res["0"][0])
     assert torch.equal(res["1"][1], res["0"][1])
     assert torch.equal(res["1"][2], res["0"][2])
-
-
-@pytest.mark.timeout(900)
-def test_norm_backward_in_the_gemm_epilogue_equals_the_separate_pass_end_to_end(monkeypatch):
-    """LHRS_FUSE_NORM_BWD=1 (the second RMSNorm's backward inside the d-gate|up GEMM's epilogue, off by default: measured slower) against the default
-    three-launch sequence on a whole step at micro-batch 15 (M = 4095: both MLP products are whole rounds of the 256-row GEMM), through the
-    module-level path and the operator path: same loss (the forward is the same), d loss / d image and the projector gradients to bf16 rounding."""
-    P = {"vit": OP.make_vit_params(seed=2), "pooler": OP.make_pooler_params(seed=1), "llama": OP.make_llama_params(seed=3, layers=3)}
-    g = torch.Generator().manual_seed(1515)
-    B, T = 15, 130
-    ids = torch.randint(3, 32000, (B, T), generator=g)
-    ids[:, 0], ids[:, 1] = 1, -200
-    labels = ids.clone()
-    labels[:, :2] = -100
-    batch = dict(rgb=torch.randn(B, 3, 224, 224, generator=g), input_ids=ids, labels=labels, attention_mask=ids.ne(0))
-    res = {}
-    for fuse, native in (("0", "1"), ("1", "1"), ("1", "0")):
-        monkeypatch.setenv("LHRS_FUSE_NORM_BWD", fuse)
-        monkeypatch.setenv("LHRS_NATIVE_LAYER", native)
-        assert hk.mlp_norm_bwd_fusable(B * 273, 4096, 11008) == (fuse == "1")
-        model = UniBind(("rgb", "text"), None, device=DEV, llama_layers=3).load_params(P)
-        model.prepare_for_training()
-        loss = model(batch)["total_loss"]
-        d_image = model.text.backward()
-        model.rgb_pooler.backward(d_image)
-        torch.cuda.synchronize()
-        res[(fuse, native)] = (loss.clone(), d_image.clone(), model.rgb_pooler.grad.clone())
-    base, fn, fo = res[("0", "1")], res[("1", "1")], res[("1", "0")]
-    assert torch.equal(fn[0], base[0]) and torch.equal(fo[0], base[0])
-    assert torch.equal(fn[1], fo[1]) and torch.equal(fn[2], fo[2])                       # module-level and operator path: the same launches
-    assert not torch.equal(fn[1], base[1])                                               # the switch really changed the arithmetic ...
-    assert rel(fn[1], base[1]) < 1e-2 and rel(fn[2], base[2]) < 1e-2, (rel(fn[1], base[1]), rel(fn[2], base[2]))   # ... by bf16 rounding only (measured 5.6e-3 / 4.1e-3 over 3 layers)

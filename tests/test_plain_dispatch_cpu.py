@@ -1,17 +1,17 @@
-"""Host-side rules of the plain long-k product dispatch (csrc/gemm.hip: lhrs_gemm_bf16_nt's first-call timing; csrc/gemm_u4.hip; csrc/vendor.cpp) that need no GPU:
-which problems are timed at all, and which problems the four-wave kernel's wrappers decline before they touch the device."""
-import ctypes
-
+"""Host-side rules of the plain long-k product dispatch (csrc/gemm.hip: lhrs_gemm_bf16_nt's shape rule; csrc/gemm_u4.hip) that need no GPU:
+which problems the four-wave kernel takes - a pure function of the shape, so that runs are bit-reproducible and every data-parallel rank runs the same
+kernels - and which problems its raw launch wrappers decline before they touch the device."""
 from lhrs_bot_amd import _lib
 
 
-def test_which_plain_products_are_decided_by_first_call_timing():
+def test_which_plain_products_take_the_four_wave_kernel_is_a_pure_shape_rule():
     lib = _lib.load()
-    takes = lambda *a: lib.lhrs_gemm_vendor_takes(*a)
+    takes = lambda *a: lib.lhrs_gemm_u4_takes(*a)
     ok = (8190, 4096, 11008, 11008, 11008, 4096, 0, 0, 0, 0, 0, 1.0)        # M, N, K, lda, ldb, ldc, ldr, bias, act, f32 out, accumulate, alpha
     try:
-        lib.lhrs_gemm_set_vendor(1, 4096)
+        lib.lhrs_gemm_set_u4(1)
         assert takes(*ok) == 1
+        assert all(takes(*ok) == 1 for _ in range(200))                                       # no state: the answer never changes (the old first-call timing had a 96-problem cap)
         assert takes(8190, 4096, 4096, 4096, 4096, 4104, 4104, 0, 0, 0, 0, 1.0) == 1          # strided output + residual, 16-B rows
         for i, v in ((7, 1), (8, 1), (9, 1), (10, 1), (11, 0.5)):                            # bias, activation, f32 output, accumulate, alpha != 1
             a = list(ok); a[i] = v
@@ -21,10 +21,18 @@ def test_which_plain_products_are_decided_by_first_call_timing():
         assert takes(8190, 4096, 2048, 2048, 2048, 4096, 0, 0, 0, 0, 0, 1.0) == 0             # short k-loop
         assert takes(8190, 4096, 4128, 4128, 4128, 4096, 0, 0, 0, 0, 0, 1.0) == 0             # K % 64 != 0
         assert takes(8190, 4096, 11008, 11008, 11008, 4100, 0, 0, 0, 0, 0, 1.0) == 0          # output rows not 16-B aligned
-        lib.lhrs_gemm_set_vendor(0, 0)
-        assert takes(*ok) == 0                                                                # library removed from the candidates
+        # the tile count decides (>= 80 % of one round of the CUs): the reference's micro-batch 8 (M = 2184: 9 x 16 = 144 tiles) and the projector
+        # product (M = 4320, N = 1024: 68 tiles) stay on the 144-row / small-tile kernels; ragged row counts around a boundary flip exactly once
+        assert takes(2184, 4096, 11008, 11008, 11008, 4096, 0, 0, 0, 0, 0, 1.0) == 0
+        assert takes(4320, 1024, 4096, 4096, 4096, 1024, 0, 0, 0, 0, 0, 1.0) == 0
+        assert takes(3840, 4096, 22016, 22016, 22016, 4096, 0, 0, 0, 0, 0, 1.0) == 1          # 240 tiles
+        assert takes(3822, 32000, 4096, 4096, 4096, 32000, 0, 0, 0, 0, 0, 1.0) == 1           # lm_head on the supervised rows
+        got = [takes(M, 4096, 4096, 4096, 4096, 4096, 0, 0, 0, 0, 0, 1.0) for M in range(1024, 8192, 64)]
+        assert got == sorted(got) and got[0] == 0 and got[-1] == 1
+        lib.lhrs_gemm_set_u4(0)
+        assert takes(*ok) == 0                                                                # kernel A/B switch: the 16-wave kernels everywhere
     finally:
-        lib.lhrs_gemm_set_vendor(1, 4096)
+        lib.lhrs_gemm_set_u4(1)
 
 
 def test_four_wave_kernel_wrappers_decline_before_touching_the_device():
@@ -42,6 +50,3 @@ def test_four_wave_kernel_wrappers_decline_before_touching_the_device():
     rope = lambda rope_cols, cos=0x50000000, sin=0x60000000, pos_mod=273: lib.lhrs_gemm_u4_rope(A, 4096, B, 4096, C, 12288, 2048, 12288, 4096, cos, sin, pos_mod,
                                                                                               0, rope_cols, None)
     assert rope(8192 + 128) == 1 and rope(16384) == 1 and rope(8192, cos=None) == 1 and rope(8192, pos_mod=0) == 1 and rope(8192, sin=0x60000004) == 1
-    assert isinstance(lib.lhrs_gemm_u4_problems(), int) and lib.lhrs_gemm_u4_problems() >= 0
-    st = (ctypes.c_long * 3)()
-    assert lib.lhrs_gemm_vendor_stats(ctypes.addressof(st)) == 0 and st[1] + st[2] == st[0]

@@ -1,7 +1,6 @@
 """All-shape throughput of the bf16 NT GEMM with the library given by LHRS_HIP_LIB (kernel A/B of build variants on one box):
    for v in base X; do LHRS_HIP_LIB=... python tools/gemm_ab.py 30; done"""
 import os as _os
-_os.environ.setdefault("LHRS_GEMM_VENDOR", "0")   # these tools measure the hand-written kernels, not the vendor library
 import os
 import sys
 

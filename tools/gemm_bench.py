@@ -2,7 +2,6 @@
 kernel with one workgroup per tile (persistent = 0) vs one persistent workgroup per CU (persistent = 1, default), alternating on the same
 box, plus a bit-exactness check between the two (same arithmetic, different schedule).   python tools/gemm_bench.py [micro_batch] [reps]"""
 import os as _os
-_os.environ.setdefault("LHRS_GEMM_VENDOR", "0")   # these tools measure the hand-written kernels, not the vendor library
 import os
 import sys
 

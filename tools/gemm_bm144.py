@@ -1,7 +1,6 @@
 """A/B of the two persistent tile heights (lhrs_gemm_set_bm144: 0 = 256 rows, 2 = 144 rows) on the eight GEMMs of one LLaMA decoder layer
 (forward + activation-gradient backward) at M = B * 273 token rows:  python tools/gemm_bm144.py [B=8] [iters=20]"""
 import os as _os
-_os.environ.setdefault("LHRS_GEMM_VENDOR", "0")   # these tools measure the hand-written kernels, not the vendor library
 import os
 import sys
 

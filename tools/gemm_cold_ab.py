@@ -2,7 +2,6 @@
 what tools/gemm_ab.py measures) and over a ring of distinct operand sets larger than the 256 MB cache (what a training step does: every layer has its own
 weights and activations).  TFLOP/s per shape.   python tools/gemm_cold_ab.py [micro-batch]"""
 import os as _os
-_os.environ.setdefault("LHRS_GEMM_VENDOR", "0")   # these tools measure the hand-written kernels, not the vendor library
 import os
 import sys
 

@@ -1,5 +1,4 @@
 import os as _os
-_os.environ.setdefault("LHRS_GEMM_VENDOR", "0")   # these tools measure the hand-written kernels, not the vendor library
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,6 +1,5 @@
 """Does a power-of-two row stride hurt the 256x256 GEMM?  Same product with operands at stride K and K + pad elements."""
 import os as _os
-_os.environ.setdefault("LHRS_GEMM_VENDOR", "0")   # these tools measure the hand-written kernels, not the vendor library
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,6 +1,5 @@
 """Per-shape time of every bf16 GEMM launch of one stage-1 step (events around each call; B=30): where the small products go."""
 import os as _os
-_os.environ.setdefault("LHRS_GEMM_VENDOR", "0")   # these tools measure the hand-written kernels, not the vendor library
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

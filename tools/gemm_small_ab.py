@@ -1,6 +1,5 @@
 """Small-tile GEMM policy A/B (ViT / projector shapes at micro-batch B): python tools/gemm_small_ab.py [B=8]"""
 import os as _os
-_os.environ.setdefault("LHRS_GEMM_VENDOR", "0")   # these tools measure the hand-written kernels, not the vendor library
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

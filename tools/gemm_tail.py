@@ -1,6 +1,5 @@
 """Tail-row rule of gemm_launch: the same product with and without the cut, on micro-batch-32 shapes (M = 32 * 273 = 8736)."""
 import os as _os
-_os.environ.setdefault("LHRS_GEMM_VENDOR", "0")   # these tools measure the hand-written kernels, not the vendor library
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

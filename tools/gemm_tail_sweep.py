@@ -1,7 +1,6 @@
 """Kernel choice for the tail rows of a row-split product (M = 8736 = 32 x 273: 8192 rows on 256-row tiles + 544 rows): us per launch by kernel.
    python tools/gemm_tail_sweep.py [M_tail]"""
 import os as _os
-_os.environ.setdefault("LHRS_GEMM_VENDOR", "0")   # these tools measure the hand-written kernels, not the vendor library
 import os
 import sys
 

@@ -1,7 +1,6 @@
 """Tile-policy sweep for the ViT-sized products (M = B * 257 rows, d = 1024): us per launch for the small-tile kernel, the 144-row and the
 256-row persistent kernels.   python tools/gemm_vit_sweep.py [micro-batch]"""
 import os as _os
-_os.environ.setdefault("LHRS_GEMM_VENDOR", "0")   # these tools measure the hand-written kernels, not the vendor library
 import os
 import sys
 
