@@ -65,6 +65,43 @@ def test_gemm_u4_four_wave_kernel_bit_identical_to_the_16_wave_kernel(M, N, K, r
     assert not hk.gemm_u4_nt(a[:, :96] if K > 96 else a, b[:, :96] if K > 96 else b, out_u[:, :N])            # K % 64 != 0 / K < 128: declined
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("M,N,K", [(8190, 4096, 4096), (8190, 4096, 11008), (8190, 4096, 12288), (8190, 4096, 22016), (3822, 32000, 4096)])
+def test_gemm_u4_soak_200_launches_under_load_every_result_identical(M, N, K):
+    """gemm_u4_kernel waits for its LDS-DMA with a COUNTED `s_waitcnt vmcnt(15)` (stage kt+1 has landed, the 15 younger pieces of stage kt+2 stay in flight;
+    csrc/gemm_u4_body.inc: WAITY).  A counted wait is only sound if the pieces of one wave retire in issue order (MI355X_MICROARCH.md: `vmcnt(N)` waits for the
+    outstanding - N OLDEST operations) and nothing that may retire out of order shares the counter inside the k-loop (the previous tile's stores are drained by the
+    `vmcnt(0)` at the top of every tile).  A premature pass would read a stale LDS stage and produce wrong tiles that come and go with memory load - so: 200
+    back-to-back launches per LLaMA shape of the step (o, down, d-qkv, d-gate|up at micro-batch 30; lm_head on the supervised rows) while a side stream keeps the
+    memory system busy (pinned host <-> device copies on the DMA engines, device copies between the launches), every result compared ON THE DEVICE with the first
+    one, and the first one bit-identical to the 16-wave kernel (which waits vmcnt(0) only)."""
+    g = torch.Generator(device="cpu").manual_seed(K + N)
+    a = bf(torch.randn(M, K, generator=g)).to(DEV)
+    b = bf(torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    want = hk.gemm_nt(a, b)                                        # fixture: u4 off -> gemm_nt_256s_kernel
+    first = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    assert hk.gemm_u4_nt(a, b, first)
+    assert torch.equal(first, want)
+    side = torch.cuda.Stream()
+    big = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
+    big2 = torch.empty_like(big)
+    host = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
+    out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    bad = torch.zeros((), device=DEV, dtype=torch.int64)
+    for it in range(200):
+        with torch.cuda.stream(side):
+            big2.copy_(big, non_blocking=True)
+            if it % 4 == 0:
+                big[: host.numel()].copy_(host, non_blocking=True)
+            elif it % 4 == 2:
+                host.copy_(big2[: host.numel()], non_blocking=True)
+        out.fill_(0)
+        assert hk.gemm_u4_nt(a, b, out)
+        bad += (out != first).sum()
+    torch.cuda.synchronize()
+    assert int(bad) == 0, f"{int(bad)} elements differed from the first launch over 200 launches"
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 1024, 1024), (2184, 4096, 4096), (1000, 12288, 4096),
                                    (273, 4096, 11008), (64, 64, 64), (33, 132, 128), (1152, 1024, 4096),
                                    (4095, 4096, 128), (3000, 4104, 128), (8190, 4096, 4096), (2184, 22016, 4096),
