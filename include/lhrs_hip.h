@@ -175,12 +175,19 @@ int lhrs_gemm_set_u4(int on);
 int lhrs_gemm_u4_takes(int M, int N, int K, int lda, int ldb, int ldc, int ldr, int has_bias, int act, int out_f32, int accumulate, float alpha);
 int lhrs_gemm_u4_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
                     void* stream);
-/* the four-wave kernel with RoPE in its epilogue (lhrs_gemm_rope_fwd's semantics without a LoRA pair; bit-identical): u4_rope is the raw launch (0 launched,
- * 1 not its problem); set_u4_rope(1) / LHRS_GEMM_U4_ROPE=1 makes lhrs_gemm_rope_fwd use it for M >= 1024 without a LoRA pair.  Off by default: 8 % faster back
- * to back, no faster inside the power-capped step (csrc/gemm.hip) */
-int lhrs_gemm_set_u4_rope(int on);
+/* the four-wave kernel with the decoder layer's fused epilogues (lhrs_gemm_rope_fwd / lhrs_gemm_swiglu_fwd / lhrs_gemm_swiglu_bwd semantics without a LoRA pair;
+ * bit-identical to them): raw launches, 0 launched, 1 not its problem.  The three operator entry points above take it by the shape rule u4_fused_takes(M, tile
+ * columns, K, K2): no LoRA pair, K >= 4096, M >= 1024, tiles that fill >= 80 % of a round of the CUs with <= 15 % of the last round idle (tile columns: N / 256
+ * for RoPE, ff / 128 for SwiGLU forward, ff / 256 for SwiGLU backward).  u4_main_rows(M, N): rows of a plain product that go to the four-wave kernel when its last
+ * round would be mostly empty (the rest: small tiles / split-K over the workspace); = M when nothing is cut. */
+int lhrs_gemm_u4_fused_takes(int M, int tiles_n, int K, int K2);
+int lhrs_gemm_u4_main_rows(int M, int N);
 int lhrs_gemm_u4_rope(const void* X, int ldx, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const float* cos_t,
                       const float* sin_t, int pos_mod, int pos0, int rope_cols, void* stream);
+int lhrs_gemm_u4_swiglu_fwd(const void* X, int ldx, const void* Wgu, int ldw, void* gu, int ld_gu, void* act, int ld_act, int M, int ff, int K,
+                            void* stream);
+int lhrs_gemm_u4_swiglu_bwd(const void* dY, int ldy, const void* WdT, int ldw, const void* gu, void* dgu, int ld_gu, int M, int ff, int K,
+                            void* stream);
 
 /* ---- LoRA gradients (peft lora.Linear backward; lhrs/models/text_modal.py:133-151) ------------------------- *
  * C[KP,N] (+)= P[M,KP]^T . Q[M,N]: dA = (s dy B)^T x and dB^T = (s x A^T)^T dy straight from token-major operands.  */

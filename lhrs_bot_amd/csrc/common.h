@@ -97,7 +97,11 @@ __device__ __forceinline__ void rope_pair(float a, float b, float co, float si, 
 }
 
 // ---- activations --------------------------------------------------------------------------------
-__device__ __forceinline__ float quick_gelu(float x) { return x / (1.f + __expf(-1.702f * x)); }
+// the logistic function with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division (a ten-instruction sequence per element: in the SwiGLU epilogues
+// of the four-wave GEMM that was half the write-out's VALU time).  EVERY kernel that needs sigma / silu / quick_gelu goes through here, so fused and unfused paths
+// keep agreeing bit for bit (tests/test_kernels_gpu.py: test_gemm_fused_swiglu_bit_identical_to_unfused)
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float quick_gelu(float x) { return x * sigmoid_f(1.702f * x); }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
@@ -118,6 +122,6 @@ __device__ __forceinline__ bool drop_keep(unsigned seed, long idx, unsigned thre
   x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
   return x >= thresh;
 }
-__device__ __forceinline__ float silu(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float silu(float x) { return x * sigmoid_f(x); }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

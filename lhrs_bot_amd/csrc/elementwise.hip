@@ -120,7 +120,7 @@ __global__ void swiglu_bwd_kernel(const bf16_t* dact, const bf16_t* gu, bf16_t* 
     unpack8(*reinterpret_cast<const uint4*>(dact + row * F + c * 8), d);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float sg = 1.f / (1.f + __expf(-g[i]));
+      const float sg = sigmoid_f(g[i]);
       du[i] = d[i] * g[i] * sg;
       dg[i] = d[i] * u[i] * sg * (1.f + g[i] * (1.f - sg));
     }

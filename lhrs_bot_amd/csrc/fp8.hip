@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_q_kernel(const bf16_t* __restr
       unpack8(*reinterpret_cast<const uint4*>(dact + row * F + c * 8), d);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float sg = 1.f / (1.f + __expf(-gv[e]));
+        const float sg = sigmoid_f(gv[e]);
         ku[i][e] = bf2f(f2bf(d[e] * gv[e] * sg));
         kg[i][e] = bf2f(f2bf(d[e] * uv[e] * sg * (1.f + gv[e] * (1.f - sg))));
         m = fmaxf(m, fmaxf(fabsf(kg[i][e]), fabsf(ku[i][e])));

@@ -521,7 +521,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
             unpack8(val, d); unpack8(gq, gg); unpack8(uq, uu);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              const float sg = 1.f / (1.f + __expf(-gg[e]));
+              const float sg = sigmoid_f(gg[e]);
               du[e] = d[e] * gg[e] * sg;
               dg[e] = d[e] * uu[e] * sg * (1.f + gg[e] * (1.f - sg));
             }
@@ -1079,6 +1079,42 @@ extern "C" int lhrs_gemm_u4_takes(int M, int N, int K, int lda, int ldb, int ldc
 static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* bias,
                        const void* residual, int ldr, int act, int out_f32, int accumulate, float alpha, const void* A2,
                        int lda2, const void* B2, int ldb2, int K2, void* stream);
+// The fused-epilogue products (qkv + RoPE, gate|up + SwiGLU, d-down + SwiGLU') on the four-wave kernel: no LoRA pair in the k-loop (that lives in the 16-wave
+// kernel), K >= 4096, and tiles that fill the chip with at most 15 % of the last round idle - the four-wave kernel has one tile height and no tail-row split for
+// the fused epilogues (micro-batch 30: 6.0 / 10.75 / 5.375 rounds: taken; the reference's micro-batch 8, M = 2184: 1.69 / 3.02 / 1.51 rounds: the 16-wave kernels with
+// their 144-row tiles and tail-row rules).  kind: 0 RoPE (tiles_n = N / 256), 1 SwiGLU forward (ff / 128), 2 SwiGLU backward (ff / 256).  A pure function of the shape.
+extern "C" int lhrs_gemm_u4_fused_takes(int M, int tiles_n, int K, int K2) {
+  plain_env();
+  const long P = num_cus(), T = (long)cdiv(M, 256) * tiles_n;
+  return g_u4_on == 1 && K2 == 0 && K >= 4096 && K % 64 == 0 && M >= 1024 && 5 * T >= 4 * P && 20 * ((T + P - 1) / P * P) <= 23 * T;
+}
+extern "C" int lhrs_gemm_u4_rope(const void* X, int ldx, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const float* cos_t, const float* sin_t,
+                                 int pos_mod, int pos0, int rope_cols, void* stream);
+extern "C" int lhrs_gemm_u4_swiglu_fwd(const void* X, int ldx, const void* Wgu, int ldw, void* gu, int ld_gu, void* act, int ld_act, int M, int ff, int K, void* stream);
+extern "C" int lhrs_gemm_u4_swiglu_bwd(const void* dY, int ldy, const void* WdT, int ldw, const void* gu, void* dgu, int ld_gu, int M, int ff, int K, void* stream);
+#define U4_FUSED_TRY(kind_, flopsN_, call_)                                                                          \
+  {                                                                                                                  \
+    const int pslot_ = prof_count(M, flopsN_, K, kind_, (hipStream_t)stream);                                        \
+    const int st_ = call_;                                                                                           \
+    if (st_ == 0) { prof_end(pslot_, (hipStream_t)stream); return 0; }                                               \
+    if (st_ < 0) return st_;                                                                                         \
+    if (pslot_ >= 0) { g_prof.used--; g_prof.seen[kind_]--; }                                                        \
+    if (g_prof.on) { g_prof.launches_all--; g_prof.total_flops_all -= 2.0 * M * (double)(flopsN_) * K; }             \
+  }
+
+static int tail_rows_splitk(const bf16_t* A, int lda, const bf16_t* B, int ldb, bf16_t* C, int ldc, int M_tail, int N, int K, const bf16_t* residual, int ldr,
+                            float alpha, hipStream_t s);
+// The four-wave kernel walks whole 256x256 tiles in ceil(T / P) rounds of the P CUs.  When the last round would be mostly empty (M = 8736, BASELINE configs[3]'s
+// micro-batch 32: 35 x 16 = 560 tiles = 2.19 rounds -> 3) the rows are cut behind the last tile row the whole rounds cover: those rows go to gemm_u4_kernel, the
+// remaining rows (544 of 8736) to gemm_launch's kernels (small tiles, split-K over the workspace for the long k-loops) - disjoint rows of C.  Returns the number of
+// rows for gemm_u4_kernel (M itself: no cut).  A pure function of the shape.
+static int u4_main_rows(int M, long tiles_n) {
+  const long P = num_cus(), tm = cdiv(M, 256), T = tm * tiles_n, full = T / P;
+  if (T % P == 0 || full < 1 || 20 * ((T + P - 1) / P * P) <= 23 * T) return M;        // whole rounds, or the idle share of the last round is <= 15 %
+  const long tm_main = full * P / tiles_n;
+  return tm_main >= 1 && tm_main < tm ? (int)(tm_main * 256) : M;
+}
+extern "C" int lhrs_gemm_u4_main_rows(int M, int N) { return u4_main_rows(M, cdiv(N, 256)); }
 
 extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N,
                                  int K, const void* bias, const void* residual, int ldr, int act, int out_f32,
@@ -1086,12 +1122,21 @@ extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
   if (lhrs_gemm_u4_takes(M, N, K, lda, ldb, ldc, residual ? ldr : 0, bias != nullptr, act, out_f32, accumulate, alpha) &&
       ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0) && ((size_t)C % 16 == 0) && ((size_t)residual % 16 == 0)) {
     hipStream_t s = (hipStream_t)stream;
-    const int slot = prof_count(M, N, K, 6, s);
-    const int st = lhrs_gemm_u4_nt(A, lda, B, ldb, C, ldc, M, N, K, residual, ldr, stream);
-    if (st == 0) { prof_end(slot, s); return 0; }
+    const int Mu = u4_main_rows(M, cdiv(N, 256));
+    const int slot = prof_count(Mu, N, K, 6, s);
+    const int st = lhrs_gemm_u4_nt(A, lda, B, ldb, C, ldc, Mu, N, K, residual, ldr, stream);
+    if (st == 0) {
+      prof_end(slot, s);
+      if (Mu == M) return 0;
+      const int ts = tail_rows_splitk((const bf16_t*)A + (long)Mu * lda, lda, (const bf16_t*)B, ldb, (bf16_t*)C + (long)Mu * ldc, ldc, M - Mu, N, K,
+                                      residual ? (const bf16_t*)residual + (long)Mu * ldr : nullptr, ldr, 1.f, s);
+      if (ts <= 0) return ts;
+      return gemm_launch((const bf16_t*)A + (long)Mu * lda, lda, B, ldb, (bf16_t*)C + (long)Mu * ldc, ldc, M - Mu, N, K, nullptr,
+                         residual ? (const bf16_t*)residual + (long)Mu * ldr : nullptr, ldr, 0, 0, 0, 1.f, nullptr, 0, nullptr, 0, 0, stream);
+    }
     if (st < 0) return st;
     if (slot >= 0) { g_prof.used--; g_prof.seen[6]--; }   // not its problem after all (addressing limits): the slot goes back (it was the last one handed out)
-    if (g_prof.on) { g_prof.launches_all--; g_prof.total_flops_all -= 2.0 * M * N * K; }
+    if (g_prof.on) { g_prof.launches_all--; g_prof.total_flops_all -= 2.0 * Mu * N * K; }
   }
   return gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, out_f32, accumulate, alpha, nullptr, 0, nullptr, 0,
                      0, stream);
@@ -1106,6 +1151,30 @@ extern "C" int lhrs_gemm_bf16_nt_lora(const void* A, int lda, const void* B, int
                "gemm_lora: bad second operand pair (K2=%d lda2=%d ldb2=%d)", K2, lda2, ldb2);
   return gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, 0, out_f32, accumulate, alpha, A2, lda2, B2, ldb2, K2,
                      stream);
+}
+
+// The tail rows of a row-split product with a LONG k-loop (M = 8736: 544 rows x 4096 columns = 160 tiles of 128^2, each walking K = 11008 .. 22016 alone: 100 - 190
+// us at 500 TFLOP/s, tools/gemm_tail_sweep.py): K is cut into slabs of ~4096 across blockIdx.y - f32 slabs in the registered workspace, summed in a fixed order with
+// the residual by one small launch - so that every CU has work for the whole tail.  0 launched, 1 not applicable (short k-loop, no workspace), -1 error.
+static int tail_rows_splitk(const bf16_t* A, int lda, const bf16_t* B, int ldb, bf16_t* C, int ldc, int M_tail, int N, int K, const bf16_t* residual, int ldr,
+                            float alpha, hipStream_t s) {
+  int dev = 0;
+  const int splits = K >= 8192 ? (K + 2048) / 4096 : 1;
+  if (splits <= 1 || N % 128 != 0 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || g_sk[dev].slabs == nullptr ||
+      (long)splits * M_tail * N * 4 > g_sk[dev].units * 256 * 256 * 4)
+    return 1;
+  const int ks = cdiv(K / 64, splits) * 64, used = cdiv(K, ks);
+  GemmArgs gt; memset(&gt, 0, sizeof(gt));
+  gt.A = A; gt.B = B; gt.C = g_sk[dev].slabs; gt.M = M_tail; gt.N = N; gt.K = K;
+  gt.lda = lda; gt.ldb = ldb; gt.ldc = N; gt.alpha = 1.f; gt.out_f32 = 1; gt.ksplit = ks; gt.drop_scale = 1.f;
+  gt.tilesM = cdiv(M_tail, 128); gt.tilesN = cdiv(N, 128);
+  if (g_prof.on) { g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M_tail * N * K; }
+  hipLaunchKernelGGL((gemm_nt_kernel<4, 4, 0>), dim3(gt.tilesM * gt.tilesN, used), dim3(256), 0, s, gt);
+  const long work = (long)M_tail * (N / 4);
+  int rg = (int)((work + 255) / 256); if (rg > 8192) rg = 8192;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, s, (const float*)g_sk[dev].slabs, C, (long)ldc, M_tail, N, used, alpha, residual, (long)ldr);
+  LHRS_CHECK_LAUNCH("gemm_tail_splitk");
+  return 0;
 }
 
 static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* bias,
@@ -1175,27 +1244,10 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
         const long esz = out_f32 ? 4 : 2;
         t_split_ok = false;
         int rc = gemm_launch(A, lda, B, ldb, C, ldc, M_main, N, K, bias, residual, ldr, act, out_f32, accumulate, alpha, A2, lda2, B2, ldb2, K2, stream);
-        // the tail rows of a LONG k-loop (M = 8736: 544 rows x 4096 columns = 160 tiles of 128^2, each walking K = 11008 .. 22016 alone: 100 - 190
-        // us at 500 TFLOP/s, tools/gemm_tail_sweep.py): cut K into slabs of ~4096 across blockIdx.y - f32 slabs in the registered workspace,
-        // summed in a fixed order with the residual by one small launch - so that every CU has work for the whole tail
-        int dev = 0;
-        const int splits = K >= 8192 ? (K + 2048) / 4096 : 1;
-        if (!rc && splits > 1 && !out_f32 && K2 == 0 && bias == nullptr && act == 0 && N % 128 == 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 &&
-            dev < 16 && g_sk[dev].slabs != nullptr && (long)splits * M_tail * N * 4 <= g_sk[dev].units * 256 * 256 * 4) {
-          const int ks = cdiv(K / 64, splits) * 64, used = cdiv(K, ks);
-          GemmArgs gt; memset(&gt, 0, sizeof(gt));
-          gt.A = (const bf16_t*)A + (long)M_main * lda; gt.B = (const bf16_t*)B; gt.C = g_sk[dev].slabs; gt.M = M_tail; gt.N = N; gt.K = K;
-          gt.lda = lda; gt.ldb = ldb; gt.ldc = N; gt.alpha = 1.f; gt.out_f32 = 1; gt.ksplit = ks; gt.drop_scale = 1.f;
-          gt.tilesM = cdiv(M_tail, 128); gt.tilesN = cdiv(N, 128);
-          if (g_prof.on) { g_prof.launches_all++; g_prof.total_flops_all += 2.0 * M_tail * N * K; }
-          hipLaunchKernelGGL((gemm_nt_kernel<4, 4, 0>), dim3(gt.tilesM * gt.tilesN, used), dim3(256), 0, s, gt);
-          const long work = (long)M_tail * (N / 4);
-          int rg = (int)((work + 255) / 256); if (rg > 8192) rg = 8192;
-          hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, s, (const float*)g_sk[dev].slabs, (bf16_t*)C + (long)M_main * ldc, (long)ldc, M_tail, N,
-                             used, alpha, residual ? (const bf16_t*)residual + (long)M_main * ldr : nullptr, (long)ldr);
-          t_split_ok = true;
-          LHRS_CHECK_LAUNCH("gemm_tail_splitk");
-          return 0;
+        if (!rc && !out_f32 && K2 == 0 && bias == nullptr && act == 0) {
+          const int ts = tail_rows_splitk((const bf16_t*)A + (long)M_main * lda, lda, (const bf16_t*)B, ldb, (bf16_t*)C + (long)M_main * ldc, ldc, M_tail, N, K,
+                                          residual ? (const bf16_t*)residual + (long)M_main * ldr : nullptr, ldr, alpha, s);
+          if (ts <= 0) { t_split_ok = true; return ts; }
         }
         if (!rc)
           rc = gemm_launch((const bf16_t*)A + (long)M_main * lda, lda, B, ldb, (char*)C + (long)M_main * ldc * esz, ldc, M_tail, N, K, bias,
@@ -1288,6 +1340,8 @@ extern "C" int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int
                                     int K2, void* gu, int ld_gu, void* act, int ld_act, int M, int ff, int K, void* stream) {
   LHRS_REQUIRE(M > 0 && ff > 0 && K > 0 && ff % 8 == 0 && ld_gu >= 2 * ff && ld_act >= ff && ld_gu % 8 == 0 && ld_act % 8 == 0,
                "gemm_swiglu_fwd: M=%d ff=%d K=%d ld_gu=%d ld_act=%d", M, ff, K, ld_gu, ld_act);
+  if (ff % 128 == 0 && lhrs_gemm_u4_fused_takes(M, ff / 128, K, K2))
+    U4_FUSED_TRY(1, 2 * ff, lhrs_gemm_u4_swiglu_fwd(X, ldx, Wgu, ldw, gu, ld_gu, act, ld_act, M, ff, K, stream))
   if (!swiglu_fusable((long)cdiv(M, 256) * (ff / 128), ff, K, K2, ldx, ldw)) {
     if (gemm_launch(X, ldx, Wgu, ldw, gu, ld_gu, M, 2 * ff, K, nullptr, nullptr, 0, 0, 0, 0, 1.f, A2, lda2, B2, ldb2, K2, stream)) return -1;
     LHRS_REQUIRE(ld_gu == 2 * ff && ld_act == ff, "gemm_swiglu_fwd: the unfused fallback needs dense gu / act");
@@ -1335,15 +1389,6 @@ extern "C" int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int
 // applied in the GEMM epilogue: columns [0, rope_cols) are heads of 128 that get rotated with the position m % pos_mod + pos0 of
 // their row, the remaining columns (v) are stored as computed.  Bit-identical to lhrs_gemm_bf16_nt(_lora) followed by lhrs_rope; that
 // pair is also the fallback when the 256-tile kernel does not apply.
-extern "C" int lhrs_gemm_u4_rope(const void* X, int ldx, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const float* cos_t, const float* sin_t,
-                                 int pos_mod, int pos0, int rope_cols, void* stream);
-static int g_u4_rope = -1;
-extern "C" int lhrs_gemm_set_u4_rope(int on) { g_u4_rope = on ? 1 : 0; return 0; }
-static bool u4_rope_on() {
-  if (g_u4_rope < 0) { const char* e = getenv("LHRS_GEMM_U4_ROPE"); g_u4_rope = (e != nullptr && e[0] == '1') ? 1 : 0; }
-  plain_env();
-  return g_u4_rope == 1 && g_u4_on == 1;   // LHRS_GEMM_U4=0 / lhrs_gemm_set_u4(0): the 16-wave kernels everywhere
-}
 extern "C" int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw, const void* A2, int lda2, const void* B2, int ldb2, int K2,
                                   void* C, int ldc, int M, int N, int K, const float* cos_t, const float* sin_t, int pos_mod, int pos0,
                                   int rope_cols, int head_dim, void* stream) {
@@ -1358,17 +1403,8 @@ extern "C" int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw
     if (rope_cols == 0) return 0;
     return lhrs_rope(C, ldc, M, rope_cols / head_dim, head_dim, cos_t, sin_t, nullptr, pos_mod, pos0, 0, stream);
   }
-  // the four-wave kernel's RoPE variant (gemm_u4.hip), OPT-IN (LHRS_GEMM_U4_ROPE=1): same result bit for bit, 666 vs 722 us at M = 8190 and 218 vs 225 at M = 2184
-  // back to back (tools/gemm_u4_rope_ab.py) - but inside the power-capped step 634-636 vs 639 us per launch and no faster a step (156.2-156.9 vs 157.4-157.7
-  // samples/s, two same-box pairs): stall removal converts at 15-20 % there, and at K = 4096 this loop has little else to offer
-  if (K2 == 0 && u4_rope_on() && M >= 1024) {
-    const int pslot = prof_count(M, N, K, 3, (hipStream_t)stream);
-    const int st = lhrs_gemm_u4_rope(X, ldx, W, ldw, C, ldc, M, N, K, cos_t, sin_t, pos_mod, pos0, rope_cols, stream);
-    if (st == 0) { prof_end(pslot, (hipStream_t)stream); return 0; }
-    if (st < 0) return st;
-    if (pslot >= 0) { g_prof.used--; g_prof.seen[3]--; }
-    if (g_prof.on) { g_prof.launches_all--; g_prof.total_flops_all -= 2.0 * M * N * K; }
-  }
+  if (head_dim == 128 && rope_cols % 256 == 0 && lhrs_gemm_u4_fused_takes(M, cdiv(N, 256), K, K2))
+    U4_FUSED_TRY(3, N, lhrs_gemm_u4_rope(X, ldx, W, ldw, C, ldc, M, N, K, cos_t, sin_t, pos_mod, pos0, rope_cols, stream))
   GemmArgs g; memset(&g, 0, sizeof(g));
   g.A = (const bf16_t*)X; g.B = (const bf16_t*)W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = ldw; g.ldc = ldc;
   g.alpha = 1.f; g.A2 = (const bf16_t*)A2; g.B2 = (const bf16_t*)B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
@@ -1386,6 +1422,8 @@ extern "C" int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw
 extern "C" int lhrs_gemm_swiglu_bwd(const void* dY, int ldy, const void* WdT, int ldw, const void* A2, int lda2, const void* B2, int ldb2,
                                     int K2, const void* gu, void* dgu, int ld_gu, void* dact_scratch, int M, int ff, int K, void* stream) {
   LHRS_REQUIRE(M > 0 && ff > 0 && K > 0 && ff % 8 == 0 && ld_gu >= 2 * ff && ld_gu % 8 == 0, "gemm_swiglu_bwd: M=%d ff=%d K=%d ld_gu=%d", M, ff, K, ld_gu);
+  if (lhrs_gemm_u4_fused_takes(M, cdiv(ff, 256), K, K2))
+    U4_FUSED_TRY(2, ff, lhrs_gemm_u4_swiglu_bwd(dY, ldy, WdT, ldw, gu, dgu, ld_gu, M, ff, K, stream))
   if (!swiglu_fusable((long)cdiv(M, 256) * cdiv(ff, 256), ff, K, K2, ldy, ldw)) {
     LHRS_REQUIRE(dact_scratch != nullptr && ld_gu == 2 * ff, "gemm_swiglu_bwd: the unfused fallback needs a [M, ff] scratch and dense gu");
     if (gemm_launch(dY, ldy, WdT, ldw, dact_scratch, ff, M, ff, K, nullptr, nullptr, 0, 0, 0, 0, 1.f, A2, lda2, B2, ldb2, K2, stream)) return -1;
