@@ -248,7 +248,7 @@ def timed_run(engine, batch, steps, warmup, world, lib, on_timed_start=None):
     dt = time.perf_counter() - t0
     prof = (ctypes.c_double * 5)()
     _lib.check(lib.lhrs_gemm_profile_read(ctypes.addressof(prof)), "gemm_profile_read")
-    kinds = (ctypes.c_double * 21)()
+    kinds = (ctypes.c_double * 30)()
     _lib.check(lib.lhrs_gemm_profile_read_kinds(ctypes.addressof(kinds)), "gemm_profile_read_kinds")
     lib.lhrs_gemm_profile_enable(0)
     blocked = 0.0
@@ -264,12 +264,13 @@ def timed_run(engine, batch, steps, warmup, world, lib, on_timed_start=None):
 # the step in event-record idle time; 7 is coprime to the launch sequence's periods (2 forward, 3 backward plain launches per layer)
 PROFILE_STRIDE = int(os.environ.get("LHRS_GEMM_PROFILE_STRIDE", "7"))
 
-GEMM_KERNEL_DESC = ("gemm_nt_256s_kernel<ACT, 0, K2P, false> (256x256 tile, 16 waves): BK=64 double-buffered LDS stages via global_load_lds DMA, "
+GEMM_KERNEL_DESC = ("gemm_nt_256s_kernel<ACT, 0, K2P> (256x256 tile, 16 waves): BK=64 double-buffered LDS stages via global_load_lds DMA, "
                     "v_mfma_f32_16x16x32_bf16, persistent over tiles; its launches with a fused SwiGLU / RoPE epilogue and the plain launches of the 144-row "
                     "kernel (ViT / projector products) are timed separately under `variants`")
 GEMM_U4_DESC = ("gemm_u4_kernel (csrc/gemm_u4.hip; hand-written): 256x256x64 tile, FOUR waves of 128x128, accumulators in named AGPRs, two 64 KiB LDS stages via paced "
-                "global_load_lds DMA (one piece per 6 MFMAs), v_mfma_f32_16x16x32_bf16, persistent - every PLAIN long-k product whose tiles fill the chip (a shape rule in "
-                "lhrs_gemm_bf16_nt: no timing, no vendor library); the fused-epilogue launches are timed separately under `variants`")
+                "global_load_lds DMA (one piece per 6 MFMAs), v_mfma_f32_16x16x32_bf16, a workgroup's tiles walked as ONE stream of stages with each finished tile written "
+                "out inside the next tile's first stage - every PLAIN long-k product whose tiles fill the chip (a shape rule in lhrs_gemm_bf16_nt: no timing, no vendor "
+                "library); its instantiation with / without a residual is named in `kernel_instantiation`, the fused-epilogue instantiations are timed separately under `variants`")
 GEMM_144_DESC = ("gemm_nt_144s_kernel<ACT, 0> (144x256 tile, 12 waves, three 50 KiB LDS stages): the plain-epilogue kernel that carries the most time at this "
                  "micro-batch; the 256-row kernel's variants are listed under `variants`")
 
@@ -280,45 +281,49 @@ def plain_products_note(lib):
             "(lhrs_gemm_u4_takes): no first-call timing, no vendor library in the process path, bit-reproducible run to run and rank to rank")
 
 
+KIND_NAMES = ("gemm_nt_256s_kernel<ACT, 0, K2P> plain (16 waves, 256-row tiles)", "gemm_nt_256s_kernel<0, 1> SwiGLU-fwd epilogue", "gemm_nt_256s_kernel<0, 2> SwiGLU-bwd epilogue",
+              "gemm_nt_256s_kernel<0, 3> RoPE epilogue", "gemm_nt_144s_kernel<ACT, 0> plain (12 waves, 144-row tiles)", "gemm_u4_kernel<0, true> plain + residual (four waves)",
+              "gemm_u4_kernel<0, false> plain (four waves)", "gemm_u4_kernel<1, false> SwiGLU-fwd epilogue (four waves)", "gemm_u4_kernel<2, false> SwiGLU-bwd epilogue (four waves)",
+              "gemm_u4_kernel<3, false> RoPE epilogue (four waves)")
+KIND_DESC = {0: GEMM_KERNEL_DESC, 4: GEMM_144_DESC, 5: GEMM_U4_DESC, 6: GEMM_U4_DESC}
+
+
+def gemm_traffic(dom, B, scale_layers):
+    """HBM-side bytes per launch of the dominant kernel: a PMC pass cannot run inside this process (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE are separate profiled runs of
+    this same command); the committed summary of that pass on this tree is quoted, with its provenance, when it names the same kernel at the same micro-batch."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r05_gemm_traffic.json")))
+        if B == tj.get("micro_batch", 30) and scale_layers == 1.0 and KIND_NAMES[dom].startswith(tj["kernel_prefix"]):
+            return int(tj["traffic_bytes_per_launch"]), tj["bench_note"]
+    except Exception:  # noqa: BLE001
+        pass
+    return None, "not measured in this run (PMC passes are separate rocprofv3 runs; no committed pass for this kernel at this micro-batch)"
+
+
 def roofline_block(prof, kinds, steps, B, S, scale_layers, sclk=None, watts=None):
-    """`achieved` is ONE kernel's figure: the plain-epilogue 256x256 persistent kernel (kind 0, `gemm_nt_256s_kernel<ACT, 0, K2P, false>` in a rocprofv3
-    kernel trace) - or, when that kernel carries less time than the plain 144-row kernel (kind 4: micro-batch 8), that one - so that its
-    `avg_launch_us` can be held against the kernel's average duration in profiles/*_kernel_stats.csv; the other kinds are listed under `variants`."""
-    dom = max((0, 4, 6), key=lambda k: kinds[3 * k + 1])   # among the PLAIN-epilogue kernels: the one that carries the most (sampled) time
+    """`achieved` is ONE kernel's figure: among the PLAIN-epilogue kernel instantiations (kinds 0, 4, 5, 6: the names a rocprofv3 kernel trace lists) the one that carries
+    the most time, so that its `avg_launch_us` can be held against that kernel's average duration in profiles/*_kernel_stats.csv; every instantiation is listed under `variants`."""
+    dom = max((0, 4, 5, 6), key=lambda k: kinds[3 * k + 1])
     n_samp, ms, fl = kinds[3 * dom], kinds[3 * dom + 1], kinds[3 * dom + 2]
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    vnames = ("<ACT,0> plain, 256-row tiles", "<0,1> SwiGLU-fwd epilogue", "<0,2> SwiGLU-bwd epilogue", "<0,3> RoPE epilogue", "<ACT,0> plain, 144-row tiles (gemm_nt_144s_kernel)",
-              "(unused)",
-              "plain long-k products on gemm_u4_kernel (4 waves of 128x128, hand-written)")
     variants = {}
-    for k, nm in enumerate(vnames):
+    for k, nm in enumerate(KIND_NAMES):
         n_k, ms_k, fl_k = kinds[3 * k], kinds[3 * k + 1], kinds[3 * k + 2]
         if n_k > 0 and ms_k > 0:
             tf = fl_k / (ms_k * 1e-3) / 1e12
             variants[nm] = {"launches": int(n_k), "avg_launch_us": round(1e3 * ms_k / n_k, 2), "achieved_tflops": round(tf, 1),
                             "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
-    all_ms = sum(kinds[3 * k + 1] for k in range(7))
-    all_fl = sum(kinds[3 * k + 2] for k in range(7))
-    hand_ms, hand_fl = all_ms, all_fl   # every GEMM launch is one of this library's kernels (round 4 had a vendor-library candidate: kind 5, gone)
-    # HBM-side bytes per launch of the dominant kernel: a PMC pass cannot run inside this process (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE are
-    # separate profiled runs of this same command); the committed summary of that pass on this tree is quoted, with its provenance
-    traffic, traffic_note = None, "not measured in this run (PMC passes are separate rocprofv3 runs)"
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r04_gemm_traffic.json")))
-        if B == 30 and scale_layers == 1.0 and dom == 0:
-            traffic = int(tj["traffic_bytes_per_launch"])
-            traffic_note = ("bytes per launch of the dominant kernel from profiles/r04_gemm_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate "
-                            "passes of `bench.py --steps 1 --warmup 1` at micro-batch 30 on this tree), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 and "
-                            "calibrated on a kernel of known byte count in the same run; memory-side L2 traffic, Infinity-Cache hits included (~3x the algorithmic bytes: "
-                            "every XCD streams its own copy of the operand panels); NOT measured in this process")
-    except Exception:  # noqa: BLE001
-        pass
-    return {"bound": "mfma", "kernel": {0: GEMM_KERNEL_DESC, 4: GEMM_144_DESC, 6: GEMM_U4_DESC}[dom], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+    all_ms = sum(kinds[3 * k + 1] for k in range(10))
+    all_fl = sum(kinds[3 * k + 2] for k in range(10))
+    u4_ms = sum(kinds[3 * k + 1] for k in range(5, 10))
+    traffic, traffic_note = gemm_traffic(dom, B, scale_layers)
+    return {"bound": "mfma", "kernel": KIND_DESC[dom], "kernel_instantiation": KIND_NAMES[dom], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "traffic_note": traffic_note,
             "variants": variants, "all_variants_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else None,
-            "hand_written_kernels_tflops": round(hand_fl / (hand_ms * 1e-3) / 1e12, 1) if hand_ms > 0 else None,
-            "hand_written_share_of_gemm_time": round(hand_ms / all_ms, 3) if all_ms > 0 else None,
+            "hand_written_kernels_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else None,   # every GEMM launch is one of this library's kernels
+            "hand_written_share_of_gemm_time": 1.0 if all_ms > 0 else None,                                      # (round 4 had a vendor-library candidate; gone)
+            "four_wave_kernel_share_of_gemm_time": round(u4_ms / all_ms, 3) if all_ms > 0 else None,
             "launches_timed": int(n_samp), "timed_every_nth_launch": PROFILE_STRIDE, "avg_launch_us": round(1e3 * ms / max(n_samp, 1), 2),
             "sclk_mhz_during_timed_region": round(sclk) if sclk else None, "package_power_w": round(watts) if watts else None,
             "frac_of_peak_at_measured_clock": round(ach / (PEAK_BF16_TFLOPS * sclk / 2400.0), 4) if sclk else None,

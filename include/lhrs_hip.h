@@ -154,16 +154,16 @@ int lhrs_dequant8_dynamic(const void* q, const float* absmax2, long n, const flo
 int lhrs_gemm_set_small_thresh(int n);
 /* kernel A/B tests only: fewest 256x256 tiles for which lhrs_gemm_bf16_nt picks the big-tile kernel (default 128) */
 int lhrs_gemm_set_min_tiles(int n);
-/* live HIP-event timing of the 16-wave 256x256 GEMM launches, on their launch stream, for bench.py's roofline leg (gemm.hip):
- * enable(n) arms n event pairs (0 = off); read() -> {launches of the plain-epilogue persistent kernels (256-row + 144-row tiles), their ms, their
- * flops, all GEMM launches, all GEMM flops}; read_kinds() -> [7][3] = {launches, ms, flops} per kind: 0 plain <ACT,0> of the 256x256 kernel,
- * 1 SwiGLU fwd, 2 SwiGLU bwd, 3 RoPE epilogue (16-wave or four-wave kernel, whichever the shape rule took), 4 the plain 144-row kernel, 5 unused,
- * 6 plain products on the four-wave gemm_u4_kernel */
+/* live HIP-event timing of the persistent GEMM launches, on their launch stream, for bench.py's roofline leg (gemm.hip):
+ * enable(n) arms n event pairs (0 = off); read() -> {launches of the plain-epilogue 16-wave kernels (256-row + 144-row tiles), their ms, their
+ * flops, all GEMM launches, all GEMM flops}; read_kinds() -> [10][3] = {launches, ms, flops} per kernel instantiation: 0 gemm_nt_256s_kernel plain, 1 its SwiGLU fwd,
+ * 2 SwiGLU bwd, 3 RoPE epilogue, 4 gemm_nt_144s_kernel plain, 5 gemm_u4_kernel<0, true> (plain + residual), 6 gemm_u4_kernel<0, false> (plain), 7 gemm_u4_kernel<1, false>
+ * (SwiGLU fwd), 8 <2, false> (SwiGLU bwd), 9 <3, false> (RoPE) */
 int lhrs_gemm_profile_enable(int max_samples);
 /* bracket only every n-th launch of each epilogue variant (default 1): the event records themselves cost stream time (1-2 % of a step) */
 int lhrs_gemm_profile_stride(int n);
 int lhrs_gemm_profile_read(double* out5_host);
-int lhrs_gemm_profile_read_kinds(double* out21_host);
+int lhrs_gemm_profile_read_kinds(double* out30_host);
 /* gemm_u4_kernel (csrc/gemm_u4.hip): the hand-written four-wave kernel for the plain long-k products (the nn.Linear calls of HF LlamaDecoderLayer / lm_head with
  * no fused epilogue, reached from lhrs/models/text_modal.py:133-151, 258-294: no bias, no activation, bf16 out, alpha 1, K >= 4096, M and N >= 1024) -
  * 256x256x64 tile, 128x128 per wave, AGPR accumulators, paced LDS-DMA, persistent; bit-identical to gemm_nt_256s_kernel without a residual (a residual joins

@@ -887,7 +887,7 @@ struct GemmProf {
   double total_flops_all = 0; // every GEMM launch while enabled (sampled or not)
   long launches_all = 0;
   int stride = 1;             // every stride-th launch of each epilogue variant is bracketed (lhrs_gemm_profile_stride)
-  long seen[7] = {0, 0, 0, 0, 0, 0, 0};  // 0 plain 256-row, 1 SwiGLU fwd, 2 SwiGLU bwd, 3 RoPE, 4 plain 144-row, 5 plain products handed to the vendor library, 6 plain products on gemm_u4_kernel
+  long seen[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // kinds: see lhrs_gemm_profile_read_kinds
   bool take(int kind) { return (seen[kind]++ % stride) == 0; }
 } g_prof;
 }  // namespace
@@ -906,7 +906,7 @@ extern "C" int lhrs_gemm_profile_enable(int max_samples) {
   }
   g_prof.on = max_samples > 0; g_prof.cap = max_samples > 0 ? max_samples : 0; g_prof.used = 0;
   g_prof.total_flops_all = 0; g_prof.launches_all = 0;
-  for (int k = 0; k < 7; ++k) g_prof.seen[k] = 0;
+  for (int k = 0; k < 10; ++k) g_prof.seen[k] = 0;
   if (g_prof.on) {
     g_prof.ev = new hipEvent_t[2 * g_prof.cap];
     g_prof.flops = new double[g_prof.cap];
@@ -932,12 +932,11 @@ extern "C" int lhrs_gemm_profile_read(double* out) {
   return 0;
 }
 
-// out[7][3]: per kind k - 0 plain <ACT,0> of the 16-wave 256x256 kernel (THE dominant kernel), 1 SwiGLU fwd <0,1>, 2 SwiGLU bwd <0,2>, 3 RoPE <0,3> of
-// the same kernel, 4 the plain 144-row persistent kernel (gemm_nt_144s_kernel<ACT, 0>: ViT / projector products, micro-batch 8),
-// 5 the plain long-k products handed to the vendor library (vendor.cpp), 6 those on the four-wave gemm_u4_kernel (gemm_u4.hip) -:
-// sampled launches, their summed duration (ms), their summed flops
+// out[10][3] = {sampled launches, their summed duration (ms), their summed flops} per kind - one kind per kernel instantiation a rocprofv3 kernel trace lists:
+//   0 gemm_nt_256s_kernel<ACT, 0, ..> plain (16 waves)   1 <0, 1> SwiGLU fwd   2 <0, 2> SwiGLU bwd   3 <0, 3> RoPE   4 gemm_nt_144s_kernel<ACT, 0> plain 144-row tiles
+//   5 gemm_u4_kernel<0, true> plain + residual (four waves)   6 gemm_u4_kernel<0, false> plain   7 gemm_u4_kernel<1, false> SwiGLU fwd   8 <2, false> SwiGLU bwd   9 <3, false> RoPE
 extern "C" int lhrs_gemm_profile_read_kinds(double* out) {
-  for (int i = 0; i < 21; ++i) out[i] = 0;
+  for (int i = 0; i < 30; ++i) out[i] = 0;
   for (int i = 0; i < g_prof.used; ++i) {
     float t = 0;
     if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) LHRS_FAIL("gemm_profile_read_kinds: event sync failed");
@@ -1123,7 +1122,8 @@ extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
       ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0) && ((size_t)C % 16 == 0) && ((size_t)residual % 16 == 0)) {
     hipStream_t s = (hipStream_t)stream;
     const int Mu = u4_main_rows(M, cdiv(N, 256));
-    const int slot = prof_count(Mu, N, K, 6, s);
+    const int ukind = residual ? 5 : 6;
+    const int slot = prof_count(Mu, N, K, ukind, s);
     const int st = lhrs_gemm_u4_nt(A, lda, B, ldb, C, ldc, Mu, N, K, residual, ldr, stream);
     if (st == 0) {
       prof_end(slot, s);
@@ -1135,7 +1135,7 @@ extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
                          residual ? (const bf16_t*)residual + (long)Mu * ldr : nullptr, ldr, 0, 0, 0, 1.f, nullptr, 0, nullptr, 0, 0, stream);
     }
     if (st < 0) return st;
-    if (slot >= 0) { g_prof.used--; g_prof.seen[6]--; }   // not its problem after all (addressing limits): the slot goes back (it was the last one handed out)
+    if (slot >= 0) { g_prof.used--; g_prof.seen[ukind]--; }   // not its problem after all (addressing limits): the slot goes back (it was the last one handed out)
     if (g_prof.on) { g_prof.launches_all--; g_prof.total_flops_all -= 2.0 * Mu * N * K; }
   }
   return gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, out_f32, accumulate, alpha, nullptr, 0, nullptr, 0,
@@ -1341,7 +1341,7 @@ extern "C" int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int
   LHRS_REQUIRE(M > 0 && ff > 0 && K > 0 && ff % 8 == 0 && ld_gu >= 2 * ff && ld_act >= ff && ld_gu % 8 == 0 && ld_act % 8 == 0,
                "gemm_swiglu_fwd: M=%d ff=%d K=%d ld_gu=%d ld_act=%d", M, ff, K, ld_gu, ld_act);
   if (ff % 128 == 0 && lhrs_gemm_u4_fused_takes(M, ff / 128, K, K2))
-    U4_FUSED_TRY(1, 2 * ff, lhrs_gemm_u4_swiglu_fwd(X, ldx, Wgu, ldw, gu, ld_gu, act, ld_act, M, ff, K, stream))
+    U4_FUSED_TRY(7, 2 * ff, lhrs_gemm_u4_swiglu_fwd(X, ldx, Wgu, ldw, gu, ld_gu, act, ld_act, M, ff, K, stream))
   if (!swiglu_fusable((long)cdiv(M, 256) * (ff / 128), ff, K, K2, ldx, ldw)) {
     if (gemm_launch(X, ldx, Wgu, ldw, gu, ld_gu, M, 2 * ff, K, nullptr, nullptr, 0, 0, 0, 0, 1.f, A2, lda2, B2, ldb2, K2, stream)) return -1;
     LHRS_REQUIRE(ld_gu == 2 * ff && ld_act == ff, "gemm_swiglu_fwd: the unfused fallback needs dense gu / act");
@@ -1404,7 +1404,7 @@ extern "C" int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw
     return lhrs_rope(C, ldc, M, rope_cols / head_dim, head_dim, cos_t, sin_t, nullptr, pos_mod, pos0, 0, stream);
   }
   if (head_dim == 128 && rope_cols % 256 == 0 && lhrs_gemm_u4_fused_takes(M, cdiv(N, 256), K, K2))
-    U4_FUSED_TRY(3, N, lhrs_gemm_u4_rope(X, ldx, W, ldw, C, ldc, M, N, K, cos_t, sin_t, pos_mod, pos0, rope_cols, stream))
+    U4_FUSED_TRY(9, N, lhrs_gemm_u4_rope(X, ldx, W, ldw, C, ldc, M, N, K, cos_t, sin_t, pos_mod, pos0, rope_cols, stream))
   GemmArgs g; memset(&g, 0, sizeof(g));
   g.A = (const bf16_t*)X; g.B = (const bf16_t*)W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = ldw; g.ldc = ldc;
   g.alpha = 1.f; g.A2 = (const bf16_t*)A2; g.B2 = (const bf16_t*)B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
@@ -1423,7 +1423,7 @@ extern "C" int lhrs_gemm_swiglu_bwd(const void* dY, int ldy, const void* WdT, in
                                     int K2, const void* gu, void* dgu, int ld_gu, void* dact_scratch, int M, int ff, int K, void* stream) {
   LHRS_REQUIRE(M > 0 && ff > 0 && K > 0 && ff % 8 == 0 && ld_gu >= 2 * ff && ld_gu % 8 == 0, "gemm_swiglu_bwd: M=%d ff=%d K=%d ld_gu=%d", M, ff, K, ld_gu);
   if (lhrs_gemm_u4_fused_takes(M, cdiv(ff, 256), K, K2))
-    U4_FUSED_TRY(2, ff, lhrs_gemm_u4_swiglu_bwd(dY, ldy, WdT, ldw, gu, dgu, ld_gu, M, ff, K, stream))
+    U4_FUSED_TRY(8, ff, lhrs_gemm_u4_swiglu_bwd(dY, ldy, WdT, ldw, gu, dgu, ld_gu, M, ff, K, stream))
   if (!swiglu_fusable((long)cdiv(M, 256) * cdiv(ff, 256), ff, K, K2, ldy, ldw)) {
     LHRS_REQUIRE(dact_scratch != nullptr && ld_gu == 2 * ff, "gemm_swiglu_bwd: the unfused fallback needs a [M, ff] scratch and dense gu");
     if (gemm_launch(dY, ldy, WdT, ldw, dact_scratch, ff, M, ff, K, nullptr, nullptr, 0, 0, 0, 0, 1.f, A2, lda2, B2, ldb2, K2, stream)) return -1;

@@ -27,16 +27,18 @@ def test_bench_emits_the_contract_line():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and 0 < r["achieved"] < r["peak"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["launches_timed"] > 0
-    assert r["traffic"] is None and "not measured in this run" in r["traffic_note"] and d["ms_per_step_median"] > 0
+    # HBM-side bytes per launch of the dominant kernel: quoted from the committed PMC pass (profiles/r05_gemm_traffic.json) when it names this kernel at this micro-batch
+    assert (r["traffic"] is None and "not measured in this run" in r["traffic_note"]) or (r["traffic"] > 0 and "profiles/r05_gemm_traffic.json" in r["traffic_note"])
+    assert d["ms_per_step_median"] > 0
     v = r["variants"]
-    u4 = "plain long-k products on gemm_u4_kernel (4 waves of 128x128, hand-written)"
-    assert {"<0,1> SwiGLU-fwd epilogue", "<0,2> SwiGLU-bwd epilogue", "<0,3> RoPE epilogue"} <= set(v), v
+    # one entry per kernel instantiation that ran (the names a rocprofv3 kernel trace lists); at the headline shape every fused-epilogue product runs the four-wave kernel
+    assert any(k.startswith("gemm_u4_kernel<0, false>") for k in v) and any(k.startswith("gemm_u4_kernel<0, true>") for k in v), v
+    for e in (1, 2, 3):                                                      # SwiGLU fwd / bwd, RoPE: on one of the two persistent kernels
+        assert any(k.startswith(f"gemm_u4_kernel<{e}, false>") or k.startswith(f"gemm_nt_256s_kernel<0, {e}>") for k in v), (e, v)
     assert not any("vendor" in k or "hipBLASLt" in k for k in v), v         # hand-written only (round 5): no library kernel among the timed launches
-    # quoted on ONE kernel - the plain-epilogue kernel that carries the most time (a shape rule, csrc/gemm.hip, names the kernel of each product)
-    plain = {"gemm_nt_256s_kernel<ACT, 0": "<ACT,0> plain, 256-row tiles", "gemm_nt_144s_kernel<ACT, 0>": "<ACT,0> plain, 144-row tiles (gemm_nt_144s_kernel)",
-             "gemm_u4_kernel (csrc/gemm_u4.hip": u4}
-    dom = [nm for key, nm in plain.items() if r["kernel"].startswith(key)]
-    assert len(dom) == 1 and abs(r["achieved"] - v[dom[0]]["achieved_tflops"]) < 0.11, r["kernel"]
+    # quoted on ONE kernel instantiation - the plain-epilogue one that carries the most time (a shape rule, csrc/gemm.hip, names the kernel of each product)
+    assert r["kernel_instantiation"] in v and abs(r["achieved"] - v[r["kernel_instantiation"]]["achieved_tflops"]) < 0.11, r["kernel_instantiation"]
+    assert r["kernel_instantiation"].split("<")[0] in r["kernel"]
     note = d["config"]["plain_long_k_products"]
     assert note.startswith("hand-written only") and r["hand_written_share_of_gemm_time"] == 1.0 and r["hand_written_kernels_tflops"] > 0
     assert all(0 < x["frac"] < 1 and x["launches"] > 0 for x in v.values())
