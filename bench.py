@@ -222,6 +222,43 @@ def timed_run(engine, batch, steps, warmup, world, lib, on_timed_start=None):
             nstep[0] += 1
         return out["total_loss"]
 
+    # LHRS_BENCH_TRACE_FINITE=1: a finite-ness flag of every phase of every step, computed ON THE DEVICE (one tiny reduction each, no host synchronisation, so
+    # the timing of the step - what a start-up race depends on - is not disturbed) and read back once, behind the timed steps: which rank's which phase went
+    # non-finite FIRST (loss -> d loss / d image -> each bucket's LOCAL gradient as it is handed to the collective -> the REDUCED gradient -> norm -> masters)
+    trace = engine._finite_trace = [] if os.environ.get("LHRS_BENCH_TRACE_FINITE") == "1" else None
+    if trace is not None:
+        def mark(label, *ts):
+            trace.append((f"step {nstep[0]}: {label}", torch.stack([(~torch.isfinite(t)).any() for t in ts]).any()))
+        text_bwd = engine.model.text.backward
+        def traced_text_backward(*a, **k):
+            d_image = text_bwd(*a, **k)
+            if d_image is not None:
+                mark("d loss / d image (LLaMA backward output)", d_image)
+            return d_image
+        engine.model.text.backward = traced_text_backward
+        for name, r in getattr(engine, "reducers", {}).items():
+            def wrap(r=r, name=name):
+                ready0, finish0 = r.ready, r.finish
+                def ready(key):
+                    if key not in r.skip:
+                        s_, e_ = r.buckets[key]
+                        mark(f"LOCAL gradient of {name} bucket {key} [{s_}, {e_}) handed to the collective", r.flat[s_:e_])
+                    ready0(key)
+                def finish():
+                    finish0()
+                    mark(f"REDUCED gradient of {name}", r.flat)
+                r.ready, r.finish = ready, finish
+            wrap()
+        step0 = step
+        def step():
+            out = engine(batch)
+            mark("loss", out["total_loss"])
+            engine.backward(out["total_loss"])
+            engine.step()
+            mark("gradient norm^2", engine.gnorm_sq)
+            mark("masters after the update", *[st.master for st in engine.stores])
+            nstep[0] += 1
+            return out["total_loss"]
     loss = None
     for _ in range(warmup):
         loss = step()
@@ -449,6 +486,11 @@ def main():
     dt = float(tmax.item())
     final_loss = float(loss.item())
     dp = None
+    if getattr(engine, "_finite_trace", None):
+        flags = torch.stack([f for _, f in engine._finite_trace]).cpu().tolist()
+        bad = [lab for (lab, _), f in zip(engine._finite_trace, flags) if f]
+        print(f"rank {rank} finite-trace: {len(flags)} phases checked, " + (f"FIRST non-finite: {bad[0]!r}; all non-finite: {bad}" if bad else "all finite"),
+              file=sys.stderr, flush=True)
     if world > 1:
         # self-validating first contact of the N > 1 path (main_pretrain_stage1.py:54-60): after K optimizer steps on DIFFERENT
         # per-rank batches every rank must hold the same trainable masters (same reduced gradients, same update) - compare an fp64 checksum

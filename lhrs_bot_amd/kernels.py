@@ -68,6 +68,30 @@ def gemm_u4_takes(M, N, K, lda=None, ldb=None, ldc=None, ldr=0, has_bias=False, 
                                         int(ldr), int(has_bias), int(act), int(out_f32), int(accumulate), float(alpha)))
 
 
+GEMM_KIND_NAMES = ("gemm_nt_256s_kernel plain", "gemm_nt_256s_kernel SwiGLU-fwd", "gemm_nt_256s_kernel SwiGLU-bwd", "gemm_nt_256s_kernel RoPE", "gemm_nt_144s_kernel plain",
+                   "gemm_u4_kernel<0, true> plain + residual", "gemm_u4_kernel<0, false> plain", "gemm_u4_kernel<1, false> SwiGLU-fwd", "gemm_u4_kernel<2, false> SwiGLU-bwd",
+                   "gemm_u4_kernel<3, false> RoPE")
+
+
+class gemm_kernel_census:
+    """with gemm_kernel_census() as c: ...  -> c.counts = {kernel instantiation: timed launches} of the persistent GEMM kernels that ran inside the block (the library's live
+    profile counters, include/lhrs_hip.h: lhrs_gemm_profile_*): which kernel the shape rules gave each product - the parity tests record it next to their numbers."""
+
+    def __enter__(self):
+        _lib.check(_L().lhrs_gemm_profile_stride(1), "gemm_profile_stride")
+        _lib.check(_L().lhrs_gemm_profile_enable(20000), "gemm_profile_enable")
+        self.counts = {}
+        return self
+
+    def __exit__(self, *exc):
+        kinds = (ctypes.c_double * 30)()
+        torch.cuda.synchronize()
+        _lib.check(_L().lhrs_gemm_profile_read_kinds(ctypes.addressof(kinds)), "gemm_profile_read_kinds")
+        _L().lhrs_gemm_profile_enable(0)
+        self.counts = {GEMM_KIND_NAMES[k]: int(kinds[3 * k]) for k in range(10) if kinds[3 * k] > 0}
+        return False
+
+
 def gemm_u4_nt(a, b, out, residual=None) -> bool:
     """The raw launch of gemm_u4_kernel (tests, tools): True when launched, False when the problem is not its kind."""
     st = _L().lhrs_gemm_u4_nt(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), a.shape[0], b.shape[0], a.shape[1],

@@ -251,10 +251,11 @@ def test_full_depth_32_layers_s273_vs_oracle_on_host_cpu():
     labels = ids.clone()
     labels[:, :2] = -100
     batch = dict(rgb=torch.randn(1, 3, 224, 224, generator=g), input_ids=ids, labels=labels, attention_mask=ids.ne(0))
-    loss = model(batch)["total_loss"].item()
-    hid = model.text.last_hidden.float().cpu().reshape(1, 273, 4096)
-    d_image = model.text.backward()
-    model.rgb_pooler.backward(d_image)
+    with hk.gemm_kernel_census() as census:      # which persistent GEMM kernel the shape rules gave each product of this run (deterministic: csrc/gemm.hip)
+        loss = model(batch)["total_loss"].item()
+        hid = model.text.last_hidden.float().cpu().reshape(1, 273, 4096)
+        d_image = model.text.backward()
+        model.rgb_pooler.backward(d_image)
     torch.cuda.synchronize()
     got_grads = {n: model.rgb_pooler.g[n].double().cpu() for n, _ in model.rgb_pooler.named_parameters()}
     d_image = d_image.float().cpu()
@@ -297,7 +298,8 @@ def test_full_depth_32_layers_s273_vs_oracle_on_host_cpu():
     print(msg)
     out_dir = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    open(os.path.join(out_dir, "full_depth_parity.txt"), "w").write(msg + "\n")
+    open(os.path.join(out_dir, "full_depth_parity.txt"), "w").write(msg + "\npersistent GEMM launches by kernel instantiation (B = 1: M = 273, below the four-wave kernel's "
+                                                                   f"shape rule): {census.counts}\n")
     assert err_h < max(3e-2, 1.5 * yard_h), msg
     assert err_g < max(6e-2, 1.5 * yard_g), msg
     assert err_h2 < 1.1 * yard_h and err_g2 < 1.1 * yard_g, msg   # one rounding per fused kernel: not further from fp32 than op-by-op bf16
@@ -372,10 +374,22 @@ def test_measured_micro_batches_end_to_end_vs_oracle(B):
     labels = ids.clone()
     labels[:, :2] = -100
     batch = dict(rgb=torch.randn(B, 3, 224, 224, generator=g), input_ids=ids, labels=labels, attention_mask=ids.ne(0))
-    loss = model(batch)["total_loss"].item()
-    d_image = model.text.backward()
-    model.rgb_pooler.backward(d_image)
+    with hk.gemm_kernel_census() as census:
+        loss = model(batch)["total_loss"].item()
+        d_image = model.text.backward()
+        model.rgb_pooler.backward(d_image)
     torch.cuda.synchronize()
+    # the shipped kernel choice is a shape rule, so it can be asserted: at micro-batch 30 / 60 the decoder products of the full layers run all five instantiations of
+    # the four-wave gemm_u4_kernel (plain, plain + residual, RoPE, SwiGLU forward / backward; the compact last layer's MLP - supervised rows only - may fall under the
+    # rule's thresholds); at micro-batch 8 (M = 2184) the fused products stay on the 16-wave kernel
+    u4 = {k: v for k, v in census.counts.items() if k.startswith("gemm_u4_kernel")}
+    if B >= 30:
+        assert len(u4) == 5 and all(v > 0 for v in u4.values()), census.counts
+    else:
+        assert not any(k.startswith("gemm_u4_kernel<1") or k.startswith("gemm_u4_kernel<2") or k.startswith("gemm_u4_kernel<3") for k in u4), census.counts
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    open(os.path.join(out_dir, f"parity_micro_batch_{B}_kernels.txt"), "w").write(f"micro-batch {B}, 2 layers: persistent GEMM launches by kernel instantiation: {census.counts}\n")
     got = {n: model.rgb_pooler.g[n].double().cpu() for n, _ in model.rgb_pooler.named_parameters()}
     d_image = d_image.float().cpu()
     for k, v in P["pooler"].items():

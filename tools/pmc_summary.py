@@ -25,18 +25,23 @@ def per_kernel(rows, counter):
 
 if sys.argv[1] == "traffic":
     fdir, wdir, out = sys.argv[2:5]
+    want = sys.argv[5] if len(sys.argv) > 5 else "gemm_u4_kernel<0, false>"
     fetch, write = per_kernel(load(fdir), "FETCH_SIZE"), per_kernel(load(wdir), "WRITE_SIZE")
-    dom = next(k for k in fetch if "gemm_nt_256s_kernel<0, 0, false" in k)
+    dom = next(k for k in fetch if want in k)
     cast = next((k for k in fetch if "cast_f32_bf16" in k or "cast_f32_to_bf16" in k), None)
     mean = lambda v: sum(v) / len(v)  # noqa: E731
     res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE  /  --pmc WRITE_SIZE (two separate passes) -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra (B=30)",
-           "kernel": "gemm_nt_256s_kernel<0, 0, false, false> (16x16x32 MFMA, persistent)", "launches": len(fetch[dom]), "fetch_size_kb_mean": mean(fetch[dom]),
+           "kernel": dom[:120], "kernel_prefix": want, "micro_batch": 30, "launches": len(fetch[dom]), "fetch_size_kb_mean": mean(fetch[dom]),
            "write_size_kb_mean": mean(write[dom])}
     if cast:
         res["calibration"] = {"kernel": cast, "fetch_size_kb_mean": mean(fetch[cast]), "write_size_kb_mean": mean(write[cast]),
                               "note": "the projector's fp32 master -> bf16 shadow cast reads 4 B and writes 2 B per parameter (79.9 M padded): FETCH_SIZE reports ~1/2 of the read bytes of a "
                                       "wide streaming read on gfx950, WRITE_SIZE the written bytes - so reads are doubled, writes taken as is"}
     res["traffic_bytes_per_launch"] = int(2 * res["fetch_size_kb_mean"] * 1024 + res["write_size_kb_mean"] * 1024)
+    res["bench_note"] = (f"bytes per launch of {want} from profiles/r05_gemm_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes of "
+                         "`bench.py --steps 1 --warmup 1` at micro-batch 30 on this tree, mean over the launches of that kernel in the step), FETCH_SIZE doubled as "
+                         "MI355X_MICROARCH.md prescribes for gfx950 and calibrated on a kernel of known byte count in the same run; memory-side L2 traffic, Infinity-Cache hits "
+                         "included; NOT measured in this process")
     res["note"] = ("memory-side L2 traffic, Infinity-Cache hits included (A + B of a launch fit the 256 MB cache): each XCD's 4 MB L2 streams 12 two-MB operand panels per "
                    "round of 32 tiles and cannot keep them for the next round - the floor of any tile order at 4 MB per XCD is ~2.5x the algorithmic bytes (docs/design_notes_r01_r02.md §4)")
     json.dump(res, open(out, "w"), indent=1)
