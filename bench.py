@@ -42,6 +42,8 @@ def make_batch(B, T, device, seed):
     labels = ids.clone()
     labels[:, :2] = -100
     rgb = torch.randn(B, 3, 224, 224, generator=g)
+    if os.environ.get("LHRS_BENCH_HOST_INTS") == "1":   # the integer tensors as a DataLoader delivers them (host memory): no synchronising device -> host copy per step
+        return dict(rgb=rgb.to(device), input_ids=ids, labels=labels, attention_mask=ids.ne(0))
     return dict(rgb=rgb.to(device), input_ids=ids.to(device), labels=labels.to(device), attention_mask=ids.ne(0).to(device))
 
 
@@ -225,7 +227,11 @@ def timed_run(engine, batch, steps, warmup, world, lib, on_timed_start=None):
     # LHRS_BENCH_TRACE_FINITE=1: a finite-ness flag of every phase of every step, computed ON THE DEVICE (one tiny reduction each, no host synchronisation, so
     # the timing of the step - what a start-up race depends on - is not disturbed) and read back once, behind the timed steps: which rank's which phase went
     # non-finite FIRST (loss -> d loss / d image -> each bucket's LOCAL gradient as it is handed to the collective -> the REDUCED gradient -> norm -> masters)
-    trace = engine._finite_trace = [] if os.environ.get("LHRS_BENCH_TRACE_FINITE") == "1" else None
+    # levels: 1 = loss / gradients / masters per step; 2 = + every stage of the forward, host <-> device integer copies, uploads; 3 = + every ViT layer; 4 = + each
+    # of the four operators in front of the first ViT layer.  (Levels 1-3 still reproduce the shared-device NaN of DESIGN.md §6; level 4 does not: the extra
+    # launches between those operators hide it.)
+    tlevel = int(os.environ.get("LHRS_BENCH_TRACE_FINITE", "0") or 0)
+    trace = engine._finite_trace = [] if tlevel >= 1 else None
     if trace is not None:
         def mark(label, *ts):
             trace.append((f"step {nstep[0]}: {label}", torch.stack([(~torch.isfinite(t)).any() for t in ts]).any()))
@@ -249,6 +255,93 @@ def timed_run(engine, batch, steps, warmup, world, lib, on_timed_start=None):
                     mark(f"REDUCED gradient of {name}", r.flat)
                 r.ready, r.finish = ready, finish
             wrap()
+        # inside the forward (the first failures all named ONE rank's loss at step 1): every stage of it, the small integer tensors the step moves between host
+        # and device (the batch is the same every step: they must never change), and every pinned-staging upload compared with its host source afterwards
+        from lhrs_bot_amd import kernels as hk_
+        model_, text_ = engine.model, engine.model.text
+        seen_ints, h2d_log = {}, []
+        def same_as_first(label, t):
+            key = label
+            if key not in seen_ints:
+                seen_ints[key] = t.clone()
+            elif seen_ints[key].shape != t.shape:
+                trace.append((f"step {nstep[0]}: {label} CHANGED SHAPE {tuple(seen_ints[key].shape)} -> {tuple(t.shape)}", torch.ones((), dtype=torch.bool, device=batch["rgb"].device)))
+            else:
+                trace.append((f"step {nstep[0]}: {label} differs from step 0 (same batch every step)", (seen_ints[key].to(t.device) != t).any().to(batch["rgb"].device)))
+        ints0, enc0, pool0, fh0, splice0, ce0, h2d0 = text_._ints_to_host, model_.rgb.encode, model_.rgb_pooler.forward, text_.forward_hidden, hk_.splice_fwd, hk_.cross_entropy, hk_.h2d
+        def ints_to_host(*ts):
+            out = ints0(*ts)
+            for i, o in enumerate(out):
+                if o is not None:
+                    same_as_first(f"host copy #{i} of the batch's integer tensors (_ints_to_host)", o)
+            return out
+        head = [False]
+        pf0, gn0, va0, ln0 = hk_.patchify, hk_.gemm_nt, hk_.vit_assemble, hk_.layernorm_fwd
+        def patchify(rgb_, *a, **k):
+            if head[0]:
+                mark("ViT head: pixel input rgb", rgb_); same_as_first("ViT head: pixel input rgb", rgb_)
+            y = pf0(rgb_, *a, **k)
+            if head[0]:
+                mark("ViT head: patchify output (im2col rows)", y)
+            return y
+        def gemm_nt(a_, b_, *a, **k):
+            if head[0]:
+                same_as_first("ViT head: patch embedding weight", b_); mark("ViT head: patchify output as the GEMM reads it", a_)
+            y = gn0(a_, b_, *a, **k)
+            if head[0]:
+                mark("ViT head: patch-embedding GEMM output", y)
+            return y
+        def vit_assemble(patch, cls, pos, *a, **k):
+            if head[0]:
+                same_as_first("ViT head: class embedding", cls); same_as_first("ViT head: position embedding", pos)
+            y = va0(patch, cls, pos, *a, **k)
+            if head[0]:
+                mark("ViT head: assembled tokens (cls + patches + pos)", y)
+            return y
+        def layernorm_fwd(x_, g_, b_, *a, **k):
+            y = ln0(x_, g_, b_, *a, **k)
+            if head[0]:
+                same_as_first("ViT head: pre-LN weight", g_); mark("ViT head: pre-LN output", y)
+            return y
+        if tlevel >= 4:
+            hk_.patchify, hk_.gemm_nt, hk_.vit_assemble, hk_.layernorm_fwd = patchify, gemm_nt, vit_assemble, layernorm_fwd
+        def encode(x):
+            head[0] = True
+            y = enc0(x); mark("ViT taps", y); return y
+        def pool_forward(x, *a, **k):
+            y = pool0(x, *a, **k); mark("projector output (image embedding)", y); return y
+        def splice_fwd(*a, **k):
+            out = splice0(*a, **k); mark("spliced input embeddings", out[0]); return out
+        def forward_hidden(*a, **k):
+            y = fh0(*a, **k); mark("final-norm hidden state (LLaMA forward output)", y); return y
+        def cross_entropy(logits, target, *a, **k):
+            mark("logits", logits); same_as_first("device targets of the loss", target)
+            return ce0(logits, target, *a, **k)
+        def h2d(t, device):
+            d = h2d0(t, device)
+            if not t.is_cuda and len(h2d_log) < 4000:
+                h2d_log.append((f"step {nstep[0]}: upload #{len(h2d_log)} {tuple(t.shape)} {t.dtype}", t, d))
+            return d
+        vit0 = hk_.vit_layer_forward
+        vit_calls = [0]
+        def vit_layer_forward(x, L, desc, B_, n_, LT, H, ff, h, qkv, o, f):
+            li = vit_calls[0] % len(model_.rgb.p["layers"])
+            head[0] = False
+            if li == 0:   # the scratch buffers as the allocator handed them out (uninitialised): do they hold NaN bit patterns?  (informational: label says so)
+                trace.append((f"step {nstep[0]}: [info] recycled scratch of the ViT holds non-finite bit patterns before its first write",
+                              torch.stack([(~torch.isfinite(t)).any() for t in (h, qkv, o, f)]).any()))
+                mark("ViT input x of layer 0 (patch embedding + pre-LN)", x)
+            y = vit0(x, L, desc, B_, n_, LT, H, ff, h, qkv, o, f)
+            for nm, t in (("LN output h", h), ("qkv", qkv), ("attention output o", o), ("fc1 output f", f), ("residual stream x", x)):
+                mark(f"ViT layer {li}: {nm}", t)
+            vit_calls[0] += 1
+            return y
+        if tlevel >= 3:
+            hk_.vit_layer_forward = vit_layer_forward
+        if tlevel >= 2:
+            text_._ints_to_host, model_.rgb.encode, model_.rgb_pooler.forward, text_.forward_hidden = ints_to_host, encode, pool_forward, forward_hidden
+            hk_.splice_fwd, hk_.cross_entropy, hk_.h2d = splice_fwd, cross_entropy, h2d
+        engine._h2d_log = h2d_log
         step0 = step
         def step():
             out = engine(batch)
@@ -487,9 +580,12 @@ def main():
     final_loss = float(loss.item())
     dp = None
     if getattr(engine, "_finite_trace", None):
+        for lab, host_t, dev_t in getattr(engine, "_h2d_log", []):      # every pinned-staging upload of the run against its host source, now that everything has run
+            engine._finite_trace.append((f"{lab}: device copy differs from its host source", (host_t.to(dev_t.device) != dev_t).any()))
         flags = torch.stack([f for _, f in engine._finite_trace]).cpu().tolist()
-        bad = [lab for (lab, _), f in zip(engine._finite_trace, flags) if f]
-        print(f"rank {rank} finite-trace: {len(flags)} phases checked, " + (f"FIRST non-finite: {bad[0]!r}; all non-finite: {bad}" if bad else "all finite"),
+        info = [lab for (lab, _), f in zip(engine._finite_trace, flags) if f and "[info]" in lab]
+        bad = [lab for (lab, _), f in zip(engine._finite_trace, flags) if f and "[info]" not in lab]
+        print(f"rank {rank} finite-trace: {len(flags)} phases checked, " + (f"FIRST non-finite: {bad[0]!r}; all non-finite: {bad}" if bad else "all finite") + (f"; info: {info[:6]}" if info else ""),
               file=sys.stderr, flush=True)
     if world > 1:
         # self-validating first contact of the N > 1 path (main_pretrain_stage1.py:54-60): after K optimizer steps on DIFFERENT

@@ -640,10 +640,27 @@ class TextModal:
     def _ints_to_host(self, *ts):
         """CPU views of the small integer inputs.  Host tensors (what a DataLoader delivers) pass through; device tensors cost ONE
         synchronising copy for all of them."""
-        out = [None if t is None else (t if not t.is_cuda else t.to("cpu", non_blocking=True)) for t in ts]
-        if any(t is not None and t.is_cuda for t in ts):
+        if not any(t is not None and t.is_cuda for t in ts):
+            return list(ts)
+        if os.environ.get("LHRS_INTS_PAGEABLE") == "1":   # the pre-round-5 path (A/B of the shared-device NaN hunt, DESIGN.md §6): async copies into PAGEABLE host memory
+            out = [None if t is None else (t if not t.is_cuda else t.to("cpu", non_blocking=True)) for t in ts]
             torch.cuda.current_stream().synchronize()
-        return out
+            return out
+        # device -> PINNED staging buffers of this model (allocated once per shape), one synchronisation, then plain host copies of them: the runtime does not have to
+        # pin / stage / unpin pageable pages around an asynchronous copy at the start of every step
+        cache = self.__dict__.setdefault("_ints_pinned", {})
+        stage = []
+        for i, t in enumerate(ts):
+            if t is None or not t.is_cuda:
+                stage.append(None)
+                continue
+            key = (i, tuple(t.shape), t.dtype)
+            if key not in cache:
+                cache[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            cache[key].copy_(t, non_blocking=True)
+            stage.append(cache[key])
+        torch.cuda.current_stream().synchronize()
+        return [t if p is None else p.clone() for t, p in zip(ts, stage)]
 
     def decode(self, input_ids, image_embedding=None, attention_mask=None, labels=None, save_ctx=True, host_ints=None):
         """TextModal.decode: returns the scalar text loss (0-dim fp32 device tensor).  All integer bookkeeping of the step (spliced

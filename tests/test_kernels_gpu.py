@@ -2,6 +2,7 @@
 statement of the same op (tolerances are bf16-level and written next to each check)."""
 import math
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -104,6 +105,66 @@ def test_gemm_u4_soak_200_launches_under_load_every_result_identical(M, N, K):
         bad += (out != first).sum()
     torch.cuda.synchronize()
     assert int(bad) == 0, f"{int(bad)} elements differed from the first launch over 200 launches"
+
+
+@pytest.mark.timeout(900)
+def test_gemm_u4_random_shapes_all_epilogues_vs_the_16_wave_kernels():
+    """Seeded random shapes through every instantiation of the four-wave kernel's raw launches - ragged M and N (edge tiles take the exposed epilogue, interior tiles
+    the in-stream write-out, in every order the tile walk produces: one to nine tiles per workgroup, odd and even stage counts) - against the 16-wave kernels /
+    unfused kernel pairs on the same operands: bit-identical wherever no residual joins the sum (same k order), fp32-torch within bf16 rounding everywhere."""
+    from lhrs_bot_amd import _lib
+    lib, st = _lib.load(), torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(20260929)
+    hd = 128
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    fr = torch.outer(torch.arange(700).float(), inv)
+    cos, sin = fr.cos().to(DEV).contiguous(), fr.sin().to(DEV).contiguous()
+    try:
+        lib.lhrs_gemm_set_min_tiles(1)        # the 16-wave kernel from one tile on (the default threshold would send the small cases to other tiles: another k order)
+        lib.lhrs_gemm_set_tail_split(0)
+        lib.lhrs_gemm_set_bm144(0)
+        for case in range(14):
+            M = int(rng.integers(300, 9000))
+            K = 64 * int(rng.integers(4, 40))
+            g = torch.Generator(device="cpu").manual_seed(1000 + case)
+            x = bf(torch.randn(M, K, generator=g)).to(DEV)
+            kind = case % 4
+            if kind == 0:      # plain, with and without a residual, ragged N (multiple of 8)
+                N = 8 * int(rng.integers(40, 700))
+                w = bf(torch.randn(N, K, generator=g) * 0.05).to(DEV)
+                r = bf(torch.randn(M, N, generator=g)).to(DEV)
+                out, out_r = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16), torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+                assert hk.gemm_u4_nt(x, w, out) and hk.gemm_u4_nt(x, w, out_r, residual=r)
+                assert torch.equal(out, hk.gemm_nt(x, w)), (case, M, N, K)
+                assert rel_err(out_r, x.float() @ w.float().t() + r.float()) < 4e-3, (case, M, N, K)
+            elif kind == 1:    # SwiGLU forward: ff a multiple of 128
+                ff = 128 * int(rng.integers(4, 40))
+                w = bf(torch.randn(2 * ff, K, generator=g) * 0.05).to(DEV)
+                gu, act = torch.zeros(M, 2 * ff, device=DEV, dtype=torch.bfloat16), torch.zeros(M, ff, device=DEV, dtype=torch.bfloat16)
+                assert lib.lhrs_gemm_u4_swiglu_fwd(x.data_ptr(), K, w.data_ptr(), K, gu.data_ptr(), 2 * ff, act.data_ptr(), ff, M, ff, K, st) == 0
+                gu_ref = hk.gemm_nt(x, w)
+                assert torch.equal(gu, gu_ref) and torch.equal(act, hk.swiglu_fwd(gu_ref, ff)), (case, M, ff, K)
+            elif kind == 2:    # SwiGLU backward in place over gate|up: ff a multiple of 8 (ragged last tile column)
+                ff = 8 * int(rng.integers(64, 600))
+                w = bf(torch.randn(ff, K, generator=g) * 0.05).to(DEV)
+                gu = bf(torch.randn(M, 2 * ff, generator=g)).to(DEV)
+                want = hk.swiglu_bwd(hk.gemm_nt(x, w), gu, ff)
+                assert lib.lhrs_gemm_u4_swiglu_bwd(x.data_ptr(), K, w.data_ptr(), K, gu.data_ptr(), gu.data_ptr(), 2 * ff, M, ff, K, st) == 0
+                assert torch.equal(gu, want), (case, M, ff, K)
+            else:              # RoPE: heads of 128, rope_cols a multiple of 256, plain columns behind them
+                nh = 2 * int(rng.integers(1, 12))
+                N = nh * 128 + 8 * int(rng.integers(0, 60))
+                S, pos0 = int(rng.integers(16, 400)), int(rng.integers(0, 200))
+                w = bf(torch.randn(N, K, generator=g) * 0.05).to(DEV)
+                out = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+                assert lib.lhrs_gemm_u4_rope(x.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), N, M, N, K, cos.data_ptr(), sin.data_ptr(), S, pos0, nh * 128, st) == 0
+                ref = hk.gemm_nt(x, w)
+                hk.rope_(ref, M, nh, hd, cos, sin, pos_mod=S, pos0=pos0)
+                assert torch.equal(out, ref), (case, M, N, K, S, pos0)
+    finally:
+        lib.lhrs_gemm_set_bm144(1)
+        lib.lhrs_gemm_set_tail_split(1)
+        lib.lhrs_gemm_set_min_tiles(128)
 
 
 @pytest.mark.timeout(600)
