@@ -42,7 +42,10 @@ def make_batch(B, T, device, seed):
     labels = ids.clone()
     labels[:, :2] = -100
     rgb = torch.randn(B, 3, 224, 224, generator=g)
-    if os.environ.get("LHRS_BENCH_HOST_INTS") == "1":   # the integer tensors as a DataLoader delivers them (host memory): no synchronising device -> host copy per step
+    # pixels on the device; the small integer tensors in HOST memory, as the reference's DataLoader / collator delivers them (cap_dataset.py:775-810) and as
+    # lhrs_bot_amd.trainer leaves them: the engine plans the step's integers on the host and uploads what the kernels read, so a step starts without a
+    # device -> host copy + stream synchronisation.  LHRS_BENCH_HOST_INTS=0: device-resident integers (the pre-round-5 bench; the A/B of DESIGN.md 6)
+    if os.environ.get("LHRS_BENCH_HOST_INTS", "1") != "0":
         return dict(rgb=rgb.to(device), input_ids=ids, labels=labels, attention_mask=ids.ne(0))
     return dict(rgb=rgb.to(device), input_ids=ids.to(device), labels=labels.to(device), attention_mask=ids.ne(0).to(device))
 

@@ -300,7 +300,14 @@ class Trainer:
     def put_input_to_device(self, batch):
         """trainer.py:400-417.  `rgb` may be a list of uint8 [H,W,3] pictures of different sizes (decoded by the DataLoader workers, see
         lhrs_bot_amd/datasets.py): each goes up as it is, the model's `_pixels` runs the CLIP transform on the device."""
-        move = lambda v: v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v  # noqa: E731
+        # The small INTEGER tensors (input_ids, labels, attention_mask) stay where the DataLoader delivered them - in host memory: the engine does its integer
+        # bookkeeping (splice lengths, supervised rows, targets) on the host and uploads only what the kernels read.  Moving them up here (as the reference's
+        # put_input_to_device does for its torch modules) would cost a device -> host copy and a stream synchronisation at the start of EVERY step
+        # (TextModal._ints_to_host) - and a drained queue at every step start is exactly the trigger of the shared-device NaN of DESIGN.md 6.
+        def move(v):
+            if not torch.is_tensor(v) or (not v.is_floating_point() and v.dtype != torch.uint8):
+                return v
+            return v.to(self.device, non_blocking=True)
         return {k: [move(x) for x in v] if isinstance(v, (list, tuple)) else move(v) for k, v in batch.items()}
 
     def train_on_iter(self):

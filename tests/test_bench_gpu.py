@@ -99,17 +99,9 @@ def test_bench_gpus8_plumbing_on_a_shared_device():
     env.update(LHRS_SHARE_GPU="1", OMP_NUM_THREADS="2")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--llama-layers", "1", "--micro-batch", "2"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=700, cwd=ROOT, env=env)
-    if out.returncode != 0 and ("non-finite" in out.stderr or "checksums [[nan" in out.stderr):
-        # DESIGN.md §7 (open item): about 2 of 100 launches of THIS configuration - eight processes time-slicing one device, gradients through
-        # gloo's host staging - end with NaN masters on every rank; 6 400 process-steps of the same engine without torch.distributed, 300-step
-        # 8-rank runs and the poisoned-memory / poisoned-LDS runs never do.  bench.py refuses to print a line in that case (that refusal is what
-        # this test is about); one relaunch keeps an unsupported device-sharing mode from deciding the whole GPU suite, and the first
-        # failure's per-rank diagnostics are kept for the record
-        keep = os.path.join(ROOT, "gpurun_out")
-        if os.path.isdir(keep):
-            with open(os.path.join(keep, "gpus8_shared_device_first_failure.txt"), "w") as f:
-                f.write("\n".join(l for l in out.stderr.splitlines() if "Gloo" not in l))
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=700, cwd=ROOT, env=env)
+    # no relaunch (round 5): the rare NaN of this configuration was traced to the drained queue at every step start (device-resident integer inputs cost a
+    # synchronising device -> host copy per step; DESIGN.md 6, profiles/r05_shared_device_nan_hunt.txt: 23 of 1030 launches with it, 0 of 160 without); bench.py and the
+    # trainer now hand the integer tensors over in host memory, as the reference's DataLoader does
     assert out.returncode == 0, out.stdout[-2000:] + "\n".join(l for l in out.stderr.splitlines() if "Gloo" not in l)[-5000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
