@@ -176,11 +176,11 @@ int lhrs_gemm_u4_takes(int M, int N, int K, int lda, int ldb, int ldc, int ldr, 
 int lhrs_gemm_u4_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
                     void* stream);
 /* the four-wave kernel with the decoder layer's fused epilogues (lhrs_gemm_rope_fwd / lhrs_gemm_swiglu_fwd / lhrs_gemm_swiglu_bwd semantics without a LoRA pair;
- * bit-identical to them): raw launches, 0 launched, 1 not its problem.  The three operator entry points above take it by the shape rule u4_fused_takes(M, tile
- * columns, K, K2): no LoRA pair, K >= 4096, M >= 1024, tiles that fill >= 80 % of a round of the CUs with <= 15 % of the last round idle (tile columns: N / 256
- * for RoPE, ff / 128 for SwiGLU forward, ff / 256 for SwiGLU backward).  u4_main_rows(M, N): rows of a plain product that go to the four-wave kernel when its last
+ * bit-identical to them): raw launches, 0 launched, 1 not its problem.  The three operator entry points above take it by the shape rule u4_fused_takes(kind, M, tile
+ * columns, K, K2): no LoRA pair, K >= 4096, M >= 1024, tiles that fill >= 80 % of a round of the CUs with <= 15 % of the last round idle (kind 0 RoPE: tile columns
+ * N / 256; kind 1 SwiGLU forward: ff / 128) or <= 5 % (kind 2 SwiGLU backward: ff / 256 - its write-out is VALU-bound on four waves and only wins on a whole-round walk).  u4_main_rows(M, N): rows of a plain product that go to the four-wave kernel when its last
  * round would be mostly empty (the rest: small tiles / split-K over the workspace); = M when nothing is cut. */
-int lhrs_gemm_u4_fused_takes(int M, int tiles_n, int K, int K2);
+int lhrs_gemm_u4_fused_takes(int kind, int M, int tiles_n, int K, int K2);
 int lhrs_gemm_u4_main_rows(int M, int N);
 int lhrs_gemm_u4_rope(const void* X, int ldx, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const float* cos_t,
                       const float* sin_t, int pos_mod, int pos0, int rope_cols, void* stream);

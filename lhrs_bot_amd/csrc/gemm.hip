@@ -1079,13 +1079,17 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, 
                        const void* residual, int ldr, int act, int out_f32, int accumulate, float alpha, const void* A2,
                        int lda2, const void* B2, int ldb2, int K2, void* stream);
 // The fused-epilogue products (qkv + RoPE, gate|up + SwiGLU, d-down + SwiGLU') on the four-wave kernel: no LoRA pair in the k-loop (that lives in the 16-wave
-// kernel), K >= 4096, and tiles that fill the chip with at most 15 % of the last round idle - the four-wave kernel has one tile height and no tail-row split for
-// the fused epilogues (micro-batch 30: 6.0 / 10.75 / 5.375 rounds: taken; the reference's micro-batch 8, M = 2184: 1.69 / 3.02 / 1.51 rounds: the 16-wave kernels with
-// their 144-row tiles and tail-row rules).  kind: 0 RoPE (tiles_n = N / 256), 1 SwiGLU forward (ff / 128), 2 SwiGLU backward (ff / 256).  A pure function of the shape.
-extern "C" int lhrs_gemm_u4_fused_takes(int M, int tiles_n, int K, int K2) {
+// kernel), K >= 4096, and tiles that fill the chip with at most `max_idle_pct` % of the last round idle - the four-wave kernel has one tile height and no tail-row
+// split for the fused epilogues.  RoPE and SwiGLU forward: 15 % (micro-batch 30: 6.0 / 10.75 rounds, micro-batch 60: 12 / 21.5: taken; the reference's micro-batch 8,
+// M = 2184: 1.69 / 3.02 rounds: the 16-wave kernels with their 144-row tiles and tail-row rules).  SwiGLU backward: 5 % - its write-out is VALU-bound on four waves
+// (the sigmoid of 256 elements per lane beside one stage of MFMAs), so it only wins where the tile walk fits: micro-batch 60 (10.75 rounds) 1261 us against the 16-wave
+// kernel's ~1307; micro-batch 30 (5.375 rounds) 678 against 634 on the same box (profiles/r05_bench_line_b30_ab_16wave.json) - stays on the 16-wave kernel.
+// kind: 0 RoPE (tiles_n = N / 256), 1 SwiGLU forward (ff / 128), 2 SwiGLU backward (ff / 256).  A pure function of the shape.
+extern "C" int lhrs_gemm_u4_fused_takes(int kind, int M, int tiles_n, int K, int K2) {
   plain_env();
-  const long P = num_cus(), T = (long)cdiv(M, 256) * tiles_n;
-  return g_u4_on == 1 && K2 == 0 && K >= 4096 && K % 64 == 0 && M >= 1024 && 5 * T >= 4 * P && 20 * ((T + P - 1) / P * P) <= 23 * T;
+  const long P = num_cus(), T = (long)cdiv(M, 256) * tiles_n, R = (T + P - 1) / P * P;
+  const long idle_ok = kind == 2 ? 100 * R <= 105 * T : 20 * R <= 23 * T;
+  return g_u4_on == 1 && K2 == 0 && K >= 4096 && K % 64 == 0 && M >= 1024 && 5 * T >= 4 * P && idle_ok;
 }
 extern "C" int lhrs_gemm_u4_rope(const void* X, int ldx, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const float* cos_t, const float* sin_t,
                                  int pos_mod, int pos0, int rope_cols, void* stream);
@@ -1340,7 +1344,7 @@ extern "C" int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int
                                     int K2, void* gu, int ld_gu, void* act, int ld_act, int M, int ff, int K, void* stream) {
   LHRS_REQUIRE(M > 0 && ff > 0 && K > 0 && ff % 8 == 0 && ld_gu >= 2 * ff && ld_act >= ff && ld_gu % 8 == 0 && ld_act % 8 == 0,
                "gemm_swiglu_fwd: M=%d ff=%d K=%d ld_gu=%d ld_act=%d", M, ff, K, ld_gu, ld_act);
-  if (ff % 128 == 0 && lhrs_gemm_u4_fused_takes(M, ff / 128, K, K2))
+  if (ff % 128 == 0 && lhrs_gemm_u4_fused_takes(1, M, ff / 128, K, K2))
     U4_FUSED_TRY(7, 2 * ff, lhrs_gemm_u4_swiglu_fwd(X, ldx, Wgu, ldw, gu, ld_gu, act, ld_act, M, ff, K, stream))
   if (!swiglu_fusable((long)cdiv(M, 256) * (ff / 128), ff, K, K2, ldx, ldw)) {
     if (gemm_launch(X, ldx, Wgu, ldw, gu, ld_gu, M, 2 * ff, K, nullptr, nullptr, 0, 0, 0, 0, 1.f, A2, lda2, B2, ldb2, K2, stream)) return -1;
@@ -1403,7 +1407,7 @@ extern "C" int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw
     if (rope_cols == 0) return 0;
     return lhrs_rope(C, ldc, M, rope_cols / head_dim, head_dim, cos_t, sin_t, nullptr, pos_mod, pos0, 0, stream);
   }
-  if (head_dim == 128 && rope_cols % 256 == 0 && lhrs_gemm_u4_fused_takes(M, cdiv(N, 256), K, K2))
+  if (head_dim == 128 && rope_cols % 256 == 0 && lhrs_gemm_u4_fused_takes(0, M, cdiv(N, 256), K, K2))
     U4_FUSED_TRY(9, N, lhrs_gemm_u4_rope(X, ldx, W, ldw, C, ldc, M, N, K, cos_t, sin_t, pos_mod, pos0, rope_cols, stream))
   GemmArgs g; memset(&g, 0, sizeof(g));
   g.A = (const bf16_t*)X; g.B = (const bf16_t*)W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = ldw; g.ldc = ldc;
@@ -1422,7 +1426,7 @@ extern "C" int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw
 extern "C" int lhrs_gemm_swiglu_bwd(const void* dY, int ldy, const void* WdT, int ldw, const void* A2, int lda2, const void* B2, int ldb2,
                                     int K2, const void* gu, void* dgu, int ld_gu, void* dact_scratch, int M, int ff, int K, void* stream) {
   LHRS_REQUIRE(M > 0 && ff > 0 && K > 0 && ff % 8 == 0 && ld_gu >= 2 * ff && ld_gu % 8 == 0, "gemm_swiglu_bwd: M=%d ff=%d K=%d ld_gu=%d", M, ff, K, ld_gu);
-  if (lhrs_gemm_u4_fused_takes(M, cdiv(ff, 256), K, K2))
+  if (lhrs_gemm_u4_fused_takes(2, M, cdiv(ff, 256), K, K2))
     U4_FUSED_TRY(8, ff, lhrs_gemm_u4_swiglu_bwd(dY, ldy, WdT, ldw, gu, dgu, ld_gu, M, ff, K, stream))
   if (!swiglu_fusable((long)cdiv(M, 256) * cdiv(ff, 256), ff, K, K2, ldy, ldw)) {
     LHRS_REQUIRE(dact_scratch != nullptr && ld_gu == 2 * ff, "gemm_swiglu_bwd: the unfused fallback needs a [M, ff] scratch and dense gu");

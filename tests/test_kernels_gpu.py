@@ -210,7 +210,10 @@ def test_gemm_u4_fused_epilogues_soak_100_launches_every_result_identical():
             gu, act = hk.gemm_swiglu_fwd(x, wgu, ff)
             bad[2] += (gu != want_gu).sum()
             bad[3] += (act != want_act).sum()
-            bad[4] += (hk.gemm_swiglu_bwd(dy, wdT, gu, ff) != want_dgu).sum()
+            # SwiGLU backward: the raw four-wave launch (at this M the operator's shape rule keeps the 16-wave kernel: 5.375 rounds), in place over gate|up
+            assert lib.lhrs_gemm_u4_swiglu_bwd(dy.data_ptr(), dy.stride(0), wdT.data_ptr(), wdT.stride(0), gu.data_ptr(), gu.data_ptr(), gu.stride(0), M, ff, d,
+                                               torch.cuda.current_stream().cuda_stream) == 0
+            bad[4] += (gu != want_dgu).sum()
         torch.cuda.synchronize()
         assert bad.tolist() == [0, 0, 0, 0, 0], bad.tolist()
     finally:
@@ -667,8 +670,9 @@ def test_gemm_fused_swiglu_bit_identical_to_unfused(M, lora):
         assert lib.lhrs_gemm_u4_swiglu_bwd(dy.data_ptr(), dy.stride(0), wdT.data_ptr(), wdT.stride(0), gu4.data_ptr(), gu4.data_ptr(), gu4.stride(0), M, ff, d, st) == 0
         assert torch.equal(gu4, dgu_ref)                              # in place over gate|up
         hk.gemm_set_u4(True)
-        taken = bool(lib.lhrs_gemm_u4_fused_takes(M, ff // 128, d, 0)) and bool(lib.lhrs_gemm_u4_fused_takes(M, -(-ff // 256), d, 0))
-        assert taken == (M >= 4095)                                   # M = 2184 (1.5 - 3.02 rounds of 256-row tiles) stays on the 16-wave kernels
+        taken_f, taken_b = bool(lib.lhrs_gemm_u4_fused_takes(1, M, ff // 128, d, 0)), bool(lib.lhrs_gemm_u4_fused_takes(2, M, -(-ff // 256), d, 0))
+        assert taken_f == (M >= 4095) and not taken_b                 # M = 2184 (3.02 rounds) stays on the 16-wave kernels; SwiGLU' (2.69 / 5.375 rounds) needs <= 5 % idle
+        assert lib.lhrs_gemm_u4_fused_takes(2, 16380, -(-ff // 256), d, 0) == 1     # micro-batch 60: 10.75 rounds
         gu5, act5 = hk.gemm_swiglu_fwd(x, wgu, ff)
         assert torch.equal(gu5, gu_ref) and torch.equal(act5, act_ref)
         assert torch.equal(hk.gemm_swiglu_bwd(dy, wdT, gu5, ff), dgu_ref)
@@ -723,7 +727,7 @@ def test_gemm_fused_rope_bit_identical_to_unfused(M, S, pos0, lora):
                                              sin.data_ptr(), S, pos0, 2 * d, torch.cuda.current_stream().cuda_stream) == 0
         assert torch.equal(raw, got)
         hk.gemm_set_u4(True)
-        assert _lib.load().lhrs_gemm_u4_fused_takes(M, 3 * d // 256, d, 0) == 1
+        assert _lib.load().lhrs_gemm_u4_fused_takes(0, M, 3 * d // 256, d, 0) == 1
         assert torch.equal(hk.gemm_rope_fwd(x, w, cos, sin, pos_mod=S, pos0=pos0, rope_cols=2 * d, head_dim=hd), got)
         hk.gemm_set_u4(False)
     ref = hk.gemm_nt_lora(x, w, a2, b2) if lora else hk.gemm_nt(x, w)

@@ -30,8 +30,8 @@ if sys.argv[1] == "traffic":
     dom = next(k for k in fetch if want in k)
     cast = next((k for k in fetch if "cast_f32_bf16" in k or "cast_f32_to_bf16" in k), None)
     mean = lambda v: sum(v) / len(v)  # noqa: E731
-    res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE  /  --pmc WRITE_SIZE (two separate passes) -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra (B=30)",
-           "kernel": dom[:120], "kernel_prefix": want, "micro_batch": 30, "launches": len(fetch[dom]), "fetch_size_kb_mean": mean(fetch[dom]),
+    res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE  /  --pmc WRITE_SIZE (two separate passes) -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra (default micro-batch)",
+           "kernel": dom[:120], "kernel_prefix": want, "micro_batch": int(sys.argv[6]) if len(sys.argv) > 6 else 60, "launches": len(fetch[dom]), "fetch_size_kb_mean": mean(fetch[dom]),
            "write_size_kb_mean": mean(write[dom])}
     if cast:
         res["calibration"] = {"kernel": cast, "fetch_size_kb_mean": mean(fetch[cast]), "write_size_kb_mean": mean(write[cast]),
@@ -39,7 +39,7 @@ if sys.argv[1] == "traffic":
                                       "wide streaming read on gfx950, WRITE_SIZE the written bytes - so reads are doubled, writes taken as is"}
     res["traffic_bytes_per_launch"] = int(2 * res["fetch_size_kb_mean"] * 1024 + res["write_size_kb_mean"] * 1024)
     res["bench_note"] = (f"bytes per launch of {want} from profiles/r05_gemm_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes of "
-                         "`bench.py --steps 1 --warmup 1` at micro-batch 30 on this tree, mean over the launches of that kernel in the step), FETCH_SIZE doubled as "
+                         "`bench.py --steps 1 --warmup 1` at the default micro-batch on this tree, mean over the launches of that kernel in the step), FETCH_SIZE doubled as "
                          "MI355X_MICROARCH.md prescribes for gfx950 and calibrated on a kernel of known byte count in the same run; memory-side L2 traffic, Infinity-Cache hits "
                          "included; NOT measured in this process")
     res["note"] = ("memory-side L2 traffic, Infinity-Cache hits included (A + B of a launch fit the 256 MB cache): each XCD's 4 MB L2 streams 12 two-MB operand panels per "
