@@ -381,12 +381,13 @@ def test_measured_micro_batches_end_to_end_vs_oracle(B):
     torch.cuda.synchronize()
     # the shipped kernel choice is a shape rule, so it can be asserted: at micro-batch 30 / 60 the decoder products of the full layers run all five instantiations of
     # the four-wave gemm_u4_kernel (plain, plain + residual, RoPE, SwiGLU forward / backward; the compact last layer's MLP - supervised rows only - may fall under the
-    # rule's thresholds); at micro-batch 8 (M = 2184) the fused products stay on the 16-wave kernel
+    # rule's thresholds); at micro-batch 8 (M = 2184) RoPE and SwiGLU' stay on the 16-wave kernel
     u4 = {k: v for k, v in census.counts.items() if k.startswith("gemm_u4_kernel")}
     if B >= 30:   # SwiGLU backward joins at micro-batch 60 only (its rule wants <= 5 % of the last round idle: 5.375 rounds at 30, 10.75 at 60)
         assert len(u4) == (5 if B >= 60 else 4) and all(v > 0 for v in u4.values()), census.counts
     else:
-        assert not any(k.startswith("gemm_u4_kernel<1") or k.startswith("gemm_u4_kernel<2") or k.startswith("gemm_u4_kernel<3") for k in u4), census.counts
+        # M = 2184: RoPE (1.69 rounds) and SwiGLU' (1.51) stay on the 16-wave kernel; gate|up's whole tile rows behind the tail-row cut (2.69 rounds) may take the four-wave one
+        assert not any(k.startswith("gemm_u4_kernel<2") or k.startswith("gemm_u4_kernel<3") for k in u4), census.counts
     out_dir = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     open(os.path.join(out_dir, f"parity_micro_batch_{B}_kernels.txt"), "w").write(f"micro-batch {B}, 2 layers: persistent GEMM launches by kernel instantiation: {census.counts}\n")
