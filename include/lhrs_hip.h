@@ -175,15 +175,21 @@ int lhrs_gemm_set_u4(int on);
 int lhrs_gemm_u4_takes(int M, int N, int K, int lda, int ldb, int ldc, int ldr, int has_bias, int act, int out_f32, int accumulate, float alpha);
 int lhrs_gemm_u4_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
                     void* stream);
+/* ... + A2 . B2^T (the fused LoRA update of lhrs_gemm_bf16_nt_lora, K2 a multiple of 64) as K2 / 64 more stages of the same k-loop; lhrs_gemm_bf16_nt_lora takes
+ * it by the same shape rule (and the same row cut; the cut rows keep the pair on the small-tile kernels). */
+int lhrs_gemm_u4_nt_lora(const void* A, int lda, const void* B, int ldb, const void* A2, int lda2, const void* B2, int ldb2, int K2, void* C, int ldc,
+                         int M, int N, int K, const void* residual, int ldr, void* stream);
 /* the four-wave kernel with the decoder layer's fused epilogues (lhrs_gemm_rope_fwd / lhrs_gemm_swiglu_fwd / lhrs_gemm_swiglu_bwd semantics without a LoRA pair;
  * bit-identical to them): raw launches, 0 launched, 1 not its problem.  The three operator entry points above take it by the shape rule u4_fused_takes(kind, M, tile
- * columns, K, K2): no LoRA pair, K >= 4096, M >= 1024, tiles that fill >= 80 % of a round of the CUs with <= 15 % of the last round idle (kind 0 RoPE: tile columns
+ * columns, K, K2): a LoRA pair only with RoPE (u4_rope_lora: stage 3's q|k|v adapters; K2 a multiple of 64), K >= 4096, M >= 1024, tiles that fill >= 80 % of a round of the CUs with <= 15 % of the last round idle (kind 0 RoPE: tile columns
  * N / 256; kind 1 SwiGLU forward: ff / 128) or <= 5 % (kind 2 SwiGLU backward: ff / 256 - its write-out is VALU-bound on four waves and only wins on a whole-round walk).  u4_main_rows(M, N): rows of a plain product that go to the four-wave kernel when its last
  * round would be mostly empty (the rest: small tiles / split-K over the workspace); = M when nothing is cut. */
 int lhrs_gemm_u4_fused_takes(int kind, int M, int tiles_n, int K, int K2);
 int lhrs_gemm_u4_main_rows(int M, int N);
 int lhrs_gemm_u4_rope(const void* X, int ldx, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const float* cos_t,
                       const float* sin_t, int pos_mod, int pos0, int rope_cols, void* stream);
+int lhrs_gemm_u4_rope_lora(const void* X, int ldx, const void* W, int ldw, const void* A2, int lda2, const void* B2, int ldb2, int K2, void* C, int ldc,
+                           int M, int N, int K, const float* cos_t, const float* sin_t, int pos_mod, int pos0, int rope_cols, void* stream);
 int lhrs_gemm_u4_swiglu_fwd(const void* X, int ldx, const void* Wgu, int ldw, void* gu, int ld_gu, void* act, int ld_act, int M, int ff, int K,
                             void* stream);
 int lhrs_gemm_u4_swiglu_bwd(const void* dY, int ldy, const void* WdT, int ldw, const void* gu, void* dgu, int ld_gu, int M, int ff, int K,

@@ -326,7 +326,8 @@ __global__ __launch_bounds__(1024, 1) void gemm_nt_256s_kernel(GemmArgs g) {
   // piece - three VALU instructions in the MFMA stream for every DMA
   auto dma_piece = [&](const char* sp, unsigned vo, int buf, int j) {
     const unsigned lds_dst = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + buf * STAGE + dst0 + j * 1024;
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(sp), "s"(lds_dst) : "memory", "m0");
+    // the pointer goes through an SALU move: "VALU writes SGPR -> VMEM reads it" needs 5 wait states the compiler cannot pad inside asm (see gemm_u4.hip: U4_SPTR)
+    asm volatile("s_mov_b64 s[100:101], %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, s[100:101]" ::"v"(vo), "s"(sp), "s"(lds_dst) : "memory", "m0", "s100", "s101");
   };
   auto issue1 = [&](const unsigned (&o1)[4], int kt, int buf, int j) {  // stage kt < nk1 of the first pair
     const int kb_ = __builtin_amdgcn_readfirstlane(kt * (BK * 2));
@@ -1078,8 +1079,8 @@ extern "C" int lhrs_gemm_u4_takes(int M, int N, int K, int lda, int ldb, int ldc
 static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* bias,
                        const void* residual, int ldr, int act, int out_f32, int accumulate, float alpha, const void* A2,
                        int lda2, const void* B2, int ldb2, int K2, void* stream);
-// The fused-epilogue products (qkv + RoPE, gate|up + SwiGLU, d-down + SwiGLU') on the four-wave kernel: no LoRA pair in the k-loop (that lives in the 16-wave
-// kernel), K >= 4096, and tiles that fill the chip with at most `max_idle_pct` % of the last round idle - the four-wave kernel has one tile height and no tail-row
+// The fused-epilogue products (qkv + RoPE, gate|up + SwiGLU, d-down + SwiGLU') on the four-wave kernel: a LoRA pair in the k-loop only for RoPE (stage 3's
+// q|k|v adapters; the SwiGLU products with a pair live in the 16-wave kernel), K >= 4096, and tiles that fill the chip with at most `max_idle_pct` % of the last round idle - the four-wave kernel has one tile height and no tail-row
 // split for the fused epilogues.  RoPE and SwiGLU forward: 15 % (micro-batch 30: 6.0 / 10.75 rounds, micro-batch 60: 12 / 21.5: taken; the reference's micro-batch 8,
 // M = 2184: 1.69 / 3.02 rounds: the 16-wave kernels with their 144-row tiles and tail-row rules).  SwiGLU backward: 5 % - its write-out is VALU-bound on four waves
 // (the sigmoid of 256 elements per lane beside one stage of MFMAs), so it only wins where the tile walk fits: micro-batch 60 (10.75 rounds) 1261 us against the 16-wave
@@ -1089,10 +1090,14 @@ extern "C" int lhrs_gemm_u4_fused_takes(int kind, int M, int tiles_n, int K, int
   plain_env();
   const long P = num_cus(), T = (long)cdiv(M, 256) * tiles_n, R = (T + P - 1) / P * P;
   const long idle_ok = kind == 2 ? 100 * R <= 105 * T : 20 * R <= 23 * T;
-  return g_u4_on == 1 && K2 == 0 && K >= 4096 && K % 64 == 0 && M >= 1024 && 5 * T >= 4 * P && idle_ok;
+  return g_u4_on == 1 && (kind == 0 ? K2 % 64 == 0 : K2 == 0) && K >= 4096 && K % 64 == 0 && M >= 1024 && 5 * T >= 4 * P && idle_ok;
 }
 extern "C" int lhrs_gemm_u4_rope(const void* X, int ldx, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const float* cos_t, const float* sin_t,
                                  int pos_mod, int pos0, int rope_cols, void* stream);
+extern "C" int lhrs_gemm_u4_rope_lora(const void* X, int ldx, const void* W, int ldw, const void* A2, int lda2, const void* B2, int ldb2, int K2, void* C, int ldc,
+                                      int M, int N, int K, const float* cos_t, const float* sin_t, int pos_mod, int pos0, int rope_cols, void* stream);
+extern "C" int lhrs_gemm_u4_nt_lora(const void* A, int lda, const void* B, int ldb, const void* A2, int lda2, const void* B2, int ldb2, int K2, void* C, int ldc,
+                                    int M, int N, int K, const void* residual, int ldr, void* stream);
 extern "C" int lhrs_gemm_u4_swiglu_fwd(const void* X, int ldx, const void* Wgu, int ldw, void* gu, int ld_gu, void* act, int ld_act, int M, int ff, int K, void* stream);
 extern "C" int lhrs_gemm_u4_swiglu_bwd(const void* dY, int ldy, const void* WdT, int ldw, const void* gu, void* dgu, int ld_gu, int M, int ff, int K, void* stream);
 #define U4_FUSED_TRY(kind_, flopsN_, call_)                                                                          \
@@ -1119,40 +1124,56 @@ static int u4_main_rows(int M, long tiles_n) {
 }
 extern "C" int lhrs_gemm_u4_main_rows(int M, int N) { return u4_main_rows(M, cdiv(N, 256)); }
 
+// the plain-epilogue product on gemm_u4_kernel when the shape rule takes it (optionally with the LoRA pair in the k-loop): 0 done, 1 not taken, -1 error
+static int plain_u4_try(const void* A, int lda, const void* B, int ldb, const void* A2, int lda2, const void* B2, int ldb2, int K2, void* C, int ldc, int M, int N,
+                        int K, const void* bias, const void* residual, int ldr, int act, int out_f32, int accumulate, float alpha, void* stream) {
+  if (!lhrs_gemm_u4_takes(M, N, K, lda, ldb, ldc, residual ? ldr : 0, bias != nullptr, act, out_f32, accumulate, alpha) || t_drop.thresh != 0 ||
+      ((size_t)A | (size_t)B | (size_t)C | (size_t)residual | (size_t)A2 | (size_t)B2) % 16 != 0)
+    return 1;
+  hipStream_t s = (hipStream_t)stream;
+  const int Mu = u4_main_rows(M, cdiv(N, 256));
+  const int ukind = residual ? 5 : 6;
+  const int slot = prof_count(Mu, N, K + K2, ukind, s);
+  const int st = K2 > 0 ? lhrs_gemm_u4_nt_lora(A, lda, B, ldb, A2, lda2, B2, ldb2, K2, C, ldc, Mu, N, K, residual, ldr, stream)
+                        : lhrs_gemm_u4_nt(A, lda, B, ldb, C, ldc, Mu, N, K, residual, ldr, stream);
+  if (st == 0) {
+    prof_end(slot, s);
+    if (Mu == M) return 0;
+    const bf16_t* At = (const bf16_t*)A + (long)Mu * lda;
+    const bf16_t* Rt = residual ? (const bf16_t*)residual + (long)Mu * ldr : nullptr;
+    bf16_t* Ct = (bf16_t*)C + (long)Mu * ldc;
+    if (K2 == 0) {   // the split-K tail has no second operand pair: a product with one takes the small-tile kernels over its whole k-loop
+      const int ts = tail_rows_splitk(At, lda, (const bf16_t*)B, ldb, Ct, ldc, M - Mu, N, K, Rt, ldr, 1.f, s);
+      if (ts <= 0) return ts;
+    }
+    return gemm_launch(At, lda, B, ldb, Ct, ldc, M - Mu, N, K, nullptr, Rt, ldr, 0, 0, 0, 1.f, K2 > 0 ? (const bf16_t*)A2 + (long)Mu * lda2 : nullptr, lda2, B2, ldb2,
+                       K2, stream) ? -1 : 0;
+  }
+  if (st < 0) return st;
+  if (slot >= 0) { g_prof.used--; g_prof.seen[ukind]--; }   // not its problem after all (addressing limits): the slot goes back (it was the last one handed out)
+  if (g_prof.on) { g_prof.launches_all--; g_prof.total_flops_all -= 2.0 * Mu * N * (K + K2); }
+  return 1;
+}
+
 extern "C" int lhrs_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N,
                                  int K, const void* bias, const void* residual, int ldr, int act, int out_f32,
                                  int accumulate, float alpha, void* stream) {
-  if (lhrs_gemm_u4_takes(M, N, K, lda, ldb, ldc, residual ? ldr : 0, bias != nullptr, act, out_f32, accumulate, alpha) &&
-      ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0) && ((size_t)C % 16 == 0) && ((size_t)residual % 16 == 0)) {
-    hipStream_t s = (hipStream_t)stream;
-    const int Mu = u4_main_rows(M, cdiv(N, 256));
-    const int ukind = residual ? 5 : 6;
-    const int slot = prof_count(Mu, N, K, ukind, s);
-    const int st = lhrs_gemm_u4_nt(A, lda, B, ldb, C, ldc, Mu, N, K, residual, ldr, stream);
-    if (st == 0) {
-      prof_end(slot, s);
-      if (Mu == M) return 0;
-      const int ts = tail_rows_splitk((const bf16_t*)A + (long)Mu * lda, lda, (const bf16_t*)B, ldb, (bf16_t*)C + (long)Mu * ldc, ldc, M - Mu, N, K,
-                                      residual ? (const bf16_t*)residual + (long)Mu * ldr : nullptr, ldr, 1.f, s);
-      if (ts <= 0) return ts;
-      return gemm_launch((const bf16_t*)A + (long)Mu * lda, lda, B, ldb, (bf16_t*)C + (long)Mu * ldc, ldc, M - Mu, N, K, nullptr,
-                         residual ? (const bf16_t*)residual + (long)Mu * ldr : nullptr, ldr, 0, 0, 0, 1.f, nullptr, 0, nullptr, 0, 0, stream);
-    }
-    if (st < 0) return st;
-    if (slot >= 0) { g_prof.used--; g_prof.seen[ukind]--; }   // not its problem after all (addressing limits): the slot goes back (it was the last one handed out)
-    if (g_prof.on) { g_prof.launches_all--; g_prof.total_flops_all -= 2.0 * Mu * N * K; }
-  }
+  const int st = plain_u4_try(A, lda, B, ldb, nullptr, 0, nullptr, 0, 0, C, ldc, M, N, K, bias, residual, ldr, act, out_f32, accumulate, alpha, stream);
+  if (st <= 0) return st;
   return gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, out_f32, accumulate, alpha, nullptr, 0, nullptr, 0,
                      0, stream);
 }
 
 // C = alpha * (A.B^T + A2.B2^T) + bias + residual: the rank-K2 LoRA update rides in the k-loop of the base GEMM
-// (peft lora.Linear forward, y = W x + (alpha/r) B A x, reached from lhrs/models/text_modal.py:133-151).
+// (peft lora.Linear forward, y = W x + (alpha/r) B A x, reached from lhrs/models/text_modal.py:133-151).  The same shape rule as lhrs_gemm_bf16_nt decides
+// between gemm_u4_kernel and the 16-wave kernels (the pair adds K2 / 64 stages to either k-loop; the two are bit-identical).
 extern "C" int lhrs_gemm_bf16_nt_lora(const void* A, int lda, const void* B, int ldb, const void* A2, int lda2, const void* B2,
                                       int ldb2, int K2, void* C, int ldc, int M, int N, int K, const void* bias,
                                       const void* residual, int ldr, int out_f32, int accumulate, float alpha, void* stream) {
   LHRS_REQUIRE(A2 && B2 && K2 > 0 && K2 % 64 == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && lda2 >= K2 && ldb2 >= K2,
                "gemm_lora: bad second operand pair (K2=%d lda2=%d ldb2=%d)", K2, lda2, ldb2);
+  const int st = plain_u4_try(A, lda, B, ldb, A2, lda2, B2, ldb2, K2, C, ldc, M, N, K, bias, residual, ldr, 0, out_f32, accumulate, alpha, stream);
+  if (st <= 0) return st;
   return gemm_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, 0, out_f32, accumulate, alpha, A2, lda2, B2, ldb2, K2,
                      stream);
 }
@@ -1408,7 +1429,8 @@ extern "C" int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw
     return lhrs_rope(C, ldc, M, rope_cols / head_dim, head_dim, cos_t, sin_t, nullptr, pos_mod, pos0, 0, stream);
   }
   if (head_dim == 128 && rope_cols % 256 == 0 && lhrs_gemm_u4_fused_takes(0, M, cdiv(N, 256), K, K2))
-    U4_FUSED_TRY(9, N, lhrs_gemm_u4_rope(X, ldx, W, ldw, C, ldc, M, N, K, cos_t, sin_t, pos_mod, pos0, rope_cols, stream))
+    U4_FUSED_TRY(9, N, K2 > 0 ? lhrs_gemm_u4_rope_lora(X, ldx, W, ldw, A2, lda2, B2, ldb2, K2, C, ldc, M, N, K, cos_t, sin_t, pos_mod, pos0, rope_cols, stream)
+                              : lhrs_gemm_u4_rope(X, ldx, W, ldw, C, ldc, M, N, K, cos_t, sin_t, pos_mod, pos0, rope_cols, stream))
   GemmArgs g; memset(&g, 0, sizeof(g));
   g.A = (const bf16_t*)X; g.B = (const bf16_t*)W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = ldw; g.ldc = ldc;
   g.alpha = 1.f; g.A2 = (const bf16_t*)A2; g.B2 = (const bf16_t*)B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;

@@ -41,6 +41,9 @@ struct U4Args {
   int M, N, K, lda, ldb, ldc, ldr, tilesM, tilesN;
   const float* rope_cos; const float* rope_sin; int rope_mod, rope_pos0, rope_cols;   // EPI 3: columns [0, rope_cols) are heads of 128, tables [pos][64] f32
   int ff; const bf16_t* aux; bf16_t* aux_out; int ld_aux;                             // EPI 1: aux_out = act [M, ff] (ld_aux); EPI 2: aux = gate|up [M, 2 ff] (ld_aux)
+  // optional second operand pair, reduced in the same k-loop behind the first: out = A.B^T + A2.B2^T (the fused LoRA update: A2 = s * x * A_lora^T [M, K2], B2 = B_lora
+  // [N, K2]; peft lora.Linear, lhrs/models/text_modal.py:133-151).  K2 = 0: none.  Same rows, same tile image: only the DMA source of the last K2 / 64 stages changes
+  const bf16_t* A2; const bf16_t* B2; int lda2, ldb2, K2;
 };
 
 __device__ __forceinline__ void u4_tile(const U4Args& g, int t, int& tm, int& tn) {
@@ -126,22 +129,29 @@ __global__ __launch_bounds__(256, 1) void gemm_u4_kernel(U4Args g) {
   // waves 0,1 bring the activation rows of a stage, waves 2,3 the weight rows: 16 pieces of 8 rows x 128 B each, chunk-swizzled as gemm.hip's image
   const bool isA = wave < 2;
   const char* base = reinterpret_cast<const char*>(isA ? g.A : g.B);
-  const long ld = isA ? g.lda : g.ldb;
+  const char* base_p2 = reinterpret_cast<const char*>(isA ? g.A2 : g.B2);
+  const long ld_p1 = isA ? g.lda : g.ldb, ld_p2 = isA ? g.lda2 : g.ldb2;
   const int rmax = (isA ? g.M : (EPI == 1 ? 2 * g.ff : g.N)) - 1;
-  const int nk = g.K / BK;                                                             // >= 4 (host)
+  const int nk1 = g.K / BK;                                                            // >= 4 (host)
+  const int nk = nk1 + g.K2 / BK;                                                      // stages per tile: the first pair's, then the second pair's
   const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
   const int dst0 = (isA ? 0 : A_BYTES) + (wave & 1) * 16384;
   unsigned off[16];
-  auto offsets = [&](int tm, int tn) {
+  auto offsets = [&](int tm, int tn, bool pair2 = false) {
+    const long ld = pair2 ? ld_p2 : ld_p1;
+    // everything derived from the lane id comes from an opaque copy made HERE: otherwise those values are invariant across the three call sites (launch start, second
+    // pair, next tile), get hoisted in front of the tile loop and sit in registers all through the main loop (the write-out variants have none to spare)
+    int le = lane;
+    asm volatile("" : "+v"(le));
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const int lchunk = (lane & 7) ^ ((((j & 1) << 2) + (lane >> 4)) & 7);
+      const int lchunk = (le & 7) ^ ((((j & 1) << 2) + (le >> 4)) & 7);
       int row;
       if (isA) {
-        row = min(tm * BM + ((wave & 1) * 16 + j) * 8 + (lane >> 3), rmax);
+        row = min(tm * BM + ((wave & 1) * 16 + j) * 8 + (le >> 3), rmax);
       } else {
         // LDS row wn * 128 + ni * 16 + a of the weight tile holds column cw of the wave's 128 (see the header): ni = j / 2, a = (j & 1) * 8 + lane / 8
-        const int ni = j >> 1, a = ((j & 1) << 3) + (lane >> 3);
+        const int ni = j >> 1, a = ((j & 1) << 3) + (le >> 3);
         const int cw = (ni >> 2) * 64 + ((ni >> 1) & 1) * 32 + (a >> 2) * 8 + (ni & 1) * 4 + (a & 3);
         if (EPI == 1) row = (ni >> 2) * g.ff + tn * 128 + (wave & 1) * 64 + (cw & 63);   // [gate; up] weight: 64 gate + 64 up columns per wave
         else row = min(tn * BN + (wave & 1) * 128 + cw, rmax);
@@ -152,7 +162,7 @@ __global__ __launch_bounds__(256, 1) void gemm_u4_kernel(U4Args g) {
   auto issue = [&](int kt, int buf, int j) {
     const char* sp = base + (long)kt * (BK * 2);
     const unsigned lds_dst = lds0 + buf * STAGE + dst0 + j * 1024;
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off[j]), "s"(sp), "s"(lds_dst) : "memory", "m0");
+    asm volatile("s_mov_b64 s[100:101], %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, s[100:101]" ::"v"(off[j]), "s"(sp), "s"(lds_dst) : "memory", "m0", "s100", "s101");   // the pointer through an SALU move: see U4_SPTR below
   };
   const int wm = wave >> 1, wn = wave & 1;
   const int sw = ((lane & 15) >> 1) & 7;
@@ -185,8 +195,13 @@ __global__ __launch_bounds__(256, 1) void gemm_u4_kernel(U4Args g) {
 #define RDACC4(mi, ni, v, o) asm volatile("v_accvgpr_read_b32 %0, " AS_##mi##_##ni##_0 "\n v_accvgpr_read_b32 %1, " AS_##mi##_##ni##_1 "\n v_accvgpr_read_b32 %2, " AS_##mi##_##ni##_2 "\n v_accvgpr_read_b32 %3, " AS_##mi##_##ni##_3 : "=v"(v[o]), "=v"(v[o + 1]), "=v"(v[o + 2]), "=v"(v[o + 3]));
 // the s_nop: a VALU write to the data registers of a > 64-bit store needs two wait states behind it on gfx950 (the compiler's hazard recognizer cannot see into
 // asm statements, and the next thing the flush bodies do is read accumulators into those very registers)
-#define GST(voff_, data_, sptr_, imm_) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(voff_), "v"(data_), "s"(sptr_), "n"(imm_) : "memory")
-#define GLD(dst_, voff_, sptr_, imm_) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst_) : "v"(voff_), "s"(sptr_), "n"(imm_) : "memory")
+// Every scalar pointer of a VMEM instruction in these asm statements goes through an SALU move into s[100:101] first: "VALU writes SGPR -> VMEM reads that SGPR"
+// needs 5 wait states on gfx9, the hazard recognizer pads it for the compiler's own instructions only, and the register allocator is free to reload a spilled pointer
+// (v_readlane_b32) or make one uniform (v_readfirstlane_b32) right in front of an asm statement - the load / store then goes out with the OLD register contents
+// (round 5: memory access faults of the SwiGLU' variant once its pointers spilled).  SALU -> VMEM has no such hazard.  tools/check_asm_sgpr_hazard.py scans the ISA.
+#define U4_SPTR "s100", "s101"
+#define GST(voff_, data_, sptr_, imm_) asm volatile("s_mov_b64 s[100:101], %2\n\tglobal_store_dwordx4 %0, %1, s[100:101] offset:%3\n\ts_nop 1" ::"v"(voff_), "v"(data_), "s"(sptr_), "n"(imm_) : "memory", U4_SPTR)
+#define GLD(dst_, voff_, sptr_, imm_) asm volatile("s_mov_b64 s[100:101], %2\n\tglobal_load_dwordx4 %0, %1, s[100:101] offset:%3" : "=v"(dst_) : "v"(voff_), "s"(sptr_), "n"(imm_) : "memory", U4_SPTR)
 
   // ---- per-lane constants of the write-out: byte offset of (row wm * 128 + fr, column fg * 8 of the wave's columns) in C / aux; rows advance by 16 per mi (scalar) ----
   const int fr = lane & 15, fg = lane >> 4;
@@ -250,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void gemm_u4_kernel(U4Args g) {
     int kt = 0;
     // one DMA piece = an s_add on m0 behind one MFMA, the load behind the next: never more than two other instructions between two MFMAs
 #define M0P(p) if (p == 0) { asm volatile("s_mov_b32 m0, %0" ::"s"(lds0 + so + dst0) : "m0"); } else { asm volatile("s_add_u32 m0, m0, 0x400" ::: "m0", "scc"); }
-#define GLDS(p) asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(off[p]), "s"(sp2) : "memory")
+#define GLDS(p) asm volatile("s_mov_b64 s[100:101], %1\n\tglobal_load_lds_dwordx4 %0, s[100:101]" ::"v"(off[p]), "s"(sp2) : "memory", U4_SPTR)
 #define RDN(dst, ad, off_) RDQ(dst, ad, off_)
 #define STAGE_ADDRS                                                                                            \
       const unsigned so = (gs & 1) * STAGE, sn = so ^ STAGE;                                                   \
@@ -315,9 +330,13 @@ __global__ __launch_bounds__(256, 1) void gemm_u4_kernel(U4Args g) {
     // steady state: stage kt requests stage kt + 2 - of this tile, or (its last two stages) stages 0 and 1 of the next tile
     const int kend = has_next ? nk - ((NLOAD > 0 && interior) ? 1 : 0) : nk - 2;
     for (; kt < kend; ++kt, ++gs) {
-      if (kt == nk - 2) offsets(ntm, ntn);                      // this tile's rows are not needed any more: its last stage is in flight
+      // the stage requested here is stage kt + 2 of the stream: of this tile's first pair, of its second pair (from stage nk1 on), or stage 0 / 1 of the next tile -
+      // the lane offsets follow the (tile, pair) they address; the rows they replace are not needed any more (their last stage is in flight)
+      const int t2 = kt + 2;
+      if (t2 == nk1 && nk1 < nk) offsets(tm, tn, true);
+      if (t2 == nk) offsets(ntm, ntn);
       STAGE_ADDRS
-      const char* sp2 = base + (long)(kt + 2 < nk ? kt + 2 : kt + 2 - nk) * (BK * 2);
+      const char* sp2 = t2 < nk1 ? base + (long)t2 * (BK * 2) : t2 < nk ? base_p2 + (long)(t2 - nk1) * (BK * 2) : base + (long)(t2 - nk) * (BK * 2);
       wait16(A0, B0);
 #include "gemm_u4_body.inc"
     }
@@ -441,6 +460,16 @@ static bool u4_addressable(const void* A, int lda, const void* B, int ldb, const
          ((size_t)A | (size_t)B | (size_t)C) % 16 == 0 && (long)M * lda * 2 < (1L << 32) && (long)N * ldb * 2 < (1L << 32) &&      // 32-bit lane offsets of the operands
          (long)144 * ldc * 2 < (1L << 32);                                                                                           // ... and of a tile's output rows
 }
+// the optional second operand pair (fused LoRA update): rows of A2 / B2 as the rows of A / B; K2 a multiple of 64.  false: not addressable by this kernel
+struct U4Pair { const void* A2; int lda2; const void* B2; int ldb2; int K2; };
+static bool u4_pair(U4Args& g, const U4Pair* p, int rowsB) {
+  if (p == nullptr || p->K2 == 0) return true;
+  if (p->K2 < 0 || p->K2 % 64 != 0 || p->A2 == nullptr || p->B2 == nullptr || p->lda2 % 8 != 0 || p->ldb2 % 8 != 0 || p->lda2 < p->K2 || p->ldb2 < p->K2 ||
+      ((size_t)p->A2 | (size_t)p->B2) % 16 != 0 || (long)g.M * p->lda2 * 2 >= (1L << 32) || (long)rowsB * p->ldb2 * 2 >= (1L << 32))
+    return false;
+  g.A2 = (const bf16_t*)p->A2; g.B2 = (const bf16_t*)p->B2; g.lda2 = p->lda2; g.ldb2 = p->ldb2; g.K2 = p->K2;
+  return true;
+}
 static dim3 u4_grid(const U4Args& g) {
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
@@ -450,23 +479,34 @@ static dim3 u4_grid(const U4Args& g) {
 }
 
 // 0 launched; 1 not this kernel's problem (the caller takes gemm.hip's kernels); -1 error.  Plain epilogue: bf16 out, optional bf16 residual.
-extern "C" int lhrs_gemm_u4_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
-                               void* stream) {
+static int u4_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr, const U4Pair* pair,
+                 void* stream) {
   if (!u4_addressable(A, lda, B, ldb, C, ldc, M, N, K) || (residual != nullptr && (ldr % 8 != 0 || ldr < N || (size_t)residual % 16 != 0 || (long)144 * ldr * 2 >= (1L << 32))))
     return 1;
   U4Args g{};
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = (bf16_t*)C; g.res = (const bf16_t*)residual;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.tilesM = (M + 255) / 256; g.tilesN = (N + 255) / 256; g.rope_mod = 1;
+  if (!u4_pair(g, pair, N)) return 1;
   if (residual != nullptr) hipLaunchKernelGGL((gemm_u4_kernel<0, true>), u4_grid(g), dim3(256), 0, (hipStream_t)stream, g);
   else hipLaunchKernelGGL((gemm_u4_kernel<0, false>), u4_grid(g), dim3(256), 0, (hipStream_t)stream, g);
   LHRS_CHECK_LAUNCH("gemm_u4_nt");
   return 0;
 }
+extern "C" int lhrs_gemm_u4_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* residual, int ldr,
+                               void* stream) {
+  return u4_nt(A, lda, B, ldb, C, ldc, M, N, K, residual, ldr, nullptr, stream);
+}
+// ... + A2 . B2^T in the same k-loop (lhrs_gemm_bf16_nt_lora's semantics with a plain epilogue; bit-identical to the 16-wave kernel's fused pair)
+extern "C" int lhrs_gemm_u4_nt_lora(const void* A, int lda, const void* B, int ldb, const void* A2, int lda2, const void* B2, int ldb2, int K2, void* C, int ldc,
+                                    int M, int N, int K, const void* residual, int ldr, void* stream) {
+  const U4Pair p{A2, lda2, B2, ldb2, K2};
+  return u4_nt(A, lda, B, ldb, C, ldc, M, N, K, residual, ldr, &p, stream);
+}
 
 // q|k|v projection with RoPE in the epilogue (the semantics of lhrs_gemm_rope_fwd without a LoRA pair): columns [0, rope_cols) are heads of 128 rotated with
 // the position m % pos_mod + pos0 of their row, the rest stored as computed.  0 launched; 1 not this kernel's problem.
-extern "C" int lhrs_gemm_u4_rope(const void* X, int ldx, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const float* cos_t, const float* sin_t,
-                                 int pos_mod, int pos0, int rope_cols, void* stream) {
+static int u4_rope(const void* X, int ldx, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const float* cos_t, const float* sin_t,
+                   int pos_mod, int pos0, int rope_cols, const U4Pair* pair, void* stream) {
   if (!u4_addressable(X, ldx, W, ldw, C, ldc, M, N, K) || rope_cols % 256 != 0 || rope_cols > N || pos_mod < 16 || pos0 < 0 || cos_t == nullptr || sin_t == nullptr ||
       ((size_t)cos_t | (size_t)sin_t) % 16 != 0 || (long)(pos_mod + pos0) * 64 * 4 >= (1L << 31))
     return 1;
@@ -474,9 +514,19 @@ extern "C" int lhrs_gemm_u4_rope(const void* X, int ldx, const void* W, int ldw,
   g.A = (const bf16_t*)X; g.B = (const bf16_t*)W; g.C = (bf16_t*)C; g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = ldw; g.ldc = ldc;
   g.tilesM = (M + 255) / 256; g.tilesN = (N + 255) / 256;
   g.rope_cos = cos_t; g.rope_sin = sin_t; g.rope_mod = pos_mod; g.rope_pos0 = pos0; g.rope_cols = rope_cols;
+  if (!u4_pair(g, pair, N)) return 1;
   hipLaunchKernelGGL((gemm_u4_kernel<3, false>), u4_grid(g), dim3(256), 0, (hipStream_t)stream, g);
   LHRS_CHECK_LAUNCH("gemm_u4_rope");
   return 0;
+}
+extern "C" int lhrs_gemm_u4_rope(const void* X, int ldx, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const float* cos_t, const float* sin_t,
+                                 int pos_mod, int pos0, int rope_cols, void* stream) {
+  return u4_rope(X, ldx, W, ldw, C, ldc, M, N, K, cos_t, sin_t, pos_mod, pos0, rope_cols, nullptr, stream);
+}
+extern "C" int lhrs_gemm_u4_rope_lora(const void* X, int ldx, const void* W, int ldw, const void* A2, int lda2, const void* B2, int ldb2, int K2, void* C, int ldc,
+                                      int M, int N, int K, const float* cos_t, const float* sin_t, int pos_mod, int pos0, int rope_cols, void* stream) {
+  const U4Pair p{A2, lda2, B2, ldb2, K2};
+  return u4_rope(X, ldx, W, ldw, C, ldc, M, N, K, cos_t, sin_t, pos_mod, pos0, rope_cols, &p, stream);
 }
 
 // LLaMA MLP, forward half: gu [M, 2 ff] = X . Wgu^T (Wgu = [gate; up] weight [2 ff, K]) and act [M, ff] = silu(gate) * up in one launch (the semantics of

@@ -92,10 +92,15 @@ class gemm_kernel_census:
         return False
 
 
-def gemm_u4_nt(a, b, out, residual=None) -> bool:
-    """The raw launch of gemm_u4_kernel (tests, tools): True when launched, False when the problem is not its kind."""
-    st = _L().lhrs_gemm_u4_nt(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), a.shape[0], b.shape[0], a.shape[1],
-                              _p(residual), residual.stride(0) if residual is not None else 0, _stream())
+def gemm_u4_nt(a, b, out, residual=None, a2=None, b2=None) -> bool:
+    """The raw launch of gemm_u4_kernel (tests, tools): True when launched, False when the problem is not its kind.  a2 / b2: the fused LoRA pair."""
+    ldr = residual.stride(0) if residual is not None else 0
+    if a2 is not None:
+        st = _L().lhrs_gemm_u4_nt_lora(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0),
+                                       a2.shape[1], out.data_ptr(), out.stride(0), a.shape[0], b.shape[0], a.shape[1], _p(residual), ldr, _stream())
+    else:
+        st = _L().lhrs_gemm_u4_nt(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), a.shape[0], b.shape[0], a.shape[1],
+                                  _p(residual), ldr, _stream())
     if st < 0:
         _lib.check(st, "gemm_u4_nt")
     return st == 0

@@ -70,6 +70,43 @@ def test_gemm_u4_four_wave_kernel_bit_identical_to_the_16_wave_kernel(M, N, K, r
     assert not hk.gemm_u4_nt(a[:, :96] if K > 96 else a, b[:, :96] if K > 96 else b, out_u[:, :N])            # K % 64 != 0 / K < 128: declined
 
 
+@pytest.mark.parametrize("M,N,K,K2,res", [(8190, 4096, 4096, 64, True), (8190, 4096, 12288, 64, False), (8190, 12288, 4096, 128, False), (8736, 4096, 4096, 64, True),
+                                          (4095, 4104, 4096, 192, False), (1000, 1032, 256, 64, True)])
+def test_gemm_u4_lora_pair_in_the_k_loop_bit_identical_to_the_16_wave_kernel(M, N, K, K2, res):
+    """lhrs_gemm_u4_nt_lora: A2 . B2^T as K2 / 64 more stages of gemm_u4_kernel's k-loop (stage 3's q / k / v / o adapters: peft lora.Linear forward reached from
+    lhrs/models/text_modal.py:133-151) - the same k order and fp32 accumulation as the pair in gemm_nt_256s_kernel<.., K2P>: bit-identical without a residual,
+    one rounding closer to the fp32 sum with one; then lhrs_gemm_bf16_nt_lora under the shape rule (with the row cut of a mostly empty last round)."""
+    from lhrs_bot_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(M + 7 * N + K + K2)
+    a = bf(torch.randn(M, K, generator=g)).to(DEV)
+    b = bf(torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    a2_full = bf(torch.randn(M, K2 + 64, generator=g) * 2.0).to(DEV)
+    a2 = a2_full[:, :K2]                                                     # strided pair operand (the adapters' T / U buffers are padded to 64 columns)
+    b2 = bf(torch.randn(N, K2, generator=g) * 0.3).to(DEV)
+    r = bf(torch.randn(M, N, generator=g)).to(DEV) if res else None
+    out_u = torch.zeros(M, N + 16, device=DEV, dtype=torch.bfloat16)
+    assert hk.gemm_u4_nt(a, b, out_u[:, :N], residual=r, a2=a2, b2=b2)
+    out_h = hk.gemm_nt_lora(a, b, a2, b2, residual=r)                       # fixture: u4 off -> gemm.hip's kernels
+    ref = a.float() @ b.float().t() + a2.float() @ b2.float().t() + (r.float() if res else 0.0)
+    assert rel_err(out_h, ref) < 4e-3 and rel_err(out_u[:, :N], ref) < 4e-3
+    assert rel_err(out_u[:, :N], hk.gemm_nt(a, b, residual=r)) > 1e-2       # the pair is in there
+    big = M >= 2048 and N >= 4096 and not res
+    Mx = {(4095, 4104): 3840}.get((M, N), M)        # the 16-wave path cuts that product's rows too; its cut rows take base + update as two launches (two roundings)
+    assert torch.equal(out_u[:Mx, :N], out_h[:Mx]) if big else True
+    assert rel_err(out_u[:, :N], out_h) < 3e-3
+    assert float(out_u[:, N:].abs().max()) == 0.0
+    hk.gemm_set_u4(True)
+    out_p = hk.gemm_nt_lora(a, b, a2, b2, residual=r)
+    taken = hk.gemm_u4_takes(M, N, K, ldr=N if res else 0)
+    Mu = _lib.load().lhrs_gemm_u4_main_rows(M, N) if taken else M
+    assert taken == (K >= 4096 and M >= 1024) and Mu == {(8736, 4096): 8192, (4095, 4104): 3840}.get((M, N), M)
+    assert torch.equal(out_p[:Mu], out_u[:Mu, :N]) if taken else torch.equal(out_p, out_h)
+    assert rel_err(out_p[Mu:], ref[Mu:]) < 4e-3 if Mu < M else True          # the cut rows: the pair rides on the small-tile kernels
+    assert torch.equal(hk.gemm_nt_lora(a, b, a2, b2, residual=r), out_p)
+    hk.gemm_set_u4(False)
+    assert not hk.gemm_u4_nt(a, b, out_u[:, :N], a2=a2_full[:, :K2 + 32], b2=b2[:, :32].repeat(1, (K2 + 32) // 32))      # K2 % 64 != 0: declined
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("M,N,K", [(8190, 4096, 4096), (8190, 4096, 11008), (8190, 4096, 12288), (8190, 4096, 22016), (3822, 32000, 4096)])
 def test_gemm_u4_soak_200_launches_under_load_every_result_identical(M, N, K):
@@ -720,15 +757,22 @@ def test_gemm_fused_rope_bit_identical_to_unfused(M, S, pos0, lora):
     fr = torch.outer(torch.arange(512).float(), inv)
     cos, sin = fr.cos().to(DEV).contiguous(), fr.sin().to(DEV).contiguous()
     got = hk.gemm_rope_fwd(x, w, cos, sin, pos_mod=S, pos0=pos0, rope_cols=2 * d, head_dim=hd, a2=a2, b2=b2)
-    if not lora and M >= 1024:   # the four-wave kernel's RoPE variant (csrc/gemm_u4.hip: partners d / d + 64 in one lane): raw launch, then the operator path under the shape rule
+    if M >= 1024:   # the four-wave kernel's RoPE variant (csrc/gemm_u4.hip: partners d / d + 64 in one lane; the LoRA pair as more stages of its k-loop): raw launch, then the operator path under the shape rule
         from lhrs_bot_amd import _lib
         raw = torch.zeros_like(got)
-        assert _lib.load().lhrs_gemm_u4_rope(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), raw.data_ptr(), raw.stride(0), M, 3 * d, d, cos.data_ptr(),
-                                             sin.data_ptr(), S, pos0, 2 * d, torch.cuda.current_stream().cuda_stream) == 0
+        st = torch.cuda.current_stream().cuda_stream
+        if lora:
+            assert _lib.load().lhrs_gemm_u4_rope_lora(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), KP,
+                                                      raw.data_ptr(), raw.stride(0), M, 3 * d, d, cos.data_ptr(), sin.data_ptr(), S, pos0, 2 * d, st) == 0
+        else:
+            assert _lib.load().lhrs_gemm_u4_rope(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), raw.data_ptr(), raw.stride(0), M, 3 * d, d, cos.data_ptr(),
+                                                 sin.data_ptr(), S, pos0, 2 * d, st) == 0
         assert torch.equal(raw, got)
         hk.gemm_set_u4(True)
-        assert _lib.load().lhrs_gemm_u4_fused_takes(0, M, 3 * d // 256, d, 0) == 1
-        assert torch.equal(hk.gemm_rope_fwd(x, w, cos, sin, pos_mod=S, pos0=pos0, rope_cols=2 * d, head_dim=hd), got)
+        assert _lib.load().lhrs_gemm_u4_fused_takes(0, M, 3 * d // 256, d, KP if lora else 0) == 1
+        with hk.gemm_kernel_census() as census:
+            assert torch.equal(hk.gemm_rope_fwd(x, w, cos, sin, pos_mod=S, pos0=pos0, rope_cols=2 * d, head_dim=hd, a2=a2, b2=b2), got)
+        assert list(census.counts) == ["gemm_u4_kernel<3, false> RoPE"], census.counts
         hk.gemm_set_u4(False)
     ref = hk.gemm_nt_lora(x, w, a2, b2) if lora else hk.gemm_nt(x, w)
     plain = ref.clone()

@@ -47,6 +47,10 @@ def test_four_wave_kernel_wrappers_decline_before_touching_the_device():
     assert u4(A, 4096, B, 4096, C, 2048, 2048, 4096, 4096) == 1                               # ldc < N
     assert u4(A, 32768, B, 32768, C, 4096, 70000, 4096, 32768) == 1                           # operand beyond the 32-bit lane offsets (4 GiB)
     assert u4(A, 4096, B, 4096, C, 4096, 2048, 4096, 4096, 0x40000004, 4096) == 1             # residual not 8-B aligned
+    pair = lambda a2=0x70000000, lda2=64, b2=0x78000000, ldb2=64, K2=64, M=2048: lib.lhrs_gemm_u4_nt_lora(A, 4096, B, 4096, a2, lda2, b2, ldb2, K2, C, 4096, M, 4096,
+                                                                                                          4096, None, 0, None)
+    assert pair(K2=96) == 1 and pair(K2=-64) == 1 and pair(a2=None) == 1 and pair(b2=0x78000008) == 1        # the LoRA pair: K2 % 64, null / misaligned operands,
+    assert pair(lda2=60) == 1 and pair(ldb2=32) == 1 and pair(K2=128) == 1                                    # rows shorter than K2 or not 16-B multiples
     rope = lambda rope_cols, cos=0x50000000, sin=0x60000000, pos_mod=273: lib.lhrs_gemm_u4_rope(A, 4096, B, 4096, C, 12288, 2048, 12288, 4096, cos, sin, pos_mod,
                                                                                               0, rope_cols, None)
     assert rope(8192 + 128) == 1 and rope(16384) == 1 and rope(8192, cos=None) == 1 and rope(8192, pos_mod=0) == 1 and rope(8192, sin=0x60000004) == 1
