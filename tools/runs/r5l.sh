@@ -1,3 +1,4 @@
+# (experiments of 29 Sep: variant libraries built into tools/tmp_ab/ for one run, not kept)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r5l; mkdir -p $O
 for M in 16380 8190; do

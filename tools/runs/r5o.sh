@@ -1,3 +1,4 @@
+# (experiment of 29 Sep: gemm_u4_kernel<4,false> split-K tail against the shipped small-tile tail, built as tools/tmp_ab/liblhrs_hip_oldtail.so; code removed afterwards: profiles/r05_tail_rows_four_wave_splitk_ab.txt)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r5o; mkdir -p $O
 timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -k "splitk or tail_rows or four_wave_kernel_bit_identical or lora_pair" > $O/kernel_tests.txt 2>&1; tail -3 $O/kernel_tests.txt
