@@ -42,12 +42,15 @@ want_rope = hk.gemm_rope_fwd(x, w_qkv, cos, sin, pos_mod=273, pos0=0, rope_cols=
 want_gu, want_act = hk.gemm_swiglu_fwd(x, w_gu, ff)
 want_dgu = hk.gemm_swiglu_bwd(dy, w_dT, want_gu.clone(), ff)
 want_down = hk.gemm_nt(act, w_down)
+want_do = hk.gemm_nt(dy, w_o)
 hk.gemm_set_u4(True)
 out_o, out_qkv, gu, a_out, out_down = torch.empty_like(want_o), torch.empty_like(want_rope), torch.empty_like(want_gu), torch.empty_like(want_act), torch.empty_like(want_down)
 dgu = want_gu.clone()
+out_o2 = torch.empty_like(want_do)
 P = lambda t: t.data_ptr()
 runs = {
     "<0,true>  o + residual   K=4096 ": (lambda: lib.lhrs_gemm_u4_nt(P(x), d, P(w_o), d, P(out_o), d, M, d, d, P(res), d, st()), 2.0 * M * d * d, lambda: (out_o.float() - want_o.float()).abs().max().item() < 0.07),
+    "<0,false> d-o            K=4096 ": (lambda: lib.lhrs_gemm_u4_nt(P(dy), d, P(w_o), d, P(out_o2), d, M, d, d, None, 0, st()), 2.0 * M * d * d, lambda: torch.equal(out_o2, want_do)),
     "<0,false> down           K=11008": (lambda: lib.lhrs_gemm_u4_nt(P(act), ff, P(w_down), ff, P(out_down), d, M, d, ff, None, 0, st()), 2.0 * M * d * ff, lambda: torch.equal(out_down, want_down)),
     "<3,false> q|k|v + RoPE   K=4096 ": (lambda: lib.lhrs_gemm_u4_rope(P(x), d, P(w_qkv), d, P(out_qkv), 3 * d, M, 3 * d, d, P(cos), P(sin), 273, 0, 2 * d, st()), 2.0 * M * 3 * d * d, lambda: torch.equal(out_qkv, want_rope)),
     "<1,false> gate|up SwiGLU K=4096 ": (lambda: lib.lhrs_gemm_u4_swiglu_fwd(P(x), d, P(w_gu), d, P(gu), 2 * ff, P(a_out), ff, M, ff, d, st()), 2.0 * M * 2 * ff * d, lambda: torch.equal(gu, want_gu) and torch.equal(a_out, want_act)),
