@@ -4,7 +4,7 @@
 //   EPI 1  SwiGLU forward: gate|up + act = silu(gate) * up  (HF LlamaMLP)        EPI 2  SwiGLU backward: d(gate|up) = swiglu'(gate|up) * d_act
 //   EPI 3  RoPE on the q / k heads of the qkv projection (HF apply_rotary_pos_emb, rotate_half convention)
 //
-// Main loop (round 4; tools/gemm_u_proto/README.md): a 128x128 wave tile reads 256 B of LDS per MFMA instead of the 16-wave kernel's 512 B, four waves meet at a
+// Main loop (round 4; docs/design_notes_r03_r04.md): a 128x128 wave tile reads 256 B of LDS per MFMA instead of the 16-wave kernel's 512 B, four waves meet at a
 // barrier instead of sixteen, and with 512 registers per wave all fragments of a 32-k half sit in registers early enough to free the LDS buffer a fifth of the way
 // into a stage - the DMA of stage kt+2 then has 0.9-1.7 stages to land.  Accumulators are not C++ variables: every MFMA is an `asm volatile` naming its AGPR tuple
 // (gemm_u4_agpr.inc); the 128-MFMA stage body is generated (tools/gen_u4.py): fragment reads of the second 32-k half behind MFMAs 0..15, barrier X behind MFMA 21,

@@ -1,5 +1,5 @@
 """All-shape throughput of the e4m3 NT GEMM (lhrs_gemm_fp8_nt), with a check against the dequantised product on the first shape:
-   python tools/gemm_fp8_ab.py 30            # LHRS_HIP_LIB=... selects the build (tools/gemm_u_proto/fp8_256s_kernel.hip.inc was measured with it)
+   python tools/gemm_fp8_ab.py 30            # LHRS_HIP_LIB=... selects the build
    GEMM_ZERO=1: all-zero operands (no power limit: the schedule alone); GEMM_LORA=1: with a fused bf16 pair of K2 = 64"""
 import os
 import sys

@@ -4,7 +4,7 @@
     python tools/gen_u4.py flush2 > lhrs_bot_amd/csrc/gemm_u4_flush2.inc    the same, one unit = 4 fragments (RoPE, SwiGLU: a lane pairs column c with column c + 64)
     python tools/gen_u4.py last1 / last2                                    last stage of a tile whose flush wants operands from memory: the first FL_DEPTH units' loads ride in it
 
-Time line of a stage (tools/gemm_u_proto/README.md: u5; E = one DMA piece per 6 MFMAs):
+Time line of a stage (docs/design_notes_r03_r04.md: u5; E = one DMA piece per 6 MFMAs):
   slots 0..15   behind every MFMA one of the 16 fragment reads of this stage's second 32-k half
   slot  X = 21  lgkmcnt(0) + barrier: every wave has read the whole stage, its LDS buffer is free; the 16 DMA pieces of stage kt+2 follow (m0 update behind
                 one MFMA, the load behind the next)

@@ -1,4 +1,4 @@
-"""agpr.inc for the prototypes: the literal AGPR names of accumulator fragment (mi, ni) - AR_ (tuple), CL_ (clobber list), AS_ (single registers)."""
+"""gemm_u4_agpr.inc: the literal AGPR names of accumulator fragment (mi, ni) of gemm_u4_kernel - AR_ (tuple), CL_ (clobber list), AS_ (single registers)."""
 for mi in range(8):
     for ni in range(8):
         b = (mi * 8 + ni) * 4
