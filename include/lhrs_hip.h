@@ -105,7 +105,7 @@ int lhrs_gemm_rope_fwd(const void* X, int ldx, const void* W, int ldw, const voi
 int lhrs_dropout_bf16(const void* x, long ldx, void* out, long ldo, long rows, int cols, float p, unsigned seed, void* stream);
 int lhrs_gemm_bf16_nt_dropmask(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                                const void* residual, int ldr, float alpha, float p, unsigned seed, void* stream);
-/* persistent big-tile kernels (tuning / A-B tests): 0 never (small tiles only), non-zero = default */
+/* persistent big-tile kernels (tuning / A-B tests): 0 never (small tiles only: neither the 16-wave / 144-row kernels nor the four-wave gemm_u4_kernel), non-zero = default */
 int lhrs_gemm_set_policy(int allow_256);
 /* kernel A/B tests only: 0 disables the tail-row rule (a product whose last round of 256x256 tiles would be nearly empty is cut into
  * whole tile rows for the 16-wave kernel + the remaining rows for the small-tile kernel); default 1 */

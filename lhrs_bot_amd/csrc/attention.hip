@@ -28,6 +28,7 @@
 // No transposed copies exist in HBM.  K/V (or Q/dO) tiles are prefetched global->registers while the previous tile is
 // multiplied, then written to LDS behind one barrier (latency hidden behind the MFMAs).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -53,6 +54,7 @@ struct AttnArgs {
   const bf16_t* o_in;
   long ld_oin;
   float* delta_w;
+  int wide;  // resident kernels: result rows go out as 16-byte stores (store_row_wide); the host clears it when a row pointer would not be 16-byte aligned
 };
 
 constexpr float NEG_INF = -__builtin_huge_valf();
@@ -126,9 +128,12 @@ __device__ __forceinline__ void tr_wait(bf16x4 (&lo)[N], bf16x4 (&hi)[N]) {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]),
                    "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7]));
-  } else {
+  } else if constexpr (N == 4) {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+  } else {
+    static_assert(N == 2, "tr_wait: 2, 4 or 8 d-blocks");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(hi[0]), "+v"(hi[1]));
   }
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -160,19 +165,40 @@ __device__ __forceinline__ float group_sum(float v) {
 __device__ __forceinline__ void store4bf(bf16_t* p, const f32x4& v, float s) {
   *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v[0] * s, v[1] * s), pack2bf(v[2] * s, v[3] * s));
 }
+// One token row of a [16 x D] result as the lanes hold it (lane (fr, fg): DB blocks of the four dims db * 16 + fg * 4 + 0..3 of row fr) stored with 16-byte stores
+// (round 6).  Eight-byte stores - DB per lane, 32 B per row and instruction - made the epilogues store-ISSUE bound (MI355X_MICROARCH: "attention epilogue store tail").
+// v_permlane16_swap exchanges, between the blocks db and db + 1, the odd 16-lane rows of the first with the even rows of the second: afterwards lane fg = 0 / 2 holds
+// dims 0..7 / 8..15 of block db and lane fg = 1 / 3 those of block db + 1 - eight consecutive bf16 per lane, 64 contiguous bytes per row and instruction, half the
+// store instructions.  Same values, same rounding: bit-identical to store4bf per block.  `row` points at dim 0 of the row (16-byte aligned, D a multiple of 32).
+template <int DB>
+__device__ __forceinline__ void store_row_wide(bf16_t* row, const f32x4 (&v)[DB], float s, int fg) {
+#pragma unroll
+  for (int db = 0; db < DB; db += 2) {
+    const uint32_t a0 = pack2bf(v[db][0] * s, v[db][1] * s), a1 = pack2bf(v[db][2] * s, v[db][3] * s);
+    const uint32_t b0 = pack2bf(v[db + 1][0] * s, v[db + 1][1] * s), b1 = pack2bf(v[db + 1][2] * s, v[db + 1][3] * s);
+    const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+    *reinterpret_cast<uint4*>(row + (db + (fg & 1)) * 16 + (fg >> 1) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+  }
+}
 
 // d(q) / d(k) of one token row, as the lane holds it (DB f32x4 blocks: dims db * 16 + fg * 4 + 0..3), through the transpose of the rotary
 // embedding: the gradient of (x1 cos - x2 sin, x2 cos + x1 sin) is rope_pair with -sin.  The values are rounded to bf16 first, exactly
 // what the stand-alone kernel reads back from HBM: attention-backward + lhrs_rope(inverse) and this fused store agree bit for bit.
+template <int DB> struct RopeRow { float4 c[DB / 2], s[DB / 2]; };
 template <int DB>
-__device__ __forceinline__ void rope_bwd_inplace(f32x4 (&g)[DB], const AttnArgs& a, long token_row, int fg) {
+__device__ __forceinline__ void rope_row_load(RopeRow<DB>& rr, const AttnArgs& a, long token_row, int fg) {
   const int pos = (int)(token_row % a.rope_mod) + a.rope_pos0;
   const float* cs = a.rope_cos + (long)pos * (DB * 8) + fg * 4;
   const float* sn = a.rope_sin + (long)pos * (DB * 8) + fg * 4;
 #pragma unroll
+  for (int db = 0; db < DB / 2; ++db) { rr.c[db] = *reinterpret_cast<const float4*>(cs + db * 16); rr.s[db] = *reinterpret_cast<const float4*>(sn + db * 16); }
+}
+template <int DB>
+__device__ __forceinline__ void rope_row_apply(f32x4 (&g)[DB], const RopeRow<DB>& rr) {
+#pragma unroll
   for (int db = 0; db < DB / 2; ++db) {
-    const float4 c4 = *reinterpret_cast<const float4*>(cs + db * 16), s4 = *reinterpret_cast<const float4*>(sn + db * 16);
-    const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w};
+    const float cv[4] = {rr.c[db].x, rr.c[db].y, rr.c[db].z, rr.c[db].w}, sv[4] = {rr.s[db].x, rr.s[db].y, rr.s[db].z, rr.s[db].w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float o1, o2;
@@ -180,6 +206,12 @@ __device__ __forceinline__ void rope_bwd_inplace(f32x4 (&g)[DB], const AttnArgs&
       g[db][i] = o1; g[db + DB / 2][i] = o2;
     }
   }
+}
+template <int DB>
+__device__ __forceinline__ void rope_bwd_inplace(f32x4 (&g)[DB], const AttnArgs& a, long token_row, int fg) {
+  RopeRow<DB> rr;
+  rope_row_load<DB>(rr, a, token_row, fg);
+  rope_row_apply<DB>(g, rr);
 }
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
@@ -509,6 +541,25 @@ __device__ __forceinline__ int zigzag_group(int p, int wave, int G, bool descend
   return descending ? G - 1 - k : k;
 }
 
+// phase stamps for tools/attn_diag.py (a -DATTN_DIAG build only; compiled out of the product)
+#ifdef ATTN_DIAG
+__device__ unsigned long long* g_attn_dbg = nullptr;
+__device__ int g_attn_dbg_sel = 0;  // 0 forward, 1 dQ, 2 dK/dV
+#define DIAG_T(slot) do { if (g_attn_dbg && g_attn_dbg_sel == DIAG_KID && lane == 0) g_attn_dbg[((long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8 + (slot)] = wall_clock64(); } while (0)
+#define DIAG_DECL(id) constexpr int DIAG_KID = id; unsigned long long dg_t = 0, dg_acc[3] = {0, 0, 0}; int dg_units = 0
+#define DIAG_MARK() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); dg_t = wall_clock64(); } while (0)
+#define DIAG_ACC(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = wall_clock64(); dg_acc[k] += t_ - dg_t; dg_t = t_; } while (0)
+#define DIAG_UNITS(n) dg_units += (n)
+#define DIAG_FLUSH() do { if (g_attn_dbg && g_attn_dbg_sel == DIAG_KID && lane == 0) { unsigned long long* d_ = g_attn_dbg + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8; d_[2] = dg_acc[0]; d_[3] = dg_acc[1]; d_[5] = dg_acc[2]; d_[6] = dg_units; } } while (0)
+#else
+#define DIAG_T(slot) do { } while (0)
+#define DIAG_DECL(id)
+#define DIAG_MARK() do { } while (0)
+#define DIAG_ACC(k) do { } while (0)
+#define DIAG_UNITS(n) do { } while (0)
+#define DIAG_FLUSH() do { } while (0)
+#endif
+
 template <int D, bool CAUSAL>
 __global__ __launch_bounds__(512, 2) void attn_fwd_res_kernel(AttnArgs a) {
   constexpr int KS = D / 32, DB = D / 16, TILE = 64 * D * 2;
@@ -611,9 +662,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_res_kernel(AttnArgs a) {
     l = group_sum(l);
     if (qrow < q_len) {
       const float inv = l > 0.f ? 1.f / l : 0.f;
-      bf16_t* op = a.o + (long)(q_off + qrow) * a.ldo + h * D + fg * 4;
+      bf16_t* op = a.o + (long)(q_off + qrow) * a.ldo + h * D;
+      if (a.wide) store_row_wide<DB>(op, o, inv, fg);
+      else {
 #pragma unroll
-      for (int db = 0; db < DB; ++db) store4bf(op + db * 16, o[db], inv);
+        for (int db = 0; db < DB; ++db) store4bf(op + fg * 4 + db * 16, o[db], inv);
+      }
       if (a.lse && fg == 0) a.lse[(long)(seq * a.H + h) * a.LTq + qrow] = (l > 0.f) ? m * a.scale + __logf(l) : NEG_INF;
     }
   }
@@ -734,9 +788,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_res_kernel(AttnArgs a) {
 #pragma unroll
       for (int db = 0; db < DB; ++db) dq[db] *= a.scale;
       if (a.rope_cos != nullptr) rope_bwd_inplace<DB>(dq, a, (long)q_off + qrow, fg);
-      bf16_t* pq = a.dq + (long)(q_off + qrow) * a.ld_dq + h * D + fg * 4;
+      bf16_t* pq = a.dq + (long)(q_off + qrow) * a.ld_dq + h * D;
+      if (a.wide) store_row_wide<DB>(pq, dq, 1.f, fg);
+      else {
 #pragma unroll
-      for (int db = 0; db < DB; ++db) store4bf(pq + db * 16, dq[db], 1.f);
+        for (int db = 0; db < DB; ++db) store4bf(pq + fg * 4 + db * 16, dq[db], 1.f);
+      }
     }
   }
 }
@@ -752,20 +809,34 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_res_kernel(AttnArgs a) {
   const int q_off = ds[0], q_len = ds[1], kv_off = ds[2], kv_len = ds[3], kv_rows = ds[4], coff = ds[5];
   const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  DIAG_DECL(2);
+  DIAG_T(0);
   const int nq_tiles = (q_len + 63) >> 6;
-  res_load<D>(lds_q, a.q + (long)q_off * a.ldq + h * D, a.ldq, nq_tiles * 64, q_len, lane, wave);
-  res_load<D>(lds_do, a.dout + (long)q_off * a.ld_do + h * D, a.ld_do, nq_tiles * 64, q_len, lane, wave);
+  // Round 6.  (1) A last query tile with at most 32 rows (S = 273: 17) is a HALF tile: its rows 32..63 are neither loaded nor multiplied (their P and dS are zero:
+  // skipping the products changes no bit).  (2) The space that frees behind the Q image holds the row statistics lse | delta of the whole sequence (2 x LTq floats):
+  // round 5 read them from L2 / HBM in front of every tile - a dependent global round trip of 1-2 us per tile on a loaded chip, 2.8 us per tile against the forward
+  // kernel's 0.9 (tools/attn_diag.py) - now they are LDS reads behind the same barrier as the operands, read where they are used.  The host sends a sequence whose
+  // image leaves no room for them (more than 288 queries at head_dim 128) to the tiled kernel (dkv_res_fits).
+  const bool half_last = nq_tiles > 0 && q_len - (nq_tiles - 1) * 64 <= 32;
+  const int rows_alloc = nq_tiles * 64 - (half_last ? 32 : 0);
+  float* lds_lse = reinterpret_cast<float*>(smem + rows_alloc * D * 2);
+  float* lds_delta = lds_lse + a.LTq;
+  const float* lsebase = a.lse + (long)(seq * a.H + h) * a.LTq;
+  const float* deltabase = a.delta + (long)(seq * a.H + h) * a.LTq;
+  res_load<D>(lds_q, a.q + (long)q_off * a.ldq + h * D, a.ldq, rows_alloc, q_len, lane, wave);
+  res_load<D>(lds_do, a.dout + (long)q_off * a.ld_do + h * D, a.ld_do, rows_alloc, q_len, lane, wave);
+  for (int t = tid; t < a.LTq; t += 512) { lds_lse[t] = lsebase[t]; lds_delta[t] = deltabase[t]; }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  DIAG_T(1);
   TrAddr<D> tq, tdo;
   tq.init(lds_q, lane);
   tdo.init(lds_do, lane);
-  const float* lsebase = a.lse + (long)(seq * a.H + h) * a.LTq;
-  const float* deltabase = a.delta + (long)(seq * a.H + h) * a.LTq;
   const int G = (kv_rows + 15) >> 4;
   for (int p = 0;; ++p) {
     const int g = zigzag_group(p, wave, G, !CAUSAL);  // causal: low key groups see the most query tiles
     if (g < 0) break;
+    DIAG_MARK();
     const int key = g * 16 + fr;
     const int key_c = min(key, kv_rows - 1);
     const bf16_t* kp = a.k + (long)(kv_off + key_c) * a.ldk + h * D;
@@ -781,27 +852,33 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_res_kernel(AttnArgs a) {
     for (int i = 0; i < DB; ++i) { dk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     int i0 = 0;
     if (CAUSAL) i0 = max(0, (g * 16 - coff) >> 6);
+    DIAG_ACC(0);
+    DIAG_UNITS(nq_tiles - i0);
     for (int i = i0; i < nq_tiles; ++i) {
+      const bool hf = half_last && i == nq_tiles - 1;  // the half tile: query blocks 0, 1 and k-step 0 only
       const char* qt = lds_q + i * TILE;
       const char* dot = lds_do + i * TILE;
-      // the row statistics of the tile's 64 queries (HBM / L2; the LDS is full) are requested in FRONT of the tile's 32 S / dP MFMAs; their
-      // 32 registers are paid for by ONE set of transposed-operand registers below instead of two
-      f32x4 lq[4], dl[4];
-#pragma unroll
-      for (int qb = 0; qb < 4; ++qb) {
-        lq[qb] = *reinterpret_cast<const f32x4*>(lsebase + i * 64 + qb * 16 + fg * 4);
-        dl[qb] = *reinterpret_cast<const f32x4*>(deltabase + i * 64 + qb * 16 + fg * 4);
-      }
-      __builtin_amdgcn_sched_barrier(0);
       f32x4 s[4], dp[4];
 #pragma unroll
-      for (int qb = 0; qb < 4; ++qb) {
+      for (int qb = 0; qb < 2; ++qb) {
         s[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
         dp[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           s[qb] = MFMA(frag_rm<D>(qt, qb * 16 + fr, ks, fg), kf[ks], s[qb]);
           dp[qb] = MFMA(frag_rm<D>(dot, qb * 16 + fr, ks, fg), vf[ks], dp[qb]);
+        }
+      }
+      if (!hf) {
+#pragma unroll
+        for (int qb = 2; qb < 4; ++qb) {
+          s[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dp[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            s[qb] = MFMA(frag_rm<D>(qt, qb * 16 + fr, ks, fg), kf[ks], s[qb]);
+            dp[qb] = MFMA(frag_rm<D>(dot, qb * 16 + fr, ks, fg), vf[ks], dp[qb]);
+          }
         }
       }
       TrAddr<D> tqi, tdi;
@@ -811,32 +888,31 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_res_kernel(AttnArgs a) {
       // only a tile on the causal diagonal, past the last query or past the last key computes the mask (a wave-uniform test: this wave's keys
       // are g*16 .. g*16+15): the 16 index computations + compares + selects were a third of the loop's VALU work
       const bool full = (i + 1) * 64 <= q_len && g * 16 + 15 < kv_len && (!CAUSAL || g * 16 + 15 <= i * 64 + coff);
-      if (full) {
-#pragma unroll
-        for (int qb = 0; qb < 4; ++qb)
+      auto probs = [&](const int qb) {  // s[qb] <- P, dp[qb] <- dS of query block qb; its row statistics come out of the LDS here
+        const f32x4 lq = *reinterpret_cast<const f32x4*>(lds_lse + i * 64 + qb * 16 + fg * 4);
+        const f32x4 dl = *reinterpret_cast<const f32x4*>(lds_delta + i * 64 + qb * 16 + fg * 4);
+        if (full) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pv = __expf(s[qb][r] * a.scale - lq[qb][r]);
-            dp[qb][r] = pv * (dp[qb][r] - dl[qb][r]) * a.scale;
+            const float pv = __expf(s[qb][r] * a.scale - lq[r]);
+            dp[qb][r] = pv * (dp[qb][r] - dl[r]) * a.scale;
             s[qb][r] = pv;
           }
-      } else {
-#pragma unroll
-        for (int qb = 0; qb < 4; ++qb) {
+        } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int q = i * 64 + qb * 16 + fg * 4 + r;
             const bool ok = q < q_len && key < kv_len && (!CAUSAL || key <= q + coff);
-            const float pv = ok ? __expf(s[qb][r] * a.scale - lq[qb][r]) : 0.f;
-            dp[qb][r] = ok ? pv * (dp[qb][r] - dl[qb][r]) * a.scale : 0.f;
+            const float pv = ok ? __expf(s[qb][r] * a.scale - lq[r]) : 0.f;
+            dp[qb][r] = ok ? pv * (dp[qb][r] - dl[r]) * a.scale : 0.f;
             s[qb][r] = pv;
           }
         }
-      }
-      const bf16x8 p0 = pack_frag(s[0], s[1]), p1 = pack_frag(s[2], s[3]);
-      const bf16x8 d0 = pack_frag(dp[0], dp[1]), d1 = pack_frag(dp[2], dp[3]);
+      };
+      probs(0); probs(1);
       // one register set: the next transposed read goes out right behind the MFMAs that consume the previous one (an MFMA has read its
       // operands long before an LDS read returns) and its latency runs under those eight MFMAs
+      const bf16x8 p0 = pack_frag(s[0], s[1]), d0 = pack_frag(dp[0], dp[1]);
       tr_issue<D, 0>(tdi, alo, ahi);
       tr_wait<DB>(alo, ahi);
 #pragma unroll
@@ -847,25 +923,39 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_res_kernel(AttnArgs a) {
 #pragma unroll
       for (int db = 0; db < DB; ++db) dk[db] = MFMA(join(alo[db], ahi[db]), d0, dk[db]);
       __builtin_amdgcn_sched_barrier(0);
-      tr_issue<D, 1>(tdi, alo, ahi);
-      tr_wait<DB>(alo, ahi);
+      if (!hf) {
+        probs(2); probs(3);
+        const bf16x8 p1 = pack_frag(s[2], s[3]), d1 = pack_frag(dp[2], dp[3]);
+        tr_issue<D, 1>(tdi, alo, ahi);
+        tr_wait<DB>(alo, ahi);
 #pragma unroll
-      for (int db = 0; db < DB; ++db) dv[db] = MFMA(join(alo[db], ahi[db]), p1, dv[db]);
-      __builtin_amdgcn_sched_barrier(0);
-      tr_issue<D, 1>(tqi, alo, ahi);
-      tr_wait<DB>(alo, ahi);
+        for (int db = 0; db < DB; ++db) dv[db] = MFMA(join(alo[db], ahi[db]), p1, dv[db]);
+        __builtin_amdgcn_sched_barrier(0);
+        tr_issue<D, 1>(tqi, alo, ahi);
+        tr_wait<DB>(alo, ahi);
 #pragma unroll
-      for (int db = 0; db < DB; ++db) dk[db] = MFMA(join(alo[db], ahi[db]), d1, dk[db]);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int db = 0; db < DB; ++db) dk[db] = MFMA(join(alo[db], ahi[db]), d1, dk[db]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
+    RopeRow<DB> rr;
+    const bool rope = a.rope_cos != nullptr;
+    if (rope) rope_row_load<DB>(rr, a, (long)kv_off + key_c, fg);
+    DIAG_ACC(1);
     if (key < kv_rows) {
-      if (a.rope_cos != nullptr) rope_bwd_inplace<DB>(dk, a, (long)kv_off + key, fg);
-      bf16_t* pk = a.dk + (long)(kv_off + key) * a.ld_dk + h * D + fg * 4;
-      bf16_t* pv = a.dv + (long)(kv_off + key) * a.ld_dv + h * D + fg * 4;
+      if (rope) rope_row_apply<DB>(dk, rr);
+      bf16_t* pk = a.dk + (long)(kv_off + key) * a.ld_dk + h * D;
+      bf16_t* pv = a.dv + (long)(kv_off + key) * a.ld_dv + h * D;
+      if (a.wide) { store_row_wide<DB>(pk, dk, 1.f, fg); store_row_wide<DB>(pv, dv, 1.f, fg); }
+      else {
 #pragma unroll
-      for (int db = 0; db < DB; ++db) { store4bf(pk + db * 16, dk[db], 1.f); store4bf(pv + db * 16, dv[db], 1.f); }
+        for (int db = 0; db < DB; ++db) { store4bf(pk + fg * 4 + db * 16, dk[db], 1.f); store4bf(pv + fg * 4 + db * 16, dv[db], 1.f); }
+      }
     }
+    DIAG_ACC(2);
   }
+  DIAG_T(4);
+  DIAG_FLUSH();
 }
 
 // ---------------------------------------------------------------- delta = rowsum(dO * O)
@@ -920,6 +1010,13 @@ int check_common(const AttnArgs& a, int D, int nseq, const char* who) {
 }  // namespace
 
 // C ABI ------------------------------------------------------------------------------------------
+#ifdef ATTN_DIAG
+extern "C" int lhrs_attn_set_dbg(void* p, int sel) {
+  unsigned long long* v = (unsigned long long*)p;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_dbg_sel), &sel, sizeof(sel)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_dbg), &v, sizeof(v)) == hipSuccess ? 0 : -1;
+}
+#endif
 extern "C" int lhrs_seq_transpose(const void* in, long ld_in, void* out, int cols, int LT, const int* desc, int nseq,
                                   int use_kv, void* stream) {
   LHRS_REQUIRE(LT % 64 == 0 && cols > 0 && nseq > 0, "seq_transpose: LT=%d cols=%d nseq=%d", LT, cols, nseq);
@@ -937,6 +1034,7 @@ static int attn_fwd_impl(const void* q, long ldq, const void* k, long ldk, const
   if (key_mask != nullptr) max_kv = 1 << 30;  // the mask lives in the tiled kernel only
   a.q = (const bf16_t*)q; a.ldq = ldq; a.k = (const bf16_t*)k; a.ldk = ldk; a.v = (const bf16_t*)v; a.ldv = ldv;
   a.o = (bf16_t*)o; a.ldo = ldo; a.lse = lse; a.desc = desc; a.H = H; a.LTq = LTq; a.scale = scale;
+  a.wide = (ldo % 8 == 0 && (size_t)o % 16 == 0) ? 1 : 0;
   if (check_common(a, D, nseq, "attn_fwd")) return -1;
   const dim3 grid(cdiv(max_q, 64), H, nseq), blk(256);
   hipStream_t s = (hipStream_t)stream;
@@ -1011,12 +1109,15 @@ static int attn_bwd_impl(const void* q, long ldq, const void* k, long ldk, const
   }
   const bool rope = rope_cos != nullptr;
   const int rmax_ = D == 128 ? res_rows<128>() : res_rows<64>();
-  const bool fuse_rope = rope && max_kv <= rmax_ && max_q <= rmax_;  // both resident kernels run: the rotation rides in their stores
+  // the resident dK/dV kernel keeps lse | delta of the sequence behind its Q image (rows rounded up to 32): head_dim 128 up to 288 queries
+  const bool dkv_fits = max_q <= rmax_ && (long)((max_q + 31) / 32 * 32) * D * 2 + 2L * LTq * 4 <= (long)rmax_ * D * 2;
+  const bool fuse_rope = rope && max_kv <= rmax_ && dkv_fits;  // both resident kernels run: the rotation rides in their stores
   if (fuse_rope) { a.rope_cos = rope_cos; a.rope_sin = rope_sin; a.rope_mod = rope_mod; a.rope_pos0 = rope_pos0; }
   a.q = (const bf16_t*)q; a.ldq = ldq; a.k = (const bf16_t*)k; a.ldk = ldk; a.v = (const bf16_t*)v; a.ldv = ldv;
   a.dout = (const bf16_t*)dout; a.ld_do = ld_do; a.lse = (float*)lse; a.delta = delta;
   a.dq = (bf16_t*)dq; a.ld_dq = ld_dq; a.dk = (bf16_t*)dk; a.ld_dk = ld_dk; a.dv = (bf16_t*)dv; a.ld_dv = ld_dv;
   a.desc = desc; a.H = H; a.LTq = LTq; a.scale = scale;
+  a.wide = (ld_dq % 8 == 0 && ld_dk % 8 == 0 && ld_dv % 8 == 0 && ((size_t)dq | (size_t)dk | (size_t)dv) % 16 == 0) ? 1 : 0;
   if (check_common(a, D, nseq, "attn_bwd")) return -1;
   hipStream_t s = (hipStream_t)stream;
   const dim3 gq(cdiv(max_q, 64), H, nseq), gk(cdiv(max_kv, 64), H, nseq), blk(256);
@@ -1028,7 +1129,7 @@ static int attn_bwd_impl(const void* q, long ldq, const void* k, long ldk, const
     else { if (causal) hipLaunchKernelGGL((attn_bwd_dq_res_kernel<64, true>), rg, rb, 0, s, a); else hipLaunchKernelGGL((attn_bwd_dq_res_kernel<64, false>), rg, rb, 0, s, a); }
     dq_done = true;
   }
-  if (max_q <= rmax) {
+  if (dkv_fits) {
     if (D == 128) { if (causal) hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<128, true>), rg, rb, 0, s, a); else hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<128, false>), rg, rb, 0, s, a); }
     else { if (causal) hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<64, true>), rg, rb, 0, s, a); else hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<64, false>), rg, rb, 0, s, a); }
     dkv_done = true;

@@ -1062,6 +1062,7 @@ extern "C" int lhrs_gemm_u4_nt(const void* A, int lda, const void* B, int ldb, v
 static int g_u4_on = -1;
 static int prof_count(int M, int N, int K, int kind, hipStream_t s);
 static void prof_end(int slot, hipStream_t s);
+static void prof_undo(int slot, int kind, double flops);
 static void plain_env() {
   if (g_u4_on < 0) {
     const char* e = getenv("LHRS_GEMM_U4");
@@ -1073,14 +1074,14 @@ extern "C" int lhrs_gemm_set_u4(int on) { plain_env(); g_u4_on = on ? 1 : 0; ret
 extern "C" int lhrs_gemm_u4_takes(int M, int N, int K, int lda, int ldb, int ldc, int ldr, int has_bias, int act, int out_f32, int accumulate, float alpha) {
   plain_env();
   const long tiles = (long)cdiv(M, 256) * cdiv(N, 256);
-  return g_u4_on == 1 && !has_bias && act == 0 && !out_f32 && !accumulate && alpha == 1.f && K >= 4096 && K % 64 == 0 && M >= 1024 && N >= 1024 &&
+  return g_u4_on == 1 && g_gemm_allow_256 != 0 && !has_bias && act == 0 && !out_f32 && !accumulate && alpha == 1.f && K >= 4096 && K % 64 == 0 && M >= 1024 && N >= 1024 &&
          5 * tiles >= 4L * num_cus() && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && ldr % 8 == 0;
 }
 static int gemm_launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* bias,
                        const void* residual, int ldr, int act, int out_f32, int accumulate, float alpha, const void* A2,
                        int lda2, const void* B2, int ldb2, int K2, void* stream);
 // The fused-epilogue products (qkv + RoPE, gate|up + SwiGLU, d-down + SwiGLU') on the four-wave kernel: a LoRA pair in the k-loop only for RoPE (stage 3's
-// q|k|v adapters; the SwiGLU products with a pair live in the 16-wave kernel), K >= 4096, and tiles that fill the chip with at most `max_idle_pct` % of the last round idle - the four-wave kernel has one tile height and no tail-row
+// q|k|v adapters; the SwiGLU products with a pair live in the 16-wave kernel), K >= 4096, and a tile walk whose rounds leave at most 15 % (SwiGLU backward: 5 %) of the CU-rounds idle (idle share over ALL rounds, R / T <= 1.15) - the four-wave kernel has one tile height and no tail-row
 // split for the fused epilogues.  RoPE and SwiGLU forward: 15 % (micro-batch 30: 6.0 / 10.75 rounds, micro-batch 60: 12 / 21.5: taken; the reference's micro-batch 8,
 // M = 2184: 1.69 / 3.02 rounds: the 16-wave kernels with their 144-row tiles and tail-row rules).  SwiGLU backward: 5 % - its write-out is VALU-bound on four waves
 // (the sigmoid of 256 elements per lane beside one stage of MFMAs), so it only wins where the tile walk fits: micro-batch 60 (10.75 rounds) 1261 us against the 16-wave
@@ -1090,7 +1091,7 @@ extern "C" int lhrs_gemm_u4_fused_takes(int kind, int M, int tiles_n, int K, int
   plain_env();
   const long P = num_cus(), T = (long)cdiv(M, 256) * tiles_n, R = (T + P - 1) / P * P;
   const long idle_ok = kind == 2 ? 100 * R <= 105 * T : 20 * R <= 23 * T;
-  return g_u4_on == 1 && (kind == 0 ? K2 % 64 == 0 : K2 == 0) && K >= 4096 && K % 64 == 0 && M >= 1024 && 5 * T >= 4 * P && idle_ok;
+  return g_u4_on == 1 && g_gemm_allow_256 != 0 && (kind == 0 ? K2 % 64 == 0 : K2 == 0) && K >= 4096 && K % 64 == 0 && M >= 1024 && 5 * T >= 4 * P && idle_ok;
 }
 extern "C" int lhrs_gemm_u4_rope(const void* X, int ldx, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const float* cos_t, const float* sin_t,
                                  int pos_mod, int pos0, int rope_cols, void* stream);
@@ -1106,8 +1107,7 @@ extern "C" int lhrs_gemm_u4_swiglu_bwd(const void* dY, int ldy, const void* WdT,
     const int st_ = call_;                                                                                           \
     if (st_ == 0) { prof_end(pslot_, (hipStream_t)stream); return 0; }                                               \
     if (st_ < 0) return st_;                                                                                         \
-    if (pslot_ >= 0) { g_prof.used--; g_prof.seen[kind_]--; }                                                        \
-    if (g_prof.on) { g_prof.launches_all--; g_prof.total_flops_all -= 2.0 * M * (double)(flopsN_) * K; }             \
+    prof_undo(pslot_, kind_, 2.0 * M * (double)(flopsN_) * K);   /* declined (addressing limits): as if never counted */ \
   }
 
 static int tail_rows_splitk(const bf16_t* A, int lda, const bf16_t* B, int ldb, bf16_t* C, int ldc, int M_tail, int N, int K, const bf16_t* residual, int ldr,
@@ -1150,8 +1150,7 @@ static int plain_u4_try(const void* A, int lda, const void* B, int ldb, const vo
                        K2, stream) ? -1 : 0;
   }
   if (st < 0) return st;
-  if (slot >= 0) { g_prof.used--; g_prof.seen[ukind]--; }   // not its problem after all (addressing limits): the slot goes back (it was the last one handed out)
-  if (g_prof.on) { g_prof.launches_all--; g_prof.total_flops_all -= 2.0 * Mu * N * (K + K2); }
+  prof_undo(slot, ukind, 2.0 * Mu * N * (K + K2));   // not its problem after all (addressing limits): as if never counted
   return 1;
 }
 
@@ -1359,6 +1358,14 @@ static int prof_count(int M, int N, int K, int kind, hipStream_t s) {
 }
 static void prof_end(int slot, hipStream_t s) {
   if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], s);
+}
+// a launch prof_count counted was declined by its kernel wrapper: everything prof_count did is taken back - the slot (the last one handed out), the totals, and the
+// sampling phase seen[kind], which take() advanced exactly when a slot was free (whether or not this launch was the stride's sample)
+static void prof_undo(int slot, int kind, double flops) {
+  if (!g_prof.on) return;
+  g_prof.launches_all--; g_prof.total_flops_all -= flops;
+  if (slot >= 0) g_prof.used--;
+  if (slot >= 0 || g_prof.used < g_prof.cap) g_prof.seen[kind]--;
 }
 
 extern "C" int lhrs_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int ldw, const void* A2, int lda2, const void* B2, int ldb2,

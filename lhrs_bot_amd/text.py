@@ -646,19 +646,22 @@ class TextModal:
             out = [None if t is None else (t if not t.is_cuda else t.to("cpu", non_blocking=True)) for t in ts]
             torch.cuda.current_stream().synchronize()
             return out
-        # device -> PINNED staging buffers of this model (allocated once per shape), one synchronisation, then plain host copies of them: the runtime does not have to
-        # pin / stage / unpin pageable pages around an asynchronous copy at the start of every step
+        # device -> PINNED staging buffers of this model, one synchronisation, then plain host copies of them: the runtime does not have to pin / stage / unpin
+        # pageable pages around an asynchronous copy at the start of every step.  ONE flat pinned buffer per (argument slot, dtype), grown geometrically to the
+        # largest element count seen and viewed per call: ragged batches (every distinct (B, T)) do not accumulate page-locked memory
         cache = self.__dict__.setdefault("_ints_pinned", {})
         stage = []
         for i, t in enumerate(ts):
             if t is None or not t.is_cuda:
                 stage.append(None)
                 continue
-            key = (i, tuple(t.shape), t.dtype)
-            if key not in cache:
-                cache[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-            cache[key].copy_(t, non_blocking=True)
-            stage.append(cache[key])
+            key = (i, t.dtype)
+            n = t.numel()
+            if key not in cache or cache[key].numel() < n:
+                cache[key] = torch.empty(max(n, 2 * cache[key].numel() if key in cache else n), dtype=t.dtype, pin_memory=True)
+            view = cache[key][:n].view(t.shape)
+            view.copy_(t, non_blocking=True)
+            stage.append(view)
         torch.cuda.current_stream().synchronize()
         return [t if p is None else p.clone() for t, p in zip(ts, stage)]
 
