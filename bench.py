@@ -212,7 +212,17 @@ def timed_run(engine, batch, steps, warmup, world, lib, on_timed_start=None):
             if not bool(torch.isfinite(t).all()):
                 raise SystemExit(f"rank {os.environ.get('RANK', '0')}: non-finite {what} at step {nstep[0]} ({int((~torch.isfinite(t)).sum())} of {t.numel()})")
 
+    # LHRS_BENCH_IDLE_START_MS=x (soak runs, tools/soak_idle_queue.py): every step starts behind a DRAINED queue - device synchronise + x ms of sleep - the trigger
+    # round 5 found for the shared-device NaN, forced here without the device -> host copy that used to cause it
+    idle_ms = float(os.environ.get("LHRS_BENCH_IDLE_START_MS", "0") or 0)
+
+    def idle_start():
+        if idle_ms > 0:
+            torch.cuda.synchronize()
+            time.sleep(idle_ms * 1e-3)
+
     def step():
+        idle_start()
         out = engine(batch)
         if check:
             finite("loss", out["total_loss"])
@@ -347,6 +357,7 @@ def timed_run(engine, batch, steps, warmup, world, lib, on_timed_start=None):
         engine._h2d_log = h2d_log
         step0 = step
         def step():
+            idle_start()
             out = engine(batch)
             mark("loss", out["total_loss"])
             engine.backward(out["total_loss"])

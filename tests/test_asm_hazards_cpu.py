@@ -12,6 +12,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import check_asm_sgpr_hazard as chk  # noqa: E402
+import check_asm_load_wait as chk_wait  # noqa: E402
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
@@ -26,6 +27,25 @@ def test_scanner_flags_a_reloaded_pointer_in_front_of_an_asm_vmem(tmp_path):
     assert len(chk.scan(str(bad))) == 1 and chk.scan(str(ok)) == [] and chk.scan(str(padded)) == []
 
 
+def test_load_wait_scanner_replays_in_order_retirement(tmp_path):
+    """tools/check_asm_load_wait.py: a register of an asm-issued load may not be named before a counted vmcnt has retired the load (round 6)."""
+    load = "\t;;#ASMSTART\n\tglobal_load_dwordx4 v[10:13], v2, s[100:101] offset:64\n\t;;#ASMEND\n"
+    store = "\tglobal_store_dwordx4 v[30:31], v[40:43], off\n"
+    def run(body):
+        f = tmp_path / "k.s"
+        f.write_text("k:\n" + body + "\ts_endpgm\n")
+        return chk_wait.scan(str(f))
+    # two stores behind the load: vmcnt(2) retires it, vmcnt(3) does not
+    ok = run(load + store + store + "\ts_waitcnt vmcnt(2)\n\tv_add_f32 v1, v10, v1\n")
+    assert ok[0] == [] and ok[1] == 1
+    early = run(load + store + store + "\ts_waitcnt vmcnt(3)\n\tv_add_f32 v1, v10, v1\n")
+    assert len(early[0]) == 1
+    copied = run(load + "\tv_mov_b32 v50, v12\n" + store + "\ts_waitcnt vmcnt(0)\n")       # a register-allocator copy between load and wait
+    assert len(copied[0]) == 1
+    lds_dma = run("\t;;#ASMSTART\n\tglobal_load_lds_dwordx4 v6, s[100:101]\n\t;;#ASMEND\n\tv_mov_b32 v6, 0\n")   # LDS-DMA has no register destination
+    assert lds_dma[0] == []
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
 @pytest.mark.parametrize("src", ["gemm_u4.hip", "gemm.hip"])
@@ -37,3 +57,10 @@ def test_no_unpadded_valu_sgpr_write_in_front_of_an_asm_vmem(src, tmp_path):
     assert text.count("global_load_lds_dwordx4") > 30                      # the asm statements are in there
     bad = chk.scan(str(out))
     assert bad == [], "\n".join(f"{ln}: {t}  <- {wop} {st} wait state(s) earlier" for _, ln, _, t, wop, st in bad)
+    # the write-out's asm register loads (GLD) against the counted waits that release them (FL_WAITN): no copy, spill or early use in between
+    early, judged, _ = chk_wait.scan(str(out))
+    assert early == [], "\n".join(f"{ln}: {code}  <- load at line {lln} ({lcode}), {y} operation(s) behind it" for _, ln, _, code, lln, lcode, y in early)
+    if src == "gemm_u4.hip":
+        assert judged >= 100, judged   # the residual / SwiGLU' / RoPE write-outs are in there
+    ver = subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout
+    open(os.path.join(ROOT, "gpurun_out", f"asm_checks_{src}.txt"), "w").write(f"{src}: {judged} asm register loads judged, 0 early uses, 0 SGPR hazards; compiler:\n{ver}") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None
