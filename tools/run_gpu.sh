@@ -1,7 +1,4 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r6c; mkdir -p $O gpurun_out/soak
-timeout 1500 python -m pytest tests/test_parity_gpu.py -x -q -k "test_measured_micro_batches_end_to_end_vs_oracle and 8" > $O/pytest_parity8.txt 2>&1
-tail -8 $O/pytest_parity8.txt; cat gpurun_out/parity_micro_batch_8_projector_backward_alone.txt
-timeout 900 python tools/soak_idle_queue.py trainer 3000 > $O/soak_trainer.txt 2>&1; grep "soak trainer" $O/soak_trainer.txt || tail -5 $O/soak_trainer.txt
-timeout 900 python tools/soak_idle_queue.py bench1 2000 > $O/soak_bench1.txt 2>&1; tail -2 $O/soak_bench1.txt
-timeout 2400 python tools/soak_idle_queue.py share8 12 40 > $O/soak_share8.txt 2>&1; tail -2 $O/soak_share8.txt
-cat gpurun_out/soak/*_log.txt | tail -20
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r6e; mkdir -p $O
+timeout 900 python -m pytest tests/test_generate_gpu.py -x -q -k "chain" > $O/pytest_chain.txt 2>&1; tail -5 $O/pytest_chain.txt
+timeout 600 python bench.py --decode --weights fp8 --new-tokens 512 --steps 2 > $O/decode_fp8_chain.json 2>$O/err1.txt; cut -c1-330 $O/decode_fp8_chain.json
+LHRS_DECODE_CHAIN=0 timeout 600 python bench.py --decode --weights fp8 --new-tokens 512 --steps 2 > $O/decode_fp8_nochain.json 2>$O/err2.txt; cut -c1-330 $O/decode_fp8_nochain.json

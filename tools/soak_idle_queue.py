@@ -27,7 +27,7 @@ def trainer(iters):
     import torch
     import main_pretrain_stage1 as drv
     from lhrs.CustomTrainer.utils import ConfigDict
-    cfg = ConfigDict(dict(stage=1, batch_size=8, data_path="synthetic", epoch_len=iters, output=os.path.join(OUT, "trainer_out"), workers=0, inf_sampler=False, prompt_template="plain", gpus=0, local_rank=0, rank=0, world_size=1,
+    cfg = ConfigDict(dict(stage=1, batch_size=8, data_path="synthetic", epoch_len=iters, output=os.path.join(os.environ.get("TMPDIR", "/tmp"), "soak_trainer_out"), workers=0, inf_sampler=False, prompt_template="plain", gpus=0, local_rank=0, rank=0, world_size=1,
                           optimizer="adanp", lr=2e-4, wd=0.0, max_grad_norm=0.3, epochs=1, llama_layers=int(os.environ.get("SOAK_LAYERS", "4")), seed=322, bf16=True,
                           fp16=False, accumulation_steps=1, tune_rgb_bk=False, tune_rgb_pooler=True, tune_im_start=False, lora=dict(enable=False),
                           schedule=dict(name="cosine", min_lr=0.0, warmup_epochs=1, warmup_method="linear", warmup_factor=0.1),
