@@ -571,6 +571,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_res_kernel(AttnArgs a) {
   const int q_off = ds[0], q_len = ds[1], kv_off = ds[2], kv_len = ds[3], coff = ds[5];
   const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  DIAG_DECL(0);
+  DIAG_T(0);
   int kv_need = kv_len;
   if (CAUSAL) kv_need = max(0, min(kv_len, q_len + coff));
   const int rows = ((kv_need + 63) >> 6) << 6;
@@ -580,6 +582,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_res_kernel(AttnArgs a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  DIAG_T(1);
   TrAddr<D> tv;
   tv.init(lds_v, lane);
   const float c2 = a.scale * 1.4426950408889634f;  // scale * log2(e)
@@ -587,11 +590,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_res_kernel(AttnArgs a) {
   for (int p = 0;; ++p) {
     const int g = zigzag_group(p, wave, G, CAUSAL);
     if (g < 0) break;
+    DIAG_MARK();
     const int qrow = g * 16 + fr;
     const bf16_t* qp = a.q + (long)(q_off + min(qrow, q_len - 1)) * a.ldq + h * D;
     bf16x8 qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32 + fg * 8);
+    DIAG_ACC(0);
     float m = NEG_INF, l = 0.f;
     f32x4 o[DB];
 #pragma unroll
@@ -659,6 +664,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_res_kernel(AttnArgs a) {
 #pragma unroll
       for (int db = 0; db < DB; ++db) o[db] = MFMA(join(v1lo[db], v1hi[db]), p1, o[db]);
     }
+    DIAG_ACC(1);
+    DIAG_UNITS(ntiles);
     l = group_sum(l);
     if (qrow < q_len) {
       const float inv = l > 0.f ? 1.f / l : 0.f;
@@ -670,7 +677,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_res_kernel(AttnArgs a) {
       }
       if (a.lse && fg == 0) a.lse[(long)(seq * a.H + h) * a.LTq + qrow] = (l > 0.f) ? m * a.scale + __logf(l) : NEG_INF;
     }
+    DIAG_ACC(2);
   }
+  DIAG_T(4);
+  DIAG_FLUSH();
 }
 
 template <int D, bool CAUSAL>

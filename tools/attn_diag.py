@@ -55,11 +55,7 @@ def row(name, dlt):
 
 
 row("entry -> operands visible", t[:, :, 1] - t[:, :, 0])
-if which == "fwd":
-    row("first group", t[:, :, 2] - t[:, :, 1])
-    row("second group", t[:, :, 3] - t[:, :, 2])
-    row("third+ groups", t[:, :, 4] - t[:, :, 3])
-else:
+if True:
     row("groups' row loads (sum)", t[:, :, 2])
     row("tile loops (sum)", t[:, :, 3])
     row("epilogues (sum)", t[:, :, 5])
