@@ -435,12 +435,13 @@ KIND_DESC = {0: GEMM_KERNEL_DESC, 4: GEMM_144_DESC, 5: GEMM_U4_DESC, 6: GEMM_U4_
 def gemm_traffic(dom, B, scale_layers):
     """HBM-side bytes per launch of the dominant kernel: a PMC pass cannot run inside this process (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE are separate profiled runs of
     this same command); the committed summary of that pass on this tree is quoted, with its provenance, when it names the same kernel at the same micro-batch."""
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r05_gemm_traffic.json")))
-        if B == tj.get("micro_batch", 30) and scale_layers == 1.0 and KIND_NAMES[dom].startswith(tj["kernel_prefix"]):
-            return int(tj["traffic_bytes_per_launch"]), tj["bench_note"]
-    except Exception:  # noqa: BLE001
-        pass
+    for name in ("r06_gemm_traffic.json", "r05_gemm_traffic.json"):   # the newest committed pass first (the kernel is unchanged since round 5)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if B == tj.get("micro_batch", 30) and scale_layers == 1.0 and KIND_NAMES[dom].startswith(tj["kernel_prefix"]):
+                return int(tj["traffic_bytes_per_launch"]), tj["bench_note"].replace("r05_gemm_traffic.json", name)
+        except Exception:  # noqa: BLE001
+            pass
     return None, "not measured in this run (PMC passes are separate rocprofv3 runs; no committed pass for this kernel at this micro-batch)"
 
 

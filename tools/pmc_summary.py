@@ -38,7 +38,7 @@ if sys.argv[1] == "traffic":
                               "note": "the projector's fp32 master -> bf16 shadow cast reads 4 B and writes 2 B per parameter (79.9 M padded): FETCH_SIZE reports ~1/2 of the read bytes of a "
                                       "wide streaming read on gfx950, WRITE_SIZE the written bytes - so reads are doubled, writes taken as is"}
     res["traffic_bytes_per_launch"] = int(2 * res["fetch_size_kb_mean"] * 1024 + res["write_size_kb_mean"] * 1024)
-    res["bench_note"] = (f"bytes per launch of {want} from profiles/r05_gemm_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes of "
+    res["bench_note"] = (f"bytes per launch of {want} from profiles/{os.path.basename(out)}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes of "
                          "`bench.py --steps 1 --warmup 1` at the default micro-batch on this tree, mean over the launches of that kernel in the step), FETCH_SIZE doubled as "
                          "MI355X_MICROARCH.md prescribes for gfx950 and calibrated on a kernel of known byte count in the same run; memory-side L2 traffic, Infinity-Cache hits "
                          "included; NOT measured in this process")
