@@ -27,8 +27,9 @@ def test_bench_emits_the_contract_line():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and 0 < r["achieved"] < r["peak"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["launches_timed"] > 0
-    # HBM-side bytes per launch of the dominant kernel: quoted from the committed PMC pass (profiles/r05_gemm_traffic.json) when it names this kernel at this micro-batch
-    assert (r["traffic"] is None and "not measured in this run" in r["traffic_note"]) or (r["traffic"] > 0 and "profiles/r05_gemm_traffic.json" in r["traffic_note"])
+    # HBM-side bytes per launch of the dominant kernel: quoted from the committed PMC pass (profiles/r0N_gemm_traffic.json, the newest) when it names this kernel at this micro-batch
+    assert (r["traffic"] is None and "not measured in this run" in r["traffic_note"]) or (r["traffic"] > 0 and "_gemm_traffic.json" in r["traffic_note"])
+    assert "resident in HBM" in d["data_note"] and "reused by every step" in d["data_note"]
     assert d["ms_per_step_median"] > 0
     v = r["variants"]
     # one entry per kernel instantiation that ran (the names a rocprofv3 kernel trace lists); at the headline shape every fused-epilogue product runs the four-wave kernel
@@ -51,6 +52,11 @@ def test_bench_emits_the_contract_line():
     assert m8["value"] > 0 and m8["micro_batch_per_gpu"] == 8 and m8["roofline"]["bound"] == "mfma" and 0 < m8["roofline"]["frac"] < 1
     assert e["generate_bf16"]["value"] > 0 and e["generate_fp8"]["value"] > 0 and e["generate_bf16"]["new_tokens"] == 512
     assert e["generate_bf16"]["roofline"]["bound"] == "hbm" and 0 < e["generate_bf16"]["roofline"]["frac"] < 1
+    # BASELINE configs[3]'s per-GPU workload rides in the default line (round 6): LoRA r = 8 on q, k, v, o at micro-batch 32, its own timed region, per-instantiation table
+    assert "stage3_error" not in e, e
+    s3 = e["stage3_lora_r8_b32"]
+    assert s3["value"] > 0 and s3["micro_batch_per_gpu"] == 32 and s3["steps"] == 8 and 0 < s3["dominant_kernel_frac"] < 1 and s3["variants"]
+    assert d["config"]["stage3_lora_r8_b32"]["value"] == s3["value"]
 
 
 @pytest.mark.timeout(900)
