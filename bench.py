@@ -435,7 +435,7 @@ KIND_DESC = {0: GEMM_KERNEL_DESC, 4: GEMM_144_DESC, 5: GEMM_U4_DESC, 6: GEMM_U4_
 def gemm_traffic(dom, B, scale_layers):
     """HBM-side bytes per launch of the dominant kernel: a PMC pass cannot run inside this process (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE are separate profiled runs of
     this same command); the committed summary of that pass on this tree is quoted, with its provenance, when it names the same kernel at the same micro-batch."""
-    for name in ("r06_gemm_traffic.json", "r05_gemm_traffic.json"):   # the newest committed pass first (the kernel is unchanged since round 5)
+    for name in ("r06_gemm_traffic_b120.json", "r06_gemm_traffic.json", "r05_gemm_traffic.json"):   # the committed pass at THIS micro-batch, newest first (the kernel is unchanged since round 5)
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
             if B == tj.get("micro_batch", 30) and scale_layers == 1.0 and KIND_NAMES[dom].startswith(tj["kernel_prefix"]):
@@ -494,10 +494,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--micro-batch", type=int, default=60,
-                    help="samples per GPU per step.  60 since round 5 (M = 16380 = 64 tile rows: every decoder product walks whole rounds of the 256 CUs except d-down's "
-                         "10.75; 48 GB of saved activations of 288 GB); rounds 1-4 quoted 30, still reported as config.micro_batch_30; the reference script uses 8 on "
-                         "80 GB parts (Script/train_stage1.sh:11), reported as micro_batch_8 (DESIGN.md §4)")
+    ap.add_argument("--micro-batch", type=int, default=120,
+                    help="samples per GPU per step.  120 since the end of round 6 (M = 32760 = 128 tile rows of 256: every decoder product walks whole rounds of the 256 CUs "
+                         "except d-down's 21.5, the attention kernels' 3840 workgroups are 15 whole rounds, half the launch boundaries per sample of micro-batch 60: +1.2 % on "
+                         "one box; 98 GB of saved activations of 288 GB); round 5 and most of round 6 quoted 60, rounds 1-4 30 - both still reported as config.micro_batch_60 / "
+                         "micro_batch_30; the reference script uses 8 on 80 GB parts (Script/train_stage1.sh:11), reported as micro_batch_8 (DESIGN.md §4)")
     ap.add_argument("--caption-tokens", type=int, default=128)
     ap.add_argument("--llama-layers", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -679,14 +680,16 @@ def main():
                     res["config"]["micro_batch_8"] = {"value": round(sps8, 2), "unit": "samples/s", "ms_per_step": round(1e3 * r8["dt"] / 12, 3),
                                                       "roofline_frac": res["micro_batch_8"]["roofline"]["frac"],
                                                       "step_mfma_frac": res["micro_batch_8"]["step_mfma_frac"]}
-                if B != 30:   # the micro-batch rounds 1-4 quoted the headline on: continuity of the series
-                    r30 = timed_run(engine, make_batch(30, T, dev, seed=322), 8, 2, 1, lib)
-                    sps30 = 30 * 8 / r30["dt"]
-                    rb30 = roofline_block(r30["prof"], r30["kinds"], 8, 30, S, scale_layers)
-                    res["config"]["micro_batch_30"] = {"value": round(sps30, 2), "unit": "samples/s", "ms_per_step": round(1e3 * r30["dt"] / 8, 3),
-                                                       "roofline_frac": rb30["frac"], "kernel_instantiation": rb30["kernel_instantiation"],
-                                                       "step_mfma_frac": round(sps30 * f_alg(S) / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 else None,
-                                                       "variants": {k: v["frac"] for k, v in rb30["variants"].items()}}
+                for bb in (60, 30):   # the micro-batches earlier rounds quoted the headline on (round 5-6: 60, rounds 1-4: 30): continuity of the series
+                    if B == bb:
+                        continue
+                    rbb = timed_run(engine, make_batch(bb, T, dev, seed=322), 8, 2, 1, lib)
+                    spsbb = bb * 8 / rbb["dt"]
+                    rfb = roofline_block(rbb["prof"], rbb["kinds"], 8, bb, S, scale_layers)
+                    res["config"][f"micro_batch_{bb}"] = {"value": round(spsbb, 2), "unit": "samples/s", "ms_per_step": round(1e3 * rbb["dt"] / 8, 3),
+                                                          "roofline_frac": rfb["frac"], "kernel_instantiation": rfb["kernel_instantiation"],
+                                                          "step_mfma_frac": round(spsbb * f_alg(S) / (PEAK_BF16_TFLOPS * 1e12), 4) if scale_layers == 1.0 else None,
+                                                          "variants": {k: v["frac"] for k, v in rfb["variants"].items()}}
                 del engine
                 torch.cuda.empty_cache()
                 # one image, ~60-token prompt, 512 new tokens, greedy
