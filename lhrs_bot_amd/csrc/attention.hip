@@ -694,6 +694,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_res_kernel(AttnArgs a) {
   const int q_off = ds[0], q_len = ds[1], kv_off = ds[2], kv_len = ds[3], coff = ds[5];
   const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  DIAG_DECL(1);
+  DIAG_T(0);
   int kv_need = kv_len;
   if (CAUSAL) kv_need = max(0, min(kv_len, q_len + coff));
   const int rows = ((kv_need + 63) >> 6) << 6;
@@ -703,12 +705,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_res_kernel(AttnArgs a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  DIAG_T(1);
   TrAddr<D> tk;
   tk.init(lds_k, lane);
   const int G = (q_len + 15) >> 4;
   for (int p = 0;; ++p) {
     const int g = zigzag_group(p, wave, G, CAUSAL);
     if (g < 0) break;
+    DIAG_MARK();
     const int qrow = g * 16 + fr;
     const int qrow_c = min(qrow, q_len - 1);
     const bf16_t* qp = a.q + (long)(q_off + qrow_c) * a.ldq + h * D;
@@ -736,6 +740,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_res_kernel(AttnArgs a) {
       delta_q = a.delta[stat];
     }
     const float lse2 = a.lse[stat] * 1.4426950408889634f, c2 = a.scale * 1.4426950408889634f;
+    DIAG_ACC(0);
     f32x4 dq[DB];
 #pragma unroll
     for (int i = 0; i < DB; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -794,6 +799,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_res_kernel(AttnArgs a) {
 #pragma unroll
       for (int db = 0; db < DB; ++db) dq[db] = MFMA(join(k1lo[db], k1hi[db]), d1, dq[db]);
     }
+    DIAG_ACC(1);
+    DIAG_UNITS(ntiles);
     if (qrow < q_len) {
 #pragma unroll
       for (int db = 0; db < DB; ++db) dq[db] *= a.scale;
@@ -805,7 +812,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_res_kernel(AttnArgs a) {
         for (int db = 0; db < DB; ++db) store4bf(pq + fg * 4 + db * 16, dq[db], 1.f);
       }
     }
+    DIAG_ACC(2);
   }
+  DIAG_T(4);
+  DIAG_FLUSH();
 }
 
 template <int D, bool CAUSAL>

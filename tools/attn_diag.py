@@ -1,6 +1,6 @@
 """Phase timing of the resident attention kernels (a build with -DATTN_DIAG: tools/build_variant.sh d attention.hip "-DATTN_DIAG"; run with LHRS_HIP_LIB=.../liblhrs_d.so).
-python tools/attn_diag.py B fwd|dq|dkv.  Per wave the kernel stamps wall_clock64() (100 MHz): 0 entry, 1 operands visible, 4 exit; forward: 2 / 3 = first / second group done;
-backward: 2 = time in the groups' row loads (Q / dO / O or K / V), 3 = in the tile loops, 5 = in the epilogues (stores), 6 = tile units."""
+python tools/attn_diag.py B fwd|dq|dkv.  Per wave the kernel stamps wall_clock64() (100 MHz): 0 entry, 1 operands visible, 4 exit; 2 = time in the groups' row loads
+(Q / dO / O or K / V), 3 = in the tile loops, 5 = in the epilogues (stores), 6 = tile units.  profiles/r06_attention_phase_analysis.txt is a reading of its output."""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes
@@ -55,13 +55,12 @@ def row(name, dlt):
 
 
 row("entry -> operands visible", t[:, :, 1] - t[:, :, 0])
-if True:
-    row("groups' row loads (sum)", t[:, :, 2])
-    row("tile loops (sum)", t[:, :, 3])
-    row("epilogues (sum)", t[:, :, 5])
-    units = t[:, :, 6] * 100
-    row("tile units", units)
-    print(f"  per tile unit: {float(t[:, :, 3].sum() / units.sum()):.3f} us")
+row("groups' row loads (sum)", t[:, :, 2])
+row("tile loops (sum)", t[:, :, 3])
+row("epilogues (sum)", t[:, :, 5])
+units = t[:, :, 6] * 100
+row("tile units", units)
+print(f"  per tile unit: {float(t[:, :, 3].sum() / units.sum()):.3f} us")
 row("wave life", t[:, :, 4] - t[:, :, 0])
 first = wg_start < t0 + 3.0
 print(f"  first-round workgroups ({int(first.sum())}): life {float(life[first].mean()):.2f} us; later rounds: {float(life[~first].mean()):.2f} us")
