@@ -435,7 +435,7 @@ KIND_DESC = {0: GEMM_KERNEL_DESC, 4: GEMM_144_DESC, 5: GEMM_U4_DESC, 6: GEMM_U4_
 def gemm_traffic(dom, B, scale_layers):
     """HBM-side bytes per launch of the dominant kernel: a PMC pass cannot run inside this process (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE are separate profiled runs of
     this same command); the committed summary of that pass on this tree is quoted, with its provenance, when it names the same kernel at the same micro-batch."""
-    for name in ("r06_gemm_traffic_b120.json", "r06_gemm_traffic.json", "r05_gemm_traffic.json"):   # the committed pass at THIS micro-batch, newest first (the kernel is unchanged since round 5)
+    for name in ("r06_gemm_traffic_b240.json", "r06_gemm_traffic_b120.json", "r06_gemm_traffic.json", "r05_gemm_traffic.json"):   # the committed pass at THIS micro-batch, newest first (the kernel is unchanged since round 5)
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
             if B == tj.get("micro_batch", 30) and scale_layers == 1.0 and KIND_NAMES[dom].startswith(tj["kernel_prefix"]):
@@ -494,11 +494,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--micro-batch", type=int, default=120,
-                    help="samples per GPU per step.  120 since the end of round 6 (M = 32760 = 128 tile rows of 256: every decoder product walks whole rounds of the 256 CUs "
-                         "except d-down's 21.5, the attention kernels' 3840 workgroups are 15 whole rounds, half the launch boundaries per sample of micro-batch 60: +1.2 % on "
-                         "one box; 98 GB of saved activations of 288 GB); round 5 and most of round 6 quoted 60, rounds 1-4 30 - both still reported as config.micro_batch_60 / "
-                         "micro_batch_30; the reference script uses 8 on 80 GB parts (Script/train_stage1.sh:11), reported as micro_batch_8 (DESIGN.md §4)")
+    ap.add_argument("--micro-batch", type=int, default=240,
+                    help="samples per GPU per step.  240 since the end of round 6: 195 GB of saved activations, 245 GB of the 288 GB allocated at the peak "
+                         "(config.peak_hbm_allocated_gb) - the memory is there to be used, and every doubling halves the launch boundaries per sample and keeps the tile walks and "
+                         "the attention kernels' workgroups on whole rounds of the 256 CUs (M = 65520 = 256 tile rows; 7680 workgroups = 30 rounds): same-box 60 -> 120 +1.2 %, "
+                         "120 -> 240 +0.8 %.  Rounds 1-4 quoted 30, rounds 5-6 60 - reported next to the headline as config.micro_batch_120 / _60 / _30; the reference script uses 8 "
+                         "on 80 GB parts (Script/train_stage1.sh:11), reported as micro_batch_8 (DESIGN.md §4)")
     ap.add_argument("--caption-tokens", type=int, default=128)
     ap.add_argument("--llama-layers", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -596,6 +597,7 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
     final_loss = float(loss.item())
+    peak_gb = torch.cuda.max_memory_allocated(dev) / 1e9   # of the headline run (model + saved activations of one step), before the extras
     dp = None
     if getattr(engine, "_finite_trace", None):
         for lab, host_t, dev_t in getattr(engine, "_h2d_log", []):      # every pinned-staging upload of the run against its host source, now that everything has run
@@ -656,6 +658,7 @@ def main():
                        "optimizer": "adanp" if a.stage == 1 else "adamw", "stage": a.stage,
                        "lora": None if a.stage == 1 else ("r=8 on q,k,v,o, lora_dropout 0" if a.stage == 3 else "r=128 on all 7 linears, lora_dropout 0.05 (train mode)"),
                        "last_layer_rows": "supervised positions only (same loss and gradients; LHRS_TAIL_ROWS_ONLY=0 computes all)" if os.environ.get("LHRS_TAIL_ROWS_ONLY", "1") != "0" else "all",
+                       "peak_hbm_allocated_gb": round(peak_gb, 1),
                        "grad_allreduce": a.comm_dtype if world > 1 else "none",
                        "dist_backend": (torch.distributed.get_backend() if world > 1 else None), "data_parallel": dp,
                        "plain_long_k_products": plain_products_note(lib)},
@@ -669,6 +672,7 @@ def main():
             extra = {}
             try:  # the reference script's micro-batch (Script/train_stage1.sh:11), same engine, its own timed region
                 if B != 8:
+                    torch.cuda.empty_cache()
                     r8 = timed_run(engine, make_batch(8, T, dev, seed=322), 12, 3, 1, lib)
                     sps8 = 8 * 12 / r8["dt"]
                     res["micro_batch_8"] = {
@@ -680,9 +684,10 @@ def main():
                     res["config"]["micro_batch_8"] = {"value": round(sps8, 2), "unit": "samples/s", "ms_per_step": round(1e3 * r8["dt"] / 12, 3),
                                                       "roofline_frac": res["micro_batch_8"]["roofline"]["frac"],
                                                       "step_mfma_frac": res["micro_batch_8"]["step_mfma_frac"]}
-                for bb in (60, 30):   # the micro-batches earlier rounds quoted the headline on (round 5-6: 60, rounds 1-4: 30): continuity of the series
-                    if B == bb:
+                for bb in (120, 60, 30):   # the micro-batches earlier lines quoted the headline on (rounds 1-4: 30, rounds 5-6: 60, end of round 6: 120): continuity of the series
+                    if B == bb or bb > B:
                         continue
+                    torch.cuda.empty_cache()   # the headline step's buffers go back to the device before a smaller shape asks for its own
                     rbb = timed_run(engine, make_batch(bb, T, dev, seed=322), 8, 2, 1, lib)
                     spsbb = bb * 8 / rbb["dt"]
                     rfb = roofline_block(rbb["prof"], rbb["kinds"], 8, bb, S, scale_layers)

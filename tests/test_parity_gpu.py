@@ -355,11 +355,11 @@ def test_last_layer_on_supervised_rows_only_equals_every_row(ragged):
     assert model.text.last_hidden.shape[0] == B * S
 
 
-@pytest.mark.timeout(2400)
-@pytest.mark.parametrize("B", [8, 30, 60, 120])
+@pytest.mark.timeout(3000)
+@pytest.mark.parametrize("B", [8, 30, 120, 240])
 def test_measured_micro_batches_end_to_end_vs_oracle(B):
-    """The micro-batches bench.py measures - 8 (Script/train_stage1.sh:11), 30 / 60 (the bench defaults of rounds 1-4 / 5-6) and 120 (the default since
-    the end of round 6: M = 32760 = 128 tile rows) - at the
+    """The micro-batches bench.py measures - 8 (Script/train_stage1.sh:11, SURVEY §8(d) config 2), 30 (the bench default of rounds 1-4), 120 and 240 (the default since the end of round 6: M = 65520 = 256 tile rows;
+    60, the default of rounds 5-6, ran here through round 6: profiles/r06_gpu_suite_final.txt) - at the
     headline sequence length S = 273 with 2 decoder layers, default engine settings (persistent 256x256 GEMM at M = 2184 / 8190 with its
     tail-row rule, fused RoPE / SwiGLU epilogues, last layer on the supervised rows; 60 = the B = 60 line of DESIGN §4.1: 64 tile rows):
     loss, the ViT taps of EVERY sample, d loss / d image and all 87 projector gradients - each by rel-L2 of the difference, so a
