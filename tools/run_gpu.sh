@@ -1,8 +1,5 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r6relax; mkdir -p $O
-C=$PWD/lhrs_bot_amd/csrc
-for v in hip relax hip relax; do LHRS_HIP_LIB=$C/liblhrs_$v.so timeout 600 python bench.py --micro-batch 8 --steps 30 --warmup 5 --no-extra --no-cpu-baseline > $O/b8_$v.json 2>$O/err.txt; python - <<P
-import json
-r=json.loads([l for l in open("$O/b8_$v.json") if l.startswith("{")][-1])
-print("$v", r["value"], r["ms_per_step"], r["roofline"]["four_wave_kernel_share_of_gemm_time"], {k.split(">")[0][-20:]:(v["avg_launch_us"], v["frac"]) for k,v in r["roofline"]["variants"].items()})
-P
-done
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r6soak2; mkdir -p $O gpurun_out/soak
+SOAK_LAYERS=32 timeout 1500 python tools/soak_idle_queue.py trainer 2000 > $O/soak_trainer32.txt 2>&1; grep "soak trainer" $O/soak_trainer32.txt || tail -5 $O/soak_trainer32.txt
+LHRS_BENCH_IDLE_START_MS=0 timeout 2400 python tools/soak_idle_queue.py share8 30 40 > $O/soak_share8_noidle.txt 2>&1; tail -1 $O/soak_share8_noidle.txt
+timeout 2400 python tools/soak_idle_queue.py share8 30 40 > $O/soak_share8_idle.txt 2>&1; tail -1 $O/soak_share8_idle.txt
+grep -c "all finite" gpurun_out/soak/share8_log.txt; grep "FAIL" gpurun_out/soak/share8_log.txt | cut -c1-300
